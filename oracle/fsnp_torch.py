@@ -1,0 +1,191 @@
+"""TEST INFRASTRUCTURE ONLY - torch-CPU functional restatement of the forward.
+
+Same algorithm as oracle/fsnp_numpy.py but on the ATen / oneDNN / MKL CPU kernels the
+reference itself runs on (torch.nn.functional.conv1d / group_norm / prelu / linear and
+the fused ``torch.lstm``), so it is (a) fast enough for parity at BASELINE.json sizes
+and (b) the stand-in for "the reference CPU PyTorch path" that bench.py times as
+``cpu_baseline`` (kind "port") on the GPU box, where /root/reference does not exist.
+
+Pinned against tests/golden/*.npz (real-reference outputs) by tests/test_oracle.py.
+Citations relative to /root/reference/speech_enhance.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+EPSILON = float(np.finfo(np.float32).eps)  # audio_zen/constant.py:8
+TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)   # audio_zen/model/module/sequence_model.py:48-57
+
+
+def offline_laplace_norm(x):
+    """base_model.py:210-225"""
+    return x / (torch.mean(x, dim=(1, 2, 3), keepdim=True) + 1e-5)
+
+
+def offline_gaussian_norm(x):
+    """base_model.py:260-275"""
+    mu = torch.mean(x, dim=(1, 2, 3), keepdim=True)
+    std = torch.std(x, dim=(1, 2, 3), keepdim=True)
+    return (x - mu) / (std + 1e-5)
+
+
+def _cum_stats(x):
+    B, C, F, T = x.shape
+    y = x.reshape(B * C, F, T)
+    count = torch.arange(F, F * T + 1, F, dtype=x.dtype).reshape(1, T)
+    return y, count
+
+
+def cumulative_laplace_norm(x):
+    """base_model.py:227-258"""
+    y, count = _cum_stats(x)
+    mean = (torch.cumsum(y.sum(dim=1), dim=-1) / count).unsqueeze(1)
+    return (y / (mean + EPSILON)).reshape(x.shape)
+
+
+def cumulative_layer_norm(x):
+    """base_model.py:277-316"""
+    y, count = _cum_stats(x)
+    cum = torch.cumsum(y.sum(dim=1), dim=-1)
+    cum_pow = torch.cumsum(torch.square(y).sum(dim=1), dim=-1)
+    mean = cum / count
+    var = (cum_pow - 2 * mean * cum) / count + mean.pow(2)
+    std = torch.sqrt(var + EPSILON)
+    return ((y - mean.unsqueeze(1)) / std.unsqueeze(1)).reshape(x.shape)
+
+
+NORMS = {
+    "offline_laplace_norm": offline_laplace_norm,
+    "cumulative_laplace_norm": cumulative_laplace_norm,
+    "offline_gaussian_norm": offline_gaussian_norm,
+    "cumulative_layer_norm": cumulative_layer_norm,
+}
+
+
+def tsse(x, p, prefix):
+    """attention_model.py:78-98"""
+    C = x.shape[1]
+    feats = []
+    for nm in ("smallConv1d", "middleConv1d", "largeConv1d"):
+        y = Fn.conv1d(x, p[f"{prefix}.{nm}.0.weight"], p[f"{prefix}.{nm}.0.bias"], groups=C)
+        feats.append(torch.relu(y.mean(dim=2, keepdim=True)))
+    feature = torch.cat(feats, dim=2)
+    squeeze = Fn.linear(feature, p[f"{prefix}.feature_concate_fc.weight"],
+                        p[f"{prefix}.feature_concate_fc.bias"])[..., 0]
+    h = torch.relu(Fn.linear(squeeze, p[f"{prefix}.fc1.weight"], p[f"{prefix}.fc1.bias"]))
+    gate = torch.sigmoid(Fn.linear(h, p[f"{prefix}.fc2.weight"], p[f"{prefix}.fc2.bias"]))
+    return x * gate.unsqueeze(2)
+
+
+def tcn_block(x, p, prefix, dilation):
+    """causal_conv.py:96-108"""
+    Hc = p[prefix + ".conv1x1.weight"].shape[0]
+    y = Fn.conv1d(x, p[prefix + ".conv1x1.weight"], p[prefix + ".conv1x1.bias"])
+    y = Fn.group_norm(Fn.prelu(y, p[prefix + ".prelu1.weight"]), 1,
+                      p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], 1e-8)
+    y = Fn.conv1d(y, p[prefix + ".depthwise_conv.weight"], p[prefix + ".depthwise_conv.bias"],
+                  padding=dilation, dilation=dilation, groups=Hc)
+    y = Fn.group_norm(Fn.prelu(y, p[prefix + ".prelu2.weight"]), 1,
+                      p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"], 1e-8)
+    return x + Fn.conv1d(y, p[prefix + ".sconv.weight"], p[prefix + ".sconv.bias"])
+
+
+def _activation(x, name):
+    if not name:
+        return x
+    return {"ReLU": torch.relu, "ReLU6": Fn.relu6, "Tanh": torch.tanh}[name](x)
+
+
+def fb_sequence_model(x, p, prefix, activation="ReLU"):
+    """sequence_model.py:106-112"""
+    for i, d in enumerate(TCN_DILATIONS):
+        x = tcn_block(x, p, f"{prefix}.sequence_model.{i}", d)
+    x = torch.relu(x)
+    o = Fn.linear(x.permute(0, 2, 1), p[prefix + ".fc_output_layer.weight"], p[prefix + ".fc_output_layer.bias"])
+    return _activation(o, activation).permute(0, 2, 1)
+
+
+def lstm2_fc(x, p, prefix="sb_model", activation=False):
+    """sequence_model.py:113-123.  x [N,in,T] -> [N,out,T]."""
+    N = x.shape[0]
+    H = p[f"{prefix}.sequence_model.weight_hh_l0"].shape[1]
+    flat = []
+    for layer in (0, 1):
+        for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            flat.append(p[f"{prefix}.sequence_model.{nm}_l{layer}"])
+    seq = x.permute(0, 2, 1).contiguous()
+    h0 = torch.zeros(2, N, H, dtype=x.dtype)
+    o, _, _ = torch.lstm(seq, (h0, h0.clone()), flat, True, 2, 0.0, False, False, True)
+    o = Fn.linear(o, p[prefix + ".fc_output_layer.weight"], p[prefix + ".fc_output_layer.bias"])
+    return _activation(o, activation).permute(0, 2, 1).contiguous()
+
+
+def unfold(x, num_neighbor):
+    """base_model.py:15-47"""
+    B, C, F, T = x.shape
+    if num_neighbor < 1:
+        return x.permute(0, 2, 1, 3).reshape(B, F, C, 1, T)
+    n = num_neighbor
+    out = Fn.pad(x.reshape(B * C, 1, F, T), [0, 0, n, n], mode="reflect")
+    out = Fn.unfold(out, (2 * n + 1, T))
+    return out.reshape(B, C, 2 * n + 1, T, F).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def drop_band(x, num_groups=2):
+    """audio_zen/acoustics/feature.py:254-285"""
+    B, _, F, _ = x.shape
+    assert B > num_groups, f"Batch size = {B}, num_groups = {num_groups}."
+    if num_groups <= 1:
+        return x
+    if F % num_groups:
+        x = x[..., :F - F % num_groups, :]
+    return torch.cat([x[g::num_groups][:, :, g::num_groups, :] for g in range(num_groups)], dim=0)
+
+
+@torch.no_grad()
+def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighbors=15,
+            fb_num_neighbors=0, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
+            fb_output_activate_function="ReLU", sb_output_activate_function=False,
+            output_size=2, apply_drop_band=None, stages=None):
+    """fullsubnet_plus/model/fullsubnet_plus.py:122-209; see fsnp_numpy.forward."""
+    assert noisy_mag.dim() == 4
+    mag, real, imag = (Fn.pad(a, [0, look_ahead]) for a in (noisy_mag, noisy_real, noisy_imag))
+    B, C, F, T = mag.shape
+    assert C == 1
+    if norm_type not in NORMS:
+        raise NotImplementedError("You must set up a type of Norm.")
+    norm = NORMS[norm_type]
+    rec = (lambda k, v: stages.__setitem__(k, v)) if stages is not None else (lambda k, v: None)
+    outs = []
+    fb_in_mag = None
+    for tag, x, att, fb in (("mag", mag, "channel_attention", "fb_model"),
+                            ("real", real, "channel_attention_real", "fb_model_real"),
+                            ("imag", imag, "channel_attention_imag", "fb_model_imag")):
+        xin = tsse(norm(x).reshape(B, F, T), p, att)
+        rec(f"att_{tag}", xin)
+        if tag == "mag":
+            fb_in_mag = xin
+        o = fb_sequence_model(xin, p, fb, fb_output_activate_function)
+        rec(f"fb_{tag}", o)
+        outs.append(o.reshape(B, 1, F, T))
+    nfb, nsb = 2 * fb_num_neighbors + 1, 2 * sb_num_neighbors + 1
+    parts = [unfold(fb_in_mag.reshape(B, 1, F, T), sb_num_neighbors).reshape(B, F, nsb, T)]
+    parts += [unfold(o, fb_num_neighbors).reshape(B, F, nfb, T) for o in outs]
+    sb_input = norm(torch.cat(parts, dim=2))
+    rec("sb_input", sb_input)
+    drop = (B > 1) if apply_drop_band is None else apply_drop_band
+    Fo = F
+    if drop:
+        sb_input = drop_band(sb_input.permute(0, 2, 1, 3), num_groups_in_drop_band)
+        Fo = sb_input.shape[2]
+        sb_input = sb_input.permute(0, 2, 1, 3)
+    sb_input = sb_input.reshape(B * Fo, nsb + 3 * nfb, T)
+    sb_mask = lstm2_fc(sb_input, p, "sb_model", sb_output_activate_function)
+    sb_mask = sb_mask.reshape(B, Fo, output_size, T).permute(0, 2, 1, 3).contiguous()
+    return sb_mask[:, :, :, look_ahead:]
+
+
+def forward_full(p, mag, real, imag, **kw):
+    """"full" mode: every utterance keeps all bins == the reference run per utterance at
+    B=1 and stacked."""
+    return forward(p, mag, real, imag, apply_drop_band=False, **kw)

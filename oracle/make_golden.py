@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE ONLY - generate tests/golden/*.npz from the REAL reference.
+
+Run in the build container (needs /root/reference):
+
+    python -m oracle.make_golden            # writes tests/golden/*.npz
+
+Each fixture holds, for one (weights seed/profile, model args, input spec):
+  out     - the reference's fp32 forward output (FullSubNet_Plus.forward,
+            fullsubnet_plus/model/fullsubnet_plus.py:122-209), literal batched call
+            (so drop_band is active when B > 1);
+  out64   - the same module deep-copied to float64 (accuracy yard-stick), stored fp32;
+  full    - (B > 1 only) the reference called per utterance at B=1 and stacked
+            == "full" mode;
+  stages  - per-stage intermediates captured with forward hooks (small cases);
+  X       - the complex input spectrogram when it came from torch.stft.
+Inputs that come from ``make_spec`` are regenerated from the seed by the tests.
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_loader
+from .weights import make_inputs, make_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def make_spec(batch, frames, seed, num_freqs=257):
+    """Synthetic complex spectrogram with the memory layout torch.stft produces
+    ([B][T][F] order, real/imag interleaved): returns (mag, real, imag) [B,1,F,T] where
+    real/imag are strided views of one complex64 buffer (inferencer.py:142-147)."""
+    rng = np.random.Generator(np.random.PCG64(20_000 + seed))
+    env = (0.05 + rng.random(size=(batch, frames, 1))) * (0.2 + rng.random(size=(batch, 1, num_freqs)))
+    re = (env * rng.standard_normal(size=(batch, frames, num_freqs))).astype(np.float32)
+    im = (env * rng.standard_normal(size=(batch, frames, num_freqs))).astype(np.float32)
+    X = torch.complex(torch.from_numpy(re), torch.from_numpy(im)).permute(0, 2, 1)  # [B,F,T], strides (T*F,1,F)
+    return X.abs().unsqueeze(1), X.real.unsqueeze(1), X.imag.unsqueeze(1)
+
+
+CASES = [
+    # name, weights(seed, profile), args overrides, input(kind, B, T-or-seconds, seed), store stages?
+    dict(name="b1_2s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 2.0, 0), stages=False),
+    dict(name="b1_t24_default_stages", wseed=1, profile="default", args={}, inp=("spec", 1, 24, 1), stages=True),
+    dict(name="b1_t24_harsh_stages", wseed=2, profile="harsh", args={}, inp=("spec", 1, 24, 2), stages=True),
+    dict(name="b1_t8_min", wseed=3, profile="default", args={}, inp=("spec", 1, 8, 3), stages=False),
+    dict(name="b3_t20_harsh", wseed=4, profile="harsh", args={}, inp=("spec", 3, 20, 4), stages=False),
+    dict(name="b4_t16_default", wseed=5, profile="default", args={}, inp=("spec", 4, 16, 5), stages=False),
+    dict(name="b5_t16_default", wseed=6, profile="default", args={}, inp=("spec", 5, 16, 6), stages=False),
+    dict(name="b1_t30_cum_laplace", wseed=7, profile="default", args={"norm_type": "cumulative_laplace_norm"},
+         inp=("spec", 1, 30, 7), stages=True),
+    dict(name="b1_t30_gaussian", wseed=8, profile="default", args={"norm_type": "offline_gaussian_norm"},
+         inp=("spec", 1, 30, 8), stages=True),
+    dict(name="b1_t30_cum_layer", wseed=9, profile="default", args={"norm_type": "cumulative_layer_norm"},
+         inp=("spec", 1, 30, 9), stages=True),
+    dict(name="b3_t18_cum_layer", wseed=10, profile="harsh", args={"norm_type": "cumulative_layer_norm"},
+         inp=("spec", 3, 18, 10), stages=False),
+    dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
+         subsample_f=4),
+]
+
+
+SB_ROWS = [0, 1, 14, 15, 16, 128, 240, 241, 242, 255, 256]   # sub-bands kept from stage sb_input (B=1)
+
+
+def build_inputs(kind, B, t, seed):
+    if kind == "stft":
+        return make_inputs(B, t, seed)
+    return make_spec(B, t, seed)
+
+
+def run_case(case, FullSubNet_Plus):
+    args = dict(ref_loader.DEFAULT_MODEL_ARGS)
+    args.update(case["args"])
+    torch.manual_seed(0)
+    model = FullSubNet_Plus(**args).eval()
+    sd = make_state_dict(case["wseed"], case["profile"])
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    kind, B, t, iseed = case["inp"]
+    mag, real, imag = build_inputs(kind, B, t, iseed)
+
+    stages = {}
+    hooks = []
+    if case["stages"]:
+        def grab(name):
+            def fn(_m, _i, o):
+                stages[name] = (o[0] if isinstance(o, tuple) else o).detach().numpy().copy()
+            return fn
+        for nm, mod in (("att_mag", model.channel_attention), ("att_real", model.channel_attention_real),
+                        ("att_imag", model.channel_attention_imag), ("fb_mag", model.fb_model),
+                        ("fb_real", model.fb_model_real), ("fb_imag", model.fb_model_imag),
+                        ("tcn0_mag", model.fb_model.sequence_model[0]),
+                        ("lstm_hidden", model.sb_model.sequence_model)):
+            hooks.append(mod.register_forward_hook(grab(nm)))
+        hooks.append(model.sb_model.register_forward_pre_hook(
+            lambda _m, i: stages.__setitem__("sb_input", i[0].detach().numpy().copy())))
+
+    with torch.no_grad():
+        out = model(mag, real, imag).numpy()
+        for h in hooks:
+            h.remove()
+        m64 = copy.deepcopy(model).double()
+        out64 = m64(mag.double(), real.double(), imag.double()).numpy().astype(np.float32)
+        payload = dict(out=out, out64=out64)
+        if B > 1:
+            full = torch.cat([model(mag[b:b + 1], real[b:b + 1], imag[b:b + 1]) for b in range(B)], 0).numpy()
+            full64 = torch.cat([m64(mag[b:b + 1].double(), real[b:b + 1].double(), imag[b:b + 1].double())
+                                for b in range(B)], 0).numpy().astype(np.float32)
+            payload.update(full=full, full64=full64)
+    sub = case.get("subsample_f")
+    if sub:
+        for k in ("out", "out64", "full", "full64"):
+            if k in payload:
+                payload[k] = np.ascontiguousarray(payload[k][:, :, ::sub, :])
+    if kind == "stft" and mag.shape[-1] <= 200:
+        X = torch.complex(real[:, 0], imag[:, 0])            # [B,F,T]
+        payload["X"] = X.numpy()
+    if "lstm_hidden" in stages:                               # [N,T',H] is big: keep the last frame only
+        stages["lstm_hidden_last"] = stages.pop("lstm_hidden")[:, -1, :].copy()
+    if "sb_input" in stages:                                  # [N=B*F,34,T']: keep edge + centre sub-bands
+        stages["sb_input"] = stages["sb_input"][SB_ROWS].copy()
+    for k, v in stages.items():
+        payload["stage_" + k] = v.astype(np.float32)
+    meta = dict(name=case["name"], wseed=case["wseed"], profile=case["profile"], args=args,
+                inp=dict(kind=kind, B=B, t=t, seed=iseed), subsample_f=sub or 1,
+                torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
+                in_checksum=[float(mag.double().sum()), float(real.double().sum()), float(imag.double().sum())])
+    payload["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return payload, (sd, args, mag, real, imag)
+
+
+def main():
+    FullSubNet_Plus = ref_loader.load_reference()
+    assert ref_loader.reference_model_args() == ref_loader.DEFAULT_MODEL_ARGS, "inference.toml drifted"
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    from . import fsnp_numpy, fsnp_torch
+    only = set(sys.argv[1:])
+    for case in CASES:
+        if only and case["name"] not in only:
+            continue
+        payload, (sd, args, mag, real, imag) = run_case(case, FullSubNet_Plus)
+        path = os.path.join(GOLDEN_DIR, case["name"] + ".npz")
+        np.savez_compressed(path, **payload)
+        # cross-check both restatements right away (report only; tests enforce)
+        kw = dict(look_ahead=args["look_ahead"], sb_num_neighbors=args["sb_num_neighbors"],
+                  fb_num_neighbors=args["fb_num_neighbors"], norm_type=args["norm_type"],
+                  num_groups_in_drop_band=args["num_groups_in_drop_band"])
+        sub = case.get("subsample_f") or 1
+        ot = fsnp_torch.forward(sd, mag, real, imag, **kw).numpy()[:, :, ::sub, :]
+        scale = np.abs(payload["out"]).max()
+        msg = f"{case['name']:28s} out{payload['out'].shape} scale {scale:.3e} " \
+              f"ref32-vs-64 {np.abs(payload['out'] - payload['out64']).max() / scale:.2e} " \
+              f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e}"
+        if mag.shape[-1] <= 40:
+            sdn = {k: v.numpy() for k, v in sd.items()}
+            on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kw)
+            msg += f" numpy64-vs-ref64 {np.abs(on[:, :, ::sub, :] - payload['out64']).max() / scale:.2e}"
+        print(msg, f"[{os.path.getsize(path) / 1024:.0f} KB]", flush=True)
+
+
+if __name__ == "__main__":
+    main()

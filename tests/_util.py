@@ -1,0 +1,49 @@
+"""Shared helpers for the tests: golden-fixture loading and input regeneration."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle.make_golden import make_spec
+from oracle.weights import make_inputs, make_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.arrays = {k: z[k] for k in z.files if k != "meta"}
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.args = self.meta["args"]
+        self.sub = self.meta.get("subsample_f", 1)
+
+    def state_dict(self):
+        return make_state_dict(self.meta["wseed"], self.meta["profile"])
+
+    def inputs(self):
+        inp = self.meta["inp"]
+        if "X" in self.arrays:
+            X = torch.from_numpy(self.arrays["X"].transpose(0, 2, 1).copy()).permute(0, 2, 1)  # stft strides
+            return X.abs().unsqueeze(1), X.real.unsqueeze(1), X.imag.unsqueeze(1)
+        if inp["kind"] == "stft":
+            return make_inputs(inp["B"], inp["t"], inp["seed"])
+        return make_spec(inp["B"], inp["t"], inp["seed"])
+
+    def fwd_kwargs(self):
+        a = self.args
+        return dict(look_ahead=a["look_ahead"], sb_num_neighbors=a["sb_num_neighbors"],
+                    fb_num_neighbors=a["fb_num_neighbors"], norm_type=a["norm_type"],
+                    num_groups_in_drop_band=a["num_groups_in_drop_band"])
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,77 @@
+"""CPU tests: pin the oracle restatements (oracle/fsnp_numpy.py, oracle/fsnp_torch.py)
+against the golden vectors that oracle/make_golden.py produced from the REAL reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fsnp_numpy, fsnp_torch, ref_loader
+from tests._util import Golden, golden_names, rel_err
+
+SMALL = [n for n in golden_names() if "2s" not in n and "10s" not in n]
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_torch_port_matches_reference(name):
+    g = Golden(name)
+    mag, real, imag = g.inputs()
+    out = fsnp_torch.forward(g.state_dict(), mag, real, imag, **g.fwd_kwargs()).numpy()[:, :, ::g.sub, :]
+    assert out.shape == g.arrays["out"].shape
+    # same ATen kernels as the reference -> agreement far inside the 1e-3 budget
+    assert rel_err(out, g.arrays["out"]) < 2e-5
+    if "full" in g.arrays:
+        full = fsnp_torch.forward_full(g.state_dict(), mag, real, imag, **g.fwd_kwargs()).numpy()
+        assert rel_err(full[:, :, ::g.sub, :], g.arrays["full"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_numpy_fp64_matches_reference_fp64(name):
+    g = Golden(name)
+    mag, real, imag = (a.numpy() for a in g.inputs())
+    sd = {k: v.numpy() for k, v in g.state_dict().items()}
+    stages = {}
+    out = fsnp_numpy.forward(sd, mag, real, imag, dtype=np.float64, stages=stages, **g.fwd_kwargs())
+    # out64 is stored as fp32 -> 6e-8 quantisation
+    assert rel_err(out, g.arrays["out64"]) < 5e-7
+    for tag in ("att_mag", "att_real", "att_imag", "fb_mag", "fb_real", "fb_imag"):
+        if "stage_" + tag in g.arrays:
+            assert rel_err(stages[tag], g.arrays["stage_" + tag]) < 2e-4, tag
+
+
+@pytest.mark.parametrize("name", ["b4_t16_default", "b5_t16_default", "b3_t20_harsh"])
+def test_parity_mode_is_subselection_of_full(name):
+    """out_parity[r] = out_full[s][:, p:256:2, :]."""
+    g = Golden(name)
+    out, full = g.arrays["out"], g.arrays["full"]
+    B = full.shape[0]
+    n0 = (B + 1) // 2
+    scale = np.abs(full).max()
+    for r in range(B):
+        s, p = (2 * r, 0) if r < n0 else (2 * (r - n0) + 1, 1)
+        assert np.abs(out[r] - full[s][:, p:256:2, :]).max() < 2e-4 * scale
+
+
+def test_batch_two_raises_like_reference():
+    g = Golden("b4_t16_default")
+    mag, real, imag = g.inputs()
+    with pytest.raises(AssertionError):
+        fsnp_torch.forward(g.state_dict(), mag[:2], real[:2], imag[:2], **g.fwd_kwargs())
+
+
+def test_frozen_model_args_match_reference_toml():
+    if not ref_loader.reference_available():
+        pytest.skip("reference not present on this box")
+    assert ref_loader.reference_model_args() == ref_loader.DEFAULT_MODEL_ARGS
+
+
+def test_state_dict_matches_reference_parameter_tree():
+    if not ref_loader.reference_available():
+        pytest.skip("reference not present on this box")
+    cls = ref_loader.load_reference()
+    model = cls(**ref_loader.DEFAULT_MODEL_ARGS)
+    ref_sd = model.state_dict()
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(0)
+    assert set(sd) == set(ref_sd)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), k
+    assert sum(v.numel() for v in sd.values()) == 8_675_102
