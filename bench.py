@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py - STFT frames/s of the FullSubNet+ forward on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward of the hot path over one batch of synthetic utterances per GPU
+(BASELINE.json configs[1]: batch = 32 x 2 s clips, fp32, num_neighbors = 15, "full" mode = all 257
+bins for every utterance).  Weak scaling: every rank processes its own 32 utterances (configs[2] =
+256 utterances on 8 GPUs); utterances are independent, so there is NO collective in the data path.
+Inputs (the STFT of seeded noise, exactly the tensors the reference inferencer hands to the model,
+inferencer.py:142-147) are resident in HBM before the timed region; the STFT itself is outside it
+on both sides.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     - dominant kernel = fused sub-band LSTM: algorithmic FLOPs per launch / its average
+                 duration measured with hipEvents on the forward's own stream (inside libfsnp_hip).
+  cpu_baseline - oracle/fsnp_torch.py (torch-CPU restatement of the reference, kind "port") timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)" (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--mode", default="full", choices=["full", "parity"])
+    ap.add_argument("--norm", default="offline_laplace_norm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, inputs, budget_s, norm):
+    """Time the torch-CPU port of the reference forward on host cores, one utterance per call
+    (== "full" semantics), until the time budget is used."""
+    from oracle import fsnp_torch
+    mag, real, imag = inputs
+    threads = torch.get_num_threads()
+    T = mag.shape[-1]
+    fsnp_torch.forward_full(sd, mag[:1], real[:1], imag[:1], norm_type=norm)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    out0 = None
+    while done < mag.shape[0]:
+        o = fsnp_torch.forward_full(sd, mag[done:done + 1], real[done:done + 1], imag[done:done + 1], norm_type=norm)
+        if out0 is None:
+            out0 = o
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done * T / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} x 1-utterance forwards of the {T}-frame clips (oracle/fsnp_torch.py, "
+                      f"torch {torch.__version__} CPU, {threads} threads), {dt:.1f} s"}, out0
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from fullsubnet_plus_amd import FullSubNet_Plus
+    from oracle.ref_loader import DEFAULT_MODEL_ARGS
+    from oracle.weights import make_inputs, make_state_dict
+
+    model_args = {**DEFAULT_MODEL_ARGS, "norm_type": args.norm}
+    sd = make_state_dict(0, "default")
+    model = FullSubNet_Plus(**model_args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.batch_mode = args.mode
+
+    B = args.batch
+    cpu_in = make_inputs(B, args.seconds, 1000 + rank)           # synthetic, per-rank seed
+    gpu_in = []
+    for t in cpu_in:                                             # keep the stft strides on the device
+        g = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev)
+        g.copy_(t)
+        gpu_in.append(g)
+    T = cpu_in[0].shape[-1]
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        out = None
+        for _ in range(args.warmup):
+            out = model(*gpu_in)
+        if out is None:
+            out = model(*gpu_in)
+        sync_all()
+        model.set_timing(True)
+        model.get_timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(*gpu_in)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        timing = model.get_timing(reset=True)
+        model.set_timing(False)
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        # batch-split plumbing: gather every rank's masks once (outside the timed region)
+        g0 = time.perf_counter()
+        gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, out.contiguous())
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+    else:
+        gather_ms = None
+
+    frames_total = world * B * T * args.steps
+    value = frames_total / elapsed
+    rows = B * (model.num_freqs // 2 if (args.mode == "parity" and B > 1) else model.num_freqs)
+    Tp = T + model.look_ahead
+    from fullsubnet_plus_amd import _lib
+    lstm_flops = float(_lib.load().fsnp_lstm_flops(model._handle, rows, Tp))
+    lstm_ms = timing["lstm_ms"] / max(timing["count"], 1)
+    achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms > 0 else 0.0
+
+    result = {
+        "metric": "STFT frames/sec (257-bin, 2 s clips), FullSubNet+ forward",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
+                               f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)",
+                   "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)"},
+        "roofline": {"bound": "mfma", "kernel": "lstm2_fc_kernel<384,40,2>", "achieved": achieved,
+                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": None, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
+                     "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
+                     "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
+    }
+    if gather_ms is not None:
+        result["gather_ms"] = gather_ms
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        base, ref0 = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm)
+        result["cpu_baseline"] = base
+        if args.mode == "full":
+            got = out[:1].cpu()
+            result["cirm_max_abs_err"] = float((got - ref0).abs().max())
+            result["cirm_rel_err"] = float((got - ref0).abs().max() / ref0.abs().max())
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""ctypes binding of include/fsnp.h (cffi is not installed in this image; ctypes is stdlib)."""
+import ctypes
+import os
+
+from . import _build
+
+c_i32, c_i64, c_f32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p
+
+
+class FsnpConfig(ctypes.Structure):
+    """struct fsnp_config (include/fsnp.h)."""
+    _fields_ = [
+        ("num_freqs", c_i32), ("look_ahead", c_i32), ("sb_num_neighbors", c_i32), ("fb_num_neighbors", c_i32),
+        ("tcn_hidden", c_i32), ("num_tcn_blocks", c_i32), ("sb_hidden", c_i32), ("output_size", c_i32),
+        ("norm_type", c_i32), ("fb_act", c_i32), ("sb_act", c_i32), ("kersize", c_i32 * 3),
+        ("num_groups_in_drop_band", c_i32),
+    ]
+
+
+NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_gaussian_norm": 2,
+              "cumulative_layer_norm": 3}
+ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
+MODE_FULL, MODE_PARITY = 0, 1
+
+# every symbol include/fsnp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "fsnp_create": (c_i32, [ctypes.POINTER(FsnpConfig), ctypes.POINTER(c_vp)]),
+    "fsnp_destroy": (None, [c_vp]),
+    "fsnp_set_weight": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i64]),
+    "fsnp_commit_weights": (c_i32, [c_vp]),
+    "fsnp_num_weights": (c_i32, [c_vp]),
+    "fsnp_weight_info": (c_i32, [c_vp, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64)]),
+    "fsnp_workspace_bytes": (ctypes.c_size_t, [c_vp, c_i32, c_i32, c_i32]),
+    "fsnp_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64 * 3 * 3), c_vp, c_i32, c_i32, c_i32,
+                             c_i32, c_i32, c_vp]),
+    "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "fsnp_read_stage": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i64]),
+    "fsnp_set_timing": (c_i32, [c_vp, c_i32]),
+    "fsnp_get_timing": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_i64 * 3), c_i32]),
+    "fsnp_forward_flops": (ctypes.c_double, [c_vp, c_i32, c_i32, c_i32]),
+    "fsnp_lstm_flops": (ctypes.c_double, [c_vp, c_i64, c_i32]),
+    "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_last_error": (ctypes.c_char_p, []),
+    "fsnp_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """dlopen libfsnp_hip.so (building it first if the sources are newer) and type every entry point.
+    Raises if the extension cannot be built/loaded - the product path never degrades to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing and (not os.path.exists(path) or (_build.is_stale() and os.access(_build.HERE, os.W_OK))):
+        try:
+            _build.build()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -m fullsubnet_plus_amd._build`")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().fsnp_last_error().decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,249 @@
+// frontend.hip - input normalisation + TSSE channel attention for the three full-band branches.
+//
+// Replaces, for each of (mag, real, imag):
+//   functional.pad(look_ahead)                       fullsubnet_plus/model/fullsubnet_plus.py:137-139
+//   self.norm(x)                                     fullsubnet_plus.py:144,157,162  (base_model.py:210-330)
+//   ChannelTimeSenseSELayer.forward                  audio_zen/model/module/attention_model.py:78-98
+// (paths relative to /root/reference/speech_enhance).
+//
+// Pipeline (all tiny, HBM/latency bound):
+//   repack : strided [B,1,F,T] view (torch.stft layout or any other) -> raw[branch][utt][t][FP], zero padded
+//   frame  : per-frame (sum, sumsq) over F in fp64
+//   scan   : per utterance -> (m_t, d_t) for every frame, normalised = (x - m_t) / d_t   [all 4 norm types]
+//   fsum   : per-frequency sum over t of the normalised input, fp64 atomics
+//   gate   : TSSE squeeze + MLP.  conv -> AdaptiveAvgPool is linear, so
+//            mean_t(conv_K(x))[f] = sum_j w[f,j] * (S_f - prefix_j - suffix_{K-1-j}) / (T'-K+1) + b[f]
+//   apply  : att = normalised * gate[f]
+#include "fsnp_common.h"
+
+namespace fsnp {
+
+struct StridedIn {
+    const float* p[3];
+    long sb[3], sf[3], st[3];
+};
+
+__global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __restrict__ raw, int B, int T, int Tp,
+                                                        int F, int FP) {
+    __shared__ float tile[32][33];
+    const int branch = blockIdx.z / B, b = blockIdx.z % B;
+    const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ src = in.p[branch] + (long)b * in.sb[branch];
+    const long sF = in.sf[branch], sT = in.st[branch];
+    const bool f_fast = sF <= sT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        if (f_fast) {
+            const int f = f0 + tx, t = t0 + r;
+            tile[r][tx] = (f < F && t < T) ? src[f * sF + t * sT] : 0.0f;
+        } else {
+            const int t = t0 + tx, f = f0 + r;
+            tile[tx][r] = (f < F && t < T) ? src[f * sF + t * sT] : 0.0f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        const int t = t0 + r, f = f0 + tx;
+        if (t < Tp && f < FP) raw[(((long)branch * B + b) * Tp + t) * FP + f] = tile[r][tx];
+    }
+}
+
+// one wave per (branch, utt, t)
+__global__ __launch_bounds__(64) void fe_frame_kernel(const float* __restrict__ raw, double* __restrict__ frame, int B,
+                                                      int Tp, int F, int FP) {
+    const long row = ((long)blockIdx.z * B + blockIdx.y) * Tp + blockIdx.x;
+    const float* __restrict__ p = raw + row * FP;
+    double s = 0.0, q = 0.0;
+    for (int f = threadIdx.x; f < F; f += 64) {
+        const double v = p[f];
+        s += v;
+        q += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (threadIdx.x == 0) { frame[row * 2] = s; frame[row * 2 + 1] = q; }
+}
+
+// EPSILON of audio_zen/constant.py:8 == np.finfo(np.float32).eps
+#define FSNP_EPS 1.1920928955078125e-07f
+
+// Turn running (sum, sumsq, count) into (m, d) for the four norm types (base_model.py:210-316).
+__device__ __forceinline__ NormMD norm_md(int norm_type, double sum, double sq, double count) {
+    NormMD r;
+    const double mean = sum / count;
+    if (norm_type == FSNP_NORM_OFFLINE_LAPLACE) {
+        r.m = 0.0f;
+        r.d = (float)mean + 1e-5f;
+    } else if (norm_type == FSNP_NORM_CUMULATIVE_LAPLACE) {
+        r.m = 0.0f;
+        r.d = (float)mean + FSNP_EPS;
+    } else if (norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
+        double var = (sq - count * mean * mean) / (count - 1.0);   // torch.std: unbiased
+        if (var < 0) var = 0;
+        r.m = (float)mean;
+        r.d = (float)sqrt(var) + 1e-5f;
+    } else {  // cumulative layer norm: var = (pow - 2*mean*sum)/count + mean^2 ; std = sqrt(var + EPS)
+        double var = (sq - 2.0 * mean * sum) / count + mean * mean;
+        r.m = (float)mean;
+        r.d = (float)sqrt(var + (double)FSNP_EPS);
+    }
+    return r;
+}
+
+// one workgroup per (branch, utt): chunked prefix scan over frames
+__global__ __launch_bounds__(256) void fe_scan_kernel(const double* __restrict__ frame, NormMD* __restrict__ md,
+                                                      int B, int Tp, int F, int norm_type) {
+    __shared__ double cs[256], cq[256];
+    const long base = ((long)blockIdx.y * B + blockIdx.x) * Tp;
+    const int tid = threadIdx.x;
+    const int chunk = cdiv(Tp, 256);
+    const int lo = tid * chunk, hi = min(lo + chunk, Tp);
+    double s = 0.0, q = 0.0;
+    for (int t = lo; t < hi; ++t) { s += frame[(base + t) * 2]; q += frame[(base + t) * 2 + 1]; }
+    cs[tid] = s; cq[tid] = q;
+    __syncthreads();
+    const bool cumulative = norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || norm_type == FSNP_NORM_CUMULATIVE_LAYER;
+    if (!cumulative) {
+        double ts = 0.0, tq = 0.0;
+        for (int i = 0; i < 256; ++i) { ts += cs[i]; tq += cq[i]; }
+        const NormMD r = norm_md(norm_type, ts, tq, (double)F * Tp);
+        for (int t = lo; t < hi; ++t) md[base + t] = r;
+    } else {
+        double ps = 0.0, pq = 0.0;
+        for (int i = 0; i < tid; ++i) { ps += cs[i]; pq += cq[i]; }
+        for (int t = lo; t < hi; ++t) {
+            ps += frame[(base + t) * 2];
+            pq += frame[(base + t) * 2 + 1];
+            md[base + t] = norm_md(norm_type, ps, pq, (double)F * (t + 1));
+        }
+    }
+}
+
+constexpr int FSUM_ROWS = 32;
+__global__ __launch_bounds__(256) void fe_fsum_kernel(const float* __restrict__ raw, const NormMD* __restrict__ md,
+                                                      double* __restrict__ fsum, int B, int Tp, int F, int FP) {
+    const long ub = (long)blockIdx.z * B + blockIdx.y;
+    const int t0 = blockIdx.x * FSUM_ROWS, t1 = min(t0 + FSUM_ROWS, Tp);
+    for (int f = threadIdx.x; f < F; f += 256) {
+        double s = 0.0;
+        for (int t = t0; t < t1; ++t) {
+            const NormMD r = md[ub * Tp + t];
+            s += (double)((raw[(ub * Tp + t) * FP + f] - r.m) / r.d);
+        }
+        atomicAdd(fsum + ub * FP + f, s);
+    }
+}
+
+struct GateArgs {
+    FrontendWeights w;
+    const float* raw; const NormMD* md; const double* fsum; float* gate;
+    int B, Tp, F, FP;
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one workgroup per (branch, utt)
+__global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
+    extern __shared__ float sh[];
+    float* sq = sh;            // [F]  squeeze
+    float* hid = sh + g.FP;    // [F/2]
+    const int branch = blockIdx.y, b = blockIdx.x;
+    const long ub = (long)branch * g.B + b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = g.F, Tp = g.Tp, Fr = F / 2;
+    constexpr int MAXK = 16;
+
+    for (int f = tid; f < F; f += 256) {
+        // prefix[j] = sum of the first j normalised frames, suffix[j] = sum of the last j
+        double pre[MAXK], suf[MAXK];
+        pre[0] = 0.0; suf[0] = 0.0;
+        const int kmax = max(max(g.w.ksize[0], g.w.ksize[1]), g.w.ksize[2]);
+        for (int j = 1; j < kmax; ++j) {
+            const NormMD a = g.md[ub * Tp + (j - 1)];
+            const NormMD z = g.md[ub * Tp + (Tp - j)];
+            pre[j] = pre[j - 1] + (double)((g.raw[(ub * Tp + (j - 1)) * g.FP + f] - a.m) / a.d);
+            suf[j] = suf[j - 1] + (double)((g.raw[(ub * Tp + (Tp - j)) * g.FP + f] - z.m) / z.d);
+        }
+        const double S = g.fsum[ub * g.FP + f];
+        float squeeze = g.w.cat_b[branch][0];
+        for (int c = 0; c < 3; ++c) {
+            const int K = g.w.ksize[c];
+            const float* wk = g.w.conv_w[branch][c] + (long)f * K;
+            double acc = 0.0;
+            for (int j = 0; j < K; ++j) acc += (double)wk[j] * (S - pre[j] - suf[K - 1 - j]);
+            float feat = (float)(acc / (double)(Tp - K + 1)) + g.w.conv_b[branch][c][f];
+            feat = fmaxf(feat, 0.f);
+            squeeze += g.w.cat_w[branch][c] * feat;
+        }
+        sq[f] = squeeze;
+    }
+    __syncthreads();
+    // fc1 + ReLU: one wave per output, lanes over F
+    for (int o = wave; o < Fr; o += 4) {
+        const float* wr = g.w.fc1_w[branch] + (long)o * F;
+        float acc = 0.f;
+        for (int f = lane; f < F; f += 64) acc += wr[f] * sq[f];
+        acc = wave_sum_f(acc);
+        if (lane == 0) hid[o] = fmaxf(acc + g.w.fc1_b[branch][o], 0.f);
+    }
+    __syncthreads();
+    // fc2 + sigmoid
+    for (int o = wave; o < F; o += 4) {
+        const float* wr = g.w.fc2_w[branch] + (long)o * Fr;
+        float acc = 0.f;
+        for (int f = lane; f < Fr; f += 64) acc += wr[f] * hid[f];
+        acc = wave_sum_f(acc);
+        if (lane == 0) g.gate[ub * g.FP + o] = 1.0f / (1.0f + expf(-(acc + g.w.fc2_b[branch][o])));
+    }
+}
+
+__global__ __launch_bounds__(256) void fe_apply_kernel(const float* __restrict__ raw, const NormMD* __restrict__ md,
+                                                       const float* __restrict__ gate, float* __restrict__ att,
+                                                       long rows, int Tp, int F, int FP) {
+    // one thread per (row, f); row = (branch*B + utt)*Tp + t
+    const long total = rows * FP;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / FP;
+        const int f = (int)(i - row * FP);
+        float v = 0.0f;
+        if (f < F) {
+            const NormMD r = md[row];
+            v = ((raw[i] - r.m) / r.d) * gate[(row / Tp) * FP + f];
+        }
+        att[i] = v;
+    }
+}
+
+void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s) {
+    StridedIn si;
+    for (int i = 0; i < 3; ++i) {
+        si.p[i] = in[i];
+        si.sb[i] = strides[i][0]; si.sf[i] = strides[i][1]; si.st[i] = strides[i][2];
+    }
+    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw,
+                       d.B, d.T, d.Tp, d.F, d.FP);
+    hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
+    hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
+    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, FSUM_ROWS), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,
+                       d.B, d.Tp, d.F, d.FP);
+    GateArgs g;
+    g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;
+    g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
+    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(256), (size_t)(d.FP + d.F / 2 + 4) * sizeof(float), s, g);
+    const long rows = 3L * d.B * d.Tp;
+    const long total = rows * d.FP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(fe_apply_kernel, dim3(blocks), dim3(256), 0, s, buf.raw, buf.md, buf.gate, buf.att, rows, d.Tp,
+                       d.F, d.FP);
+}
+
+}  // namespace fsnp

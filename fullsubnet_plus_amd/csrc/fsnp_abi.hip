@@ -1,0 +1,576 @@
+// fsnp_abi.hip - C ABI of libfsnp_hip.so (include/fsnp.h): handle, strict weight loading + packing,
+// workspace management and the forward orchestration.  Host code only; kernels live in
+// frontend.hip / tcn.hip / subband.hip / lstm.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "fsnp_common.h"
+
+namespace fsnp {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+struct WeightSpec {
+    std::string name;
+    int64_t numel;
+};
+
+struct Workspace {
+    // offsets in bytes from the workspace base
+    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, zero_begin, fsum, gn, sb_acc, zero_end,
+        dbg_tcn0, total;
+};
+
+struct TimingRec {
+    hipEvent_t e[3];  // start, after full-band stages, after lstm (= end)
+};
+
+}  // namespace fsnp
+
+using namespace fsnp;
+
+struct fsnp_handle {
+    fsnp_config cfg{};
+    int device = 0;
+    int F = 0, FP = 0, CH = 0, H = 0, NSB = 0, NIN = 0, KX = 0, NB = 0, Fr = 0;
+    std::vector<WeightSpec> specs;
+    std::map<std::string, std::vector<float>> host_w;
+    bool committed = false;
+
+    float* d_weights = nullptr;
+    FrontendWeights fw{};
+    TcnWeights tw{};
+    LstmWeights lw{};
+    const float* d_refl_w = nullptr;
+
+    unsigned char* ws = nullptr;
+    size_t ws_bytes = 0;
+    Workspace last_ws{};
+    Dims last_dims{};
+    bool have_last = false;
+    bool debug = false;
+
+    bool timing = false;
+    std::vector<TimingRec> timing_recs;
+    double acc_ms[3] = {0, 0, 0};
+    int64_t acc_cnt[3] = {0, 0, 0};
+};
+
+namespace fsnp {
+
+static const int kDilations[8] = {1, 2, 5, 9, 1, 2, 5, 9};  // sequence_model.py:48-57
+static const char* kAtt[3] = {"channel_attention", "channel_attention_real", "channel_attention_imag"};
+static const char* kFb[3] = {"fb_model", "fb_model_real", "fb_model_imag"};
+static const char* kConvNames[3] = {"smallConv1d", "middleConv1d", "largeConv1d"};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void build_specs(fsnp_handle* h) {
+    auto add = [&](const std::string& n, int64_t numel) { h->specs.push_back({n, numel}); };
+    const int F = h->F, CH = h->CH, H = h->H, Fr = h->Fr;
+    for (int a = 0; a < 3; ++a) {
+        const std::string p = kAtt[a];
+        for (int c = 0; c < 3; ++c) {
+            add(p + "." + kConvNames[c] + ".0.weight", (int64_t)F * h->cfg.kersize[c]);
+            add(p + "." + kConvNames[c] + ".0.bias", F);
+        }
+        add(p + ".feature_concate_fc.weight", 3);
+        add(p + ".feature_concate_fc.bias", 1);
+        add(p + ".fc1.weight", (int64_t)Fr * F);
+        add(p + ".fc1.bias", Fr);
+        add(p + ".fc2.weight", (int64_t)F * Fr);
+        add(p + ".fc2.bias", F);
+    }
+    for (int b = 0; b < 3; ++b) {
+        for (int i = 0; i < h->NB; ++i) {
+            const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
+            add(p + ".conv1x1.weight", (int64_t)CH * F);
+            add(p + ".conv1x1.bias", CH);
+            add(p + ".prelu1.weight", 1);
+            add(p + ".norm1.weight", CH);
+            add(p + ".norm1.bias", CH);
+            add(p + ".depthwise_conv.weight", (int64_t)CH * 3);
+            add(p + ".depthwise_conv.bias", CH);
+            add(p + ".prelu2.weight", 1);
+            add(p + ".norm2.weight", CH);
+            add(p + ".norm2.bias", CH);
+            add(p + ".sconv.weight", (int64_t)F * CH);
+            add(p + ".sconv.bias", F);
+        }
+        add(std::string(kFb[b]) + ".fc_output_layer.weight", (int64_t)F * F);
+        add(std::string(kFb[b]) + ".fc_output_layer.bias", F);
+    }
+    const std::string s = "sb_model.sequence_model.";
+    add(s + "weight_ih_l0", (int64_t)4 * H * h->NIN);
+    add(s + "weight_hh_l0", (int64_t)4 * H * H);
+    add(s + "bias_ih_l0", 4 * H);
+    add(s + "bias_hh_l0", 4 * H);
+    add(s + "weight_ih_l1", (int64_t)4 * H * H);
+    add(s + "weight_hh_l1", (int64_t)4 * H * H);
+    add(s + "bias_ih_l1", 4 * H);
+    add(s + "bias_hh_l1", 4 * H);
+    add("sb_model.fc_output_layer.weight", (int64_t)h->cfg.output_size * H);
+    add("sb_model.fc_output_layer.bias", h->cfg.output_size);
+}
+
+// rows of the sub-band problem: (utterance, frequency) -> output offset
+__global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_rows_pad, int B, int F, int T, int mode,
+                                  int batch_offset, int global_batch, int dense_out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= num_rows_pad) return;
+    RowDesc r{0, 0, 0, 0};
+    if (n < num_rows) {
+        r.valid = 1;
+        if (dense_out) {               // fsnp_lstm2_fc: out[n][o][t]
+            r.b = 0; r.f = 0; r.out_off = n * 2 * T;
+        } else if (mode == FSNP_MODE_FULL) {
+            r.b = n / F; r.f = n % F;
+            r.out_off = ((r.b * 2) * F + r.f) * T;
+        } else {                       // drop_band (feature.py:254-285), num_groups == 2
+            const int Fh = F / 2;
+            r.b = n / Fh;
+            const int i = n % Fh;
+            const int s = batch_offset + r.b, p = s & 1;
+            const int n0 = (global_batch + 1) / 2;
+            const int orow = p == 0 ? s / 2 : n0 + (s - 1) / 2;
+            r.f = p + 2 * i;
+            r.out_off = ((orow * 2) * Fh + i) * T;
+        }
+    }
+    rows[n] = r;
+}
+
+static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
+
+static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
+    Workspace w{};
+    const size_t Tp = (size_t)T + h->cfg.look_ahead;
+    const size_t xb = (size_t)3 * B * Tp * h->FP * 4;
+    const size_t yb = (size_t)3 * B * Tp * h->CH * 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    w.att = take(xb);
+    w.fb = take(xb);
+    w.raw = take(xb);
+    w.x = take(xb);
+    w.y1 = take(yb);
+    w.y2 = take(yb);
+    w.gate = take((size_t)3 * B * h->FP * 4);
+    w.md = take((size_t)3 * B * Tp * sizeof(NormMD));
+    w.md_utt = take((size_t)B * sizeof(NormMD));
+    const size_t nrows_pad = align_up((size_t)B * rows_per_utt(h, mode), 32);
+    const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
+    w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
+    w.rows = take(nrows_pad * sizeof(RowDesc));
+    w.frame = take((size_t)3 * B * Tp * 2 * 8);
+    w.zero_begin = o;
+    w.fsum = take((size_t)3 * B * h->FP * 8);
+    w.gn = take((size_t)h->NB * 2 * 3 * B * 2 * 8);
+    w.sb_acc = take((size_t)B * 2 * 8);
+    w.zero_end = o;
+    w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
+    w.total = o;
+    return w;
+}
+
+static int ensure_workspace(fsnp_handle* h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return 0;
+    if (h->ws) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes));
+    h->ws_bytes = bytes;
+    return 0;
+}
+
+static double lstm_flops_per_step(const fsnp_handle* h) {
+    const double H = h->H, NIN = h->NIN, OUT = h->cfg.output_size;
+    return 2.0 * 4 * H * (NIN + H) + 2.0 * 4 * H * (2 * H) + 2.0 * H * OUT;
+}
+static double tcn_flops_per_frame(const fsnp_handle* h) {
+    const double F = h->F, CH = h->CH;
+    return h->NB * (2.0 * F * CH + 2.0 * CH * 3 + 2.0 * CH * F) + 2.0 * F * F;
+}
+
+}  // namespace fsnp
+
+extern "C" {
+
+const char* fsnp_last_error(void) { return g_last_error.c_str(); }
+const char* fsnp_version(void) { return "fsnp-hip 0.1 (gfx950)"; }
+
+int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
+    if (!cfg || !out) { set_error("fsnp_create: null argument"); return 1; }
+    *out = nullptr;
+    if (cfg->fb_num_neighbors != 0) { set_error("fb_num_neighbors != 0 is not supported by the HIP path"); return 2; }
+    if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
+    if (cfg->sb_hidden != 384) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
+    if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
+    if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
+    if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
+    const int nin = 2 * cfg->sb_num_neighbors + 1 + 3;
+    if (nin > 40) { set_error("sb_num_neighbors too large for the KX=40 LSTM instantiation"); return 2; }
+    if (cfg->num_freqs <= cfg->sb_num_neighbors) { set_error("num_freqs must exceed sb_num_neighbors (reflect pad)"); return 2; }
+    for (int c = 0; c < 3; ++c)
+        if (cfg->kersize[c] < 1 || cfg->kersize[c] > 16) { set_error("kersize must be in [1,16]"); return 2; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device visible: libfsnp_hip needs an MI355X (gfx950); there is no CPU fallback");
+        return 3;
+    }
+    int dev = 0;
+    FSNP_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FSNP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libfsnp_hip is built for gfx950 only", dev, prop.gcnArchName);
+        return 3;
+    }
+    fsnp_handle* h = new fsnp_handle();
+    h->cfg = *cfg;
+    h->device = dev;
+    h->F = cfg->num_freqs;
+    h->FP = (int)align_up(cfg->num_freqs, 4);
+    h->CH = cfg->tcn_hidden;
+    h->H = cfg->sb_hidden;
+    h->NSB = 2 * cfg->sb_num_neighbors + 1;
+    h->NIN = nin;
+    h->KX = 40;
+    h->NB = cfg->num_tcn_blocks;
+    h->Fr = cfg->num_freqs / 2;
+    build_specs(h);
+    const char* dbg = getenv("FSNP_DEBUG_STAGES");
+    h->debug = dbg && dbg[0] == '1';
+    *out = h;
+    return 0;
+}
+
+void fsnp_destroy(fsnp_handle* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->d_weights) (void)hipFree(h->d_weights);
+    for (auto& r : h->timing_recs)
+        for (auto& e : r.e) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int fsnp_num_weights(const fsnp_handle* h) { return h ? (int)h->specs.size() : 0; }
+
+int fsnp_weight_info(const fsnp_handle* h, int index, const char** name, int64_t* numel) {
+    if (!h || index < 0 || index >= (int)h->specs.size()) { set_error("fsnp_weight_info: bad index"); return 1; }
+    if (name) *name = h->specs[index].name.c_str();
+    if (numel) *numel = h->specs[index].numel;
+    return 0;
+}
+
+int fsnp_set_weight(fsnp_handle* h, const char* name, const float* host_data, int64_t numel) {
+    if (!h || !name || !host_data) { set_error("fsnp_set_weight: null argument"); return 1; }
+    for (const auto& s : h->specs) {
+        if (s.name == name) {
+            if (s.numel != numel) {
+                set_error("size mismatch for %s: expected %lld elements, got %lld", name, (long long)s.numel, (long long)numel);
+                return 2;
+            }
+            h->host_w[s.name].assign(host_data, host_data + numel);
+            h->committed = false;
+            return 0;
+        }
+    }
+    set_error("unexpected key in state_dict: %s", name);
+    return 2;
+}
+
+int fsnp_commit_weights(fsnp_handle* h) {
+    if (!h) { set_error("null handle"); return 1; }
+    for (const auto& s : h->specs)
+        if (!h->host_w.count(s.name)) { set_error("missing key in state_dict: %s", s.name.c_str()); return 2; }
+    const int F = h->F, CH = h->CH, H = h->H, NB = h->NB, Fr = h->Fr;
+    std::vector<float> blob;
+    auto alloc = [&](size_t n) { size_t o = blob.size(); blob.resize(align_up(o + n, 64), 0.0f); return o; };
+    auto W = [&](const std::string& n) -> const std::vector<float>& { return h->host_w.at(n); };
+    auto put = [&](const std::string& n) { const auto& v = W(n); size_t o = alloc(v.size()); std::copy(v.begin(), v.end(), blob.begin() + o); return o; };
+
+    // ---- frontend (TSSE) : reference layouts are already what the kernels want
+    size_t o_conv_w[3][3], o_conv_b[3][3], o_cat_w[3], o_cat_b[3], o_fc1w[3], o_fc1b[3], o_fc2w[3], o_fc2b[3];
+    for (int a = 0; a < 3; ++a) {
+        const std::string p = kAtt[a];
+        for (int c = 0; c < 3; ++c) {
+            o_conv_w[a][c] = put(p + "." + kConvNames[c] + ".0.weight");
+            o_conv_b[a][c] = put(p + "." + kConvNames[c] + ".0.bias");
+        }
+        o_cat_w[a] = put(p + ".feature_concate_fc.weight");
+        o_cat_b[a] = put(p + ".feature_concate_fc.bias");
+        o_fc1w[a] = put(p + ".fc1.weight"); o_fc1b[a] = put(p + ".fc1.bias");
+        o_fc2w[a] = put(p + ".fc2.weight"); o_fc2b[a] = put(p + ".fc2.bias");
+    }
+    // ---- TCN: zero-padded row-major [N pad 64][K pad 16] GEMM operands, [branch][block] major
+    const int N1P = (int)align_up(CH, 64), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, 64), K2P = (int)align_up(CH, 16);
+    const size_t o_w1 = alloc((size_t)3 * NB * N1P * K1P), o_b1 = alloc((size_t)3 * NB * N1P), o_a1 = alloc(3 * NB + 1);
+    const size_t o_g1w = alloc((size_t)3 * NB * CH), o_g1b = alloc((size_t)3 * NB * CH);
+    const size_t o_dw = alloc((size_t)3 * NB * 3 * CH), o_db = alloc((size_t)3 * NB * CH), o_a2 = alloc(3 * NB + 1);
+    const size_t o_g2w = alloc((size_t)3 * NB * CH), o_g2b = alloc((size_t)3 * NB * CH);
+    const size_t o_w2 = alloc((size_t)3 * NB * N2P * K2P), o_b2 = alloc((size_t)3 * NB * N2P);
+    const size_t o_wf = alloc((size_t)3 * N2P * K1P), o_bf = alloc((size_t)3 * N2P);
+    for (int b = 0; b < 3; ++b) {
+        for (int i = 0; i < NB; ++i) {
+            const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
+            const size_t bi = (size_t)b * NB + i;
+            const auto& w1 = W(p + ".conv1x1.weight");
+            for (int n = 0; n < CH; ++n)
+                for (int k = 0; k < F; ++k) blob[o_w1 + (bi * N1P + n) * K1P + k] = w1[(size_t)n * F + k];
+            std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + o_b1 + bi * N1P);
+            blob[o_a1 + bi] = W(p + ".prelu1.weight")[0];
+            std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + o_g1w + bi * CH);
+            std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + o_g1b + bi * CH);
+            const auto& dw = W(p + ".depthwise_conv.weight");   // [CH][1][3]
+            for (int c = 0; c < CH; ++c)
+                for (int j = 0; j < 3; ++j) blob[o_dw + (bi * 3 + j) * CH + c] = dw[(size_t)c * 3 + j];
+            std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + o_db + bi * CH);
+            blob[o_a2 + bi] = W(p + ".prelu2.weight")[0];
+            std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + o_g2w + bi * CH);
+            std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + o_g2b + bi * CH);
+            const auto& w2 = W(p + ".sconv.weight");             // [F][CH][1]
+            for (int n = 0; n < F; ++n)
+                for (int k = 0; k < CH; ++k) blob[o_w2 + (bi * N2P + n) * K2P + k] = w2[(size_t)n * CH + k];
+            std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + o_b2 + bi * N2P);
+        }
+        const auto& wf = W(std::string(kFb[b]) + ".fc_output_layer.weight");
+        for (int n = 0; n < F; ++n)
+            for (int k = 0; k < F; ++k) blob[o_wf + ((size_t)b * N2P + n) * K1P + k] = wf[(size_t)n * F + k];
+        const auto& bf = W(std::string(kFb[b]) + ".fc_output_layer.bias");
+        std::copy(bf.begin(), bf.end(), blob.begin() + o_bf + (size_t)b * N2P);
+    }
+    // ---- LSTM: MFMA B-fragment order + summed biases
+    const std::string s = "sb_model.sequence_model.";
+    const size_t o_wpack = alloc(lstm_pack_floats(H, h->KX));
+    lstm_pack_weights(H, h->NIN, h->KX, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                      W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack);
+    const size_t o_lbias = alloc((size_t)2 * 4 * H);
+    for (int l = 0; l < 2; ++l) {
+        const auto& bi = W(s + "bias_ih_l" + std::to_string(l));
+        const auto& bh = W(s + "bias_hh_l" + std::to_string(l));
+        for (int i = 0; i < 4 * H; ++i) blob[o_lbias + (size_t)l * 4 * H + i] = bi[i] + bh[i];
+    }
+    const size_t o_wfc = put("sb_model.fc_output_layer.weight");
+    const size_t o_bfc = put("sb_model.fc_output_layer.bias");
+    // ---- unfold multiplicities w_r, by brute force over (f, j)
+    const size_t o_refl = alloc(F);
+    for (int f = 0; f < F; ++f)
+        for (int j = 0; j < h->NSB; ++j) blob[o_refl + reflect_index(f - h->cfg.sb_num_neighbors + j, F)] += 1.0f;
+
+    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    if (h->d_weights) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->d_weights)); h->d_weights = nullptr; }
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_weights), blob.size() * sizeof(float)));
+    FSNP_HIP_CHECK(hipMemcpy(h->d_weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* d = h->d_weights;
+    for (int a = 0; a < 3; ++a) {
+        for (int c = 0; c < 3; ++c) { h->fw.conv_w[a][c] = d + o_conv_w[a][c]; h->fw.conv_b[a][c] = d + o_conv_b[a][c]; }
+        h->fw.cat_w[a] = d + o_cat_w[a]; h->fw.cat_b[a] = d + o_cat_b[a];
+        h->fw.fc1_w[a] = d + o_fc1w[a]; h->fw.fc1_b[a] = d + o_fc1b[a];
+        h->fw.fc2_w[a] = d + o_fc2w[a]; h->fw.fc2_b[a] = d + o_fc2b[a];
+    }
+    for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
+    h->tw.w1 = d + o_w1; h->tw.b1 = d + o_b1; h->tw.a1 = d + o_a1; h->tw.g1w = d + o_g1w; h->tw.g1b = d + o_g1b;
+    h->tw.dw = d + o_dw; h->tw.db = d + o_db; h->tw.a2 = d + o_a2; h->tw.g2w = d + o_g2w; h->tw.g2b = d + o_g2b;
+    h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
+    h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
+    for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
+    h->lw.wpack = d + o_wpack; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
+    h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
+    h->d_refl_w = d + o_refl;
+    h->committed = true;
+    (void)Fr;
+    return 0;
+}
+
+size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode) {
+    if (!h || batch <= 0 || frames <= 0) return 0;
+    return plan_workspace(h, batch, frames, mode).total;
+}
+
+int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
+                 const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
+                 int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
+    if (!h || !mag || !real || !imag || !out || !strides) { set_error("fsnp_forward: null argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_forward: weights not committed (call fsnp_commit_weights)"); return 2; }
+    if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
+    if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
+    if (mode == FSNP_MODE_PARITY && h->cfg.num_groups_in_drop_band != 2) { set_error("PARITY mode needs num_groups_in_drop_band == 2"); return 2; }
+    if (batch_offset < 0 || global_batch < batch_offset + batch) { set_error("bad batch_offset/global_batch"); return 2; }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    Dims d;
+    d.B = batch; d.T = frames; d.LA = h->cfg.look_ahead; d.Tp = frames + d.LA; d.F = h->F; d.FP = h->FP;
+    d.CH = h->CH; d.H = h->H; d.NSB = h->NSB; d.NIN = h->NIN;
+    int kmax = 1;
+    for (int c = 0; c < 3; ++c) kmax = kmax > h->cfg.kersize[c] ? kmax : h->cfg.kersize[c];
+    if (d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
+    if ((double)3 * d.B * d.Tp * d.FP * 2 > 2.0e9) { set_error("batch too large for 32-bit gather offsets; split the batch"); return 2; }
+
+    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    const Workspace w = plan_workspace(h, batch, frames, mode);
+    if (ensure_workspace(h, w.total)) return 4;
+    unsigned char* base = h->ws;
+    auto fptr = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+
+    TimingRec rec{};
+    if (h->timing) {
+        for (auto& e : rec.e) FSNP_HIP_CHECK(hipEventCreate(&e));
+        FSNP_HIP_CHECK(hipEventRecord(rec.e[0], s));
+    }
+    FSNP_HIP_CHECK(hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, s));
+
+    const int num_rows = batch * rows_per_utt(h, mode);
+    const int num_rows_pad = (int)align_up(num_rows, 32);
+    RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
+    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_rows_pad, 256)), dim3(256), 0, s, rows, num_rows, num_rows_pad,
+                       batch, h->F, frames, mode, batch_offset, global_batch, 0);
+
+    FrontendBuffers fbuf;
+    fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
+    fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
+    fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
+    const float* in[3] = {mag, real, imag};
+    launch_frontend(d, h->cfg.norm_type, in, strides, h->fw, fbuf, s);
+
+    TcnBuffers tbuf;
+    tbuf.att = fptr(w.att); tbuf.x = fptr(w.x); tbuf.y1 = fptr(w.y1); tbuf.y2 = fptr(w.y2);
+    tbuf.gn = reinterpret_cast<double*>(base + w.gn); tbuf.fb = fptr(w.fb);
+    tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
+    launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+
+    const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
+    SubbandBuffers sbuf;
+    sbuf.att_mag = fptr(w.att); sbuf.fb = fptr(w.fb); sbuf.refl_w = h->d_refl_w;
+    sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
+    sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
+    sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
+    launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_rows, s);
+    if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[1], s));
+
+    LstmArgs a{};
+    a.att_mag = fptr(w.att); a.fb = fptr(w.fb);
+    a.fb_rel = (int)((w.fb - w.att) / 4);
+    a.fb_branch_stride = d.B * d.Tp * d.FP;
+    a.rows = rows; a.md_utt = sbuf.md_utt; a.md_row = sbuf.md_row; a.dense = nullptr;
+    a.out = out;
+    a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
+    a.num_rows = num_rows; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
+    a.act = h->cfg.sb_act;
+    launch_lstm(h->lw, a, s);
+    if (h->timing) {
+        FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
+        h->timing_recs.push_back(rec);
+    }
+    FSNP_HIP_CHECK(hipGetLastError());
+    h->last_ws = w; h->last_dims = d; h->have_last = true;
+    return 0;
+}
+
+int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, void* hip_stream) {
+    if (!h || !x || !out) { set_error("fsnp_lstm2_fc: null argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_lstm2_fc: weights not committed"); return 2; }
+    if (num_seq <= 0 || steps <= 0) { set_error("fsnp_lstm2_fc: empty input"); return 2; }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    const int pad = (int)align_up(num_seq, 32);
+    if (ensure_workspace(h, (size_t)pad * sizeof(RowDesc))) return 4;
+    RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
+    h->have_last = false;   // the workspace no longer holds a forward's stages
+    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, s, rows, num_seq, pad, 1, 1, steps, 0, 0, 1, 1);
+    LstmArgs a{};
+    a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
+    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
+    launch_lstm(h->lw, a, s);
+    FSNP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t numel) {
+    if (!h || !name || !host_out) { set_error("fsnp_read_stage: null argument"); return 1; }
+    if (!h->have_last) { set_error("fsnp_read_stage: no forward has run"); return 2; }
+    const Dims& d = h->last_dims;
+    const Workspace& w = h->last_ws;
+    const size_t plane = (size_t)d.B * d.Tp * d.FP;       // one branch, padded rows
+    const std::string n = name;
+    const float* src = nullptr;
+    bool is_gate = false;
+    static const char* tags[3] = {"mag", "real", "imag"};
+    for (int b = 0; b < 3; ++b) {
+        if (n == std::string("att_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.att) + b * plane;
+        if (n == std::string("fb_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.fb) + b * plane;
+        if (n == std::string("gate_") + tags[b]) { src = reinterpret_cast<float*>(h->ws + w.gate) + (size_t)b * d.B * d.FP; is_gate = true; }
+    }
+    if (n == "tcn0_mag") {
+        if (!h->debug) { set_error("tcn0_mag needs FSNP_DEBUG_STAGES=1 at fsnp_create time"); return 2; }
+        src = reinterpret_cast<float*>(h->ws + w.dbg_tcn0);
+    }
+    if (!src) { set_error("unknown stage %s", name); return 2; }
+    const int64_t rows = is_gate ? d.B : (int64_t)d.B * d.Tp;
+    if (numel != rows * d.F) { set_error("stage %s has %lld elements, caller asked %lld", name, (long long)(rows * d.F), (long long)numel); return 2; }
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
+    FSNP_HIP_CHECK(hipMemcpy2D(host_out, (size_t)d.F * 4, src, (size_t)d.FP * 4, (size_t)d.F * 4, (size_t)rows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fsnp_set_timing(fsnp_handle* h, int32_t enable) {
+    if (!h) { set_error("null handle"); return 1; }
+    h->timing = enable != 0;
+    return 0;
+}
+
+int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t reset) {
+    if (!h || !ms || !count) { set_error("fsnp_get_timing: null argument"); return 1; }
+    for (auto& r : h->timing_recs) {
+        FSNP_HIP_CHECK(hipEventSynchronize(r.e[2]));
+        float fb = 0, lstm = 0, all = 0;
+        FSNP_HIP_CHECK(hipEventElapsedTime(&fb, r.e[0], r.e[1]));
+        FSNP_HIP_CHECK(hipEventElapsedTime(&lstm, r.e[1], r.e[2]));
+        FSNP_HIP_CHECK(hipEventElapsedTime(&all, r.e[0], r.e[2]));
+        h->acc_ms[0] += lstm; h->acc_ms[1] += fb; h->acc_ms[2] += all;
+        for (int i = 0; i < 3; ++i) h->acc_cnt[i] += 1;
+        for (auto& e : r.e) if (e) (void)hipEventDestroy(e);
+    }
+    h->timing_recs.clear();
+    for (int i = 0; i < 3; ++i) { ms[i] = h->acc_ms[i]; count[i] = h->acc_cnt[i]; }
+    if (reset) for (int i = 0; i < 3; ++i) { h->acc_ms[i] = 0; h->acc_cnt[i] = 0; }
+    return 0;
+}
+
+int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0,
+                         const float* wih1, const float* whh1, float* out, int64_t out_floats) {
+    if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_pack: null argument"); return 1; }
+    if (hidden % 128 != 0 || kx % 8 != 0 || input_size > kx) { set_error("fsnp_debug_lstm_pack: bad sizes"); return 2; }
+    if ((int64_t)lstm_pack_floats(hidden, kx) != out_floats) {
+        set_error("fsnp_debug_lstm_pack: need %lld floats", (long long)lstm_pack_floats(hidden, kx));
+        return 2;
+    }
+    lstm_pack_weights(hidden, input_size, kx, wih0, whh0, wih1, whh1, out);
+    return 0;
+}
+
+double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps) {
+    if (!h) return 0;
+    return (double)num_seq * steps * lstm_flops_per_step(h);
+}
+
+double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode) {
+    if (!h) return 0;
+    const double Tp = frames + h->cfg.look_ahead;
+    return batch * Tp * (rows_per_utt(h, mode) * lstm_flops_per_step(h) + 3.0 * tcn_flops_per_frame(h));
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// fsnp_common.h - internal declarations shared by the HIP translation units of libfsnp_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsnp.h"
+
+namespace fsnp {
+
+// ---------------------------------------------------------------------------------------------
+// Problem dimensions of one forward call (device layouts are time-major: [utt][t][freq]).
+struct Dims {
+    int B;    // utterances in this call
+    int T;    // un-padded frames
+    int Tp;   // T + look_ahead
+    int F;    // num_freqs (257)
+    int FP;   // padded row stride of [.,.,F] buffers (multiple of 4)
+    int CH;   // TCN hidden channels (512)
+    int H;    // sub-band LSTM hidden (384)
+    int NSB;  // 2*sb_num_neighbors+1 (31)
+    int NIN;  // LSTM input size (34)
+    int LA;   // look_ahead
+};
+
+// One (m_t, d_t) pair: normalised = (x - m) / d.
+struct NormMD { float m, d; };
+
+// ---------------------------------------------------------------------------------------------
+// frontend.hip : strided input -> raw, norm statistics, TSSE gate, att = norm(x) * gate
+struct FrontendWeights {
+    // per branch (mag, real, imag): depthwise conv weights [F][k], biases [F], for 3 kernel sizes
+    const float* conv_w[3][3];
+    const float* conv_b[3][3];
+    const float* cat_w[3];   // [3]
+    const float* cat_b[3];   // [1]
+    const float* fc1_w[3];   // [F/2][F]
+    const float* fc1_b[3];   // [F/2]
+    const float* fc2_w[3];   // [F][F/2]
+    const float* fc2_b[3];   // [F]
+    int ksize[3];
+};
+
+struct FrontendBuffers {
+    float* raw;       // [3][B][Tp][FP]
+    double* frame;    // [3][B][Tp][2]   per-frame (sum, sum of squares) over F
+    NormMD* md;       // [3][B][Tp]
+    double* fsum;     // [3][B][FP]      per-frequency sum over t of the normalised input
+    float* gate;      // [3][B][FP]
+    float* att;       // [3][B][Tp][FP]
+};
+
+void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// tcn.hip : 8 x TCNBlock + ReLU + Linear + activation for the three full-band branches at once
+struct TcnWeights {
+    // packed per branch/block; see pack_tcn() in fsnp_abi.hip for layouts
+    const float* w1;     // [3][NB][N1P][K1P]  conv1x1  (N1P = CH padded to 64, K1P = F padded to 16)
+    const float* b1;     // [3][NB][N1P]
+    const float* a1;     // [3][NB]            PReLU slope
+    const float* g1w;    // [3][NB][CH]        GroupNorm gamma
+    const float* g1b;    // [3][NB][CH]
+    const float* dw;     // [3][NB][3][CH]     depthwise taps, tap-major
+    const float* db;     // [3][NB][CH]
+    const float* a2;     // [3][NB]
+    const float* g2w;    // [3][NB][CH]
+    const float* g2b;    // [3][NB][CH]
+    const float* w2;     // [3][NB][N2P][K2P]  sconv  (N2P = F padded to 64, K2P = CH padded to 16)
+    const float* b2;     // [3][NB][N2P]
+    const float* wf;     // [3][N2P][K1P]      fc_output_layer
+    const float* bf;     // [3][N2P]
+    int NB, N1P, K1P, N2P, K2P;
+    int dilation[16];
+};
+
+struct TcnBuffers {
+    const float* att;  // [3][B][Tp][FP]  input (kept intact)
+    float* x;          // [3][B][Tp][FP]  running activation
+    float* y1;         // [3][B][Tp][CH]
+    float* y2;         // [3][B][Tp][CH]
+    double* gn;        // [NB][2][3][B][2] GroupNorm (sum, sumsq) accumulators, zeroed per forward
+    float* fb;         // [3][B][Tp][FP]  output
+    float* dbg_tcn0;   // optional [B][Tp][FP]: mag branch after block 0
+};
+
+void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// subband.hip : statistics of the (never materialised) sub-band input tensor
+struct SubbandBuffers {
+    const float* att_mag;  // [B][Tp][FP]
+    const float* fb;       // [3][B][Tp][FP]
+    const float* refl_w;   // [F] multiplicity of each frequency row inside the unfold
+    double* acc;           // [B][2]  (sum, sumsq) over the whole [F,NIN,Tp] tensor, zeroed per forward
+    NormMD* md_utt;        // [B]
+    NormMD* md_row;        // [Nrows][Tp] (cumulative norms only)
+};
+struct RowDesc { int b, f, out_off, valid; };  // one sub-band sequence
+
+void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
+                          int num_rows, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile
+struct LstmWeights {
+    const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream]
+    const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
+    const float* wfc;    // [OUT][H]
+    const float* bfc;    // [OUT]
+    int H, NIN, KX, OUT;
+};
+struct LstmArgs {
+    // gather mode (dense == nullptr): x_j(t) built from att_mag / fb (fullsubnet_plus.py:167-189)
+    const float* att_mag;  // [B][Tp][FP]
+    const float* fb;       // [3][B][Tp][FP]
+    int fb_rel;            // fb - att_mag in floats (same workspace allocation)
+    int fb_branch_stride;  // floats between fb branches
+    const RowDesc* rows;   // [num_tiles*32]
+    const NormMD* md_utt;  // [B]   (offline norms)
+    const NormMD* md_row;  // [rows][Tp] or nullptr
+    // dense mode: x[row][t][NIN]
+    const float* dense;
+    float* out;            // out[row.out_off + o*out_stride_o + (t-LA)]
+    long out_stride_o;
+    int num_rows;          // valid rows
+    int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
+    int act;               // FSNP_ACT_* on the Linear output
+};
+
+void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t lstm_pack_floats(int H, int KX);  // size of wpack in floats
+// host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
+void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1,
+                       const float* whh1, float* wpack);
+
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define FSNP_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            fsnp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// reflect index used by BaseModel.unfold's reflect padding (base_model.py:38): refl(-k)=k, refl(F-1+k)=F-1-k
+__host__ __device__ inline int reflect_index(int i, int F) {
+    if (i < 0) i = -i;
+    if (i >= F) i = 2 * (F - 1) - i;
+    return i;
+}
+
+}  // namespace fsnp

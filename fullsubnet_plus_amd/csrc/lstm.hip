@@ -1,0 +1,301 @@
+// lstm.hip - fused two-layer sub-band LSTM + Linear for gfx950 (MI355X).
+//
+// Replaces SequenceModel.forward's LSTM branch
+//   (speech_enhance/audio_zen/model/module/sequence_model.py:113-123: permute -> nn.LSTM(34,384,
+//    num_layers=2, batch_first) -> Linear(384,2) -> permute)
+// together with the tensor plumbing in front of it in FullSubNet_Plus.forward
+//   (speech_enhance/fullsubnet_plus/model/fullsubnet_plus.py:167-206: four unfolds, cat, second norm,
+//    drop_band, reshape, and the final reshape/permute/look-ahead slice),
+// none of which is materialised: every 32-sequence tile gathers its 34-dim input frame from the
+// time-major [utt][t][freq] full-band buffers each step, and writes its 2 mask values straight into
+// out[b, o, f, t - look_ahead].
+//
+// Mapping (one workgroup = 4 waves = one per SIMD, one workgroup per CU, 512 registers per lane):
+//   * rows      : 32 independent sequences per workgroup = the M of v_mfma_f32_32x32x2_f32.
+//   * columns   : wave w owns hidden units [w*H/4, (w+1)*H/4) of BOTH layers, i.e. 4 gates x 96 units
+//                 = 12 accumulator tiles of 32 columns (192 accumulator registers); the i/f/g/o values
+//                 of one (row, unit) land in the same lane/register of 4 tiles, so the cell update is
+//                 lane-local and c never leaves registers.
+//   * K         : layer 0: [x_t (34, zero-padded to KX=40) | h0_{t-1} (384)], layer 1: [h1_{t-1} | h0_t].
+//   * B operand : weights are pre-packed on the host in exact MFMA B-fragment order, one float4 per
+//                 lane per (8-deep k-group, tile) = 4 MFMAs; each wave streams its private 1.8 MB/step
+//                 slice straight from L2 into registers (no LDS: no other wave shares it), always one
+//                 k-group (12 x 1 KiB loads) ahead, continuously across phase boundaries.
+//   * A operand : x_t, h0, h1 live in LDS in A-fragment order ([k-group][k parity][row][4 k-pairs]) so
+//                 one ds_read_b128 per k-group feeds 48 MFMAs.
+// fp32 throughout: v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain.
+#include "fsnp_common.h"
+
+namespace fsnp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == FSNP_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == FSNP_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    if (act == FSNP_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// float index of A element (row, k) inside an A-fragment-ordered LDS matrix
+__host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
+    return (((k >> 3) * 64) + ((k & 1) * 32) + row) * 4 + ((k >> 1) & 3);
+}
+
+// Consume `ngroups` k-groups: A from LDS (A already offset by lane), B from the rotating register
+// buffer `b` (always holding the group about to be used); refills b from the weight stream.
+template <int NT>
+__device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float4 (&b)[NT], const float4* __restrict__ A,
+                                            int ngroups, const float4* __restrict__ wlane, int& gnext,
+                                            int groups_total) {
+    float4 a = A[0];
+    for (int g = 0; g < ngroups; ++g) {
+        const float4 an = A[(g + 1 < ngroups ? g + 1 : g) * 64];
+        const float4* __restrict__ wn = wlane + (size_t)gnext * (NT * 64);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+            // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
+            // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
+            // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
+            b[n] = wn[n * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
+        a = an;
+    }
+}
+
+template <int ST, int UW>
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST], float* __restrict__ Hs, int wave,
+                                          int lane) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+        const int k = wave * UW + s * 32 + (lane & 31);
+        const int kbase = (((k >> 3) * 64) + ((k & 1) * 32)) * 4 + ((k >> 1) & 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ig = fast_sigmoid(acc[s][r]);
+            const float fg = fast_sigmoid(acc[ST + s][r]);
+            const float gg = fast_tanh(acc[2 * ST + s][r]);
+            const float og = fast_sigmoid(acc[3 * ST + s][r]);
+            const float cn = fg * c[s][r] + ig * gg;
+            c[s][r] = cn;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Hs[kbase + row * 4] = og * fast_tanh(cn);
+        }
+    }
+}
+
+template <int HID, int KX, int OUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
+    static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
+    constexpr int UW = HID / 4, ST = UW / 32, NT = 4 * ST;
+    static_assert(UW % 32 == 0, "hidden/4 must be a multiple of 32");
+    constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH, KG1 = 2 * KGH, KGT = KG0 + KG1;
+    static_assert(KGH % 4 == 0, "FC k-split");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* Xs = reinterpret_cast<float4*>(smem_raw);   // [KGX][64]
+    float4* H0s = Xs + KGX * 64;                         // [KGH][64]
+    float4* H1s = H0s + KGH * 64;                        // [KGH][64]
+    float4* Wfc4 = H1s + KGH * 64;                       // [OUT][KGH][2]
+    RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [32]
+    float* Bs = reinterpret_cast<float*>(rows_s + 32);                   // [2][4][NT][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 32;
+    const int Tp = a.Tp;
+
+    for (int i = tid; i < (KGX + 2 * KGH) * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < OUT * KGH * 2; i += 256) {
+        const int o = i / (KGH * 2), kg = (i >> 1) % KGH, kh = i & 1;
+        const float* wr = w.wfc + (size_t)o * HID + kg * 8 + kh;
+        Wfc4[i] = make_float4(wr[0], wr[2], wr[4], wr[6]);
+    }
+    if (tid < 32) rows_s[tid] = a.rows[row0 + tid];
+    for (int i = tid; i < 2 * 4 * NT * 32; i += 256) {
+        const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) & 3, layer = i / (32 * NT * 4);
+        Bs[i] = w.bias[layer * 4 * HID + (n / ST) * HID + wv * UW + (n % ST) * 32 + col];
+    }
+    __syncthreads();
+
+    // ---- per-thread gather plan: row = tid & 31, features j = (tid >> 5) + 8 i ------------------
+    // 32-bit float offsets from one wave-uniform base (att_mag, or this tile's dense rows); -1 = zero.
+    const int grow = tid & 31;
+    const RowDesc rd = rows_s[grow];
+    const bool dense = a.dense != nullptr;
+    const float* __restrict__ gbase = dense ? a.dense + (size_t)row0 * Tp * w.NIN : a.att_mag;
+    const int gstep = dense ? w.NIN : a.FP;
+    int goff[KGX];
+#pragma unroll
+    for (int i = 0; i < KGX; ++i) {
+        const int j = (tid >> 5) + 8 * i;
+        int off = -1;
+        if (rd.valid && j < w.NIN) {
+            if (dense) {
+                off = grow * Tp * w.NIN + j;
+            } else {
+                const int base = rd.b * Tp * a.FP;
+                const int nsb = 2 * a.NSBN + 1;
+                off = (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
+                                : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
+            }
+        }
+        goff[i] = off;
+    }
+    const int xdst0 = a_frag_index(grow, tid >> 5);   // feature j = (tid>>5) + 8 i  ->  + i * 256 floats
+    NormMD md = {0.0f, 1.0f};
+    if (!dense && rd.valid && a.md_row == nullptr) md = a.md_utt[rd.b];
+    const NormMD* md_row = (!dense && rd.valid && a.md_row != nullptr) ? a.md_row + (size_t)(row0 + grow) * Tp : nullptr;
+
+    float* Xf = reinterpret_cast<float*>(Xs);
+    {   // x(0)
+        NormMD m0 = md;
+        if (md_row) m0 = md_row[0];
+#pragma unroll
+        for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
+    }
+
+    // ---- register state -----------------------------------------------------------------------------
+    // biases sit in LDS in (layer, wave, tile, column) order: Bs[((layer*4 + wave)*NT + n)*32 + col]
+    const float* __restrict__ bias_l0 = Bs + ((0 * 4 + wave) * NT) * 32 + (lane & 31);
+    const float* __restrict__ bias_l1 = Bs + ((1 * 4 + wave) * NT) * 32 + (lane & 31);
+    f32x16 c0[ST], c1[ST];
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[s][r] = 0.0f; c1[s][r] = 0.0f; }
+
+    const float4* __restrict__ wlane = reinterpret_cast<const float4*>(w.wpack) + (size_t)wave * KGT * NT * 64 + lane;
+    float4 breg[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) breg[n] = wlane[n * 64];   // group 0
+    int gnext = 1;
+
+    // FC lane mapping: 8 rows x 2 outputs x 4 k-parts per wave
+    const int fc_row = wave * 8 + (lane & 7);
+    const int fc_o = (lane >> 3) & 1;
+    const int fc_kp = lane >> 4;
+    const float fc_bias = w.bfc[fc_o];
+    const RowDesc fc_rd = rows_s[fc_row];
+
+    auto fc_store = [&](int t_of_h) {
+        constexpr int KGP = KGH / 4;
+        float sum = 0.0f;
+#pragma unroll 4
+        for (int kk = 0; kk < KGP; ++kk) {
+            const int kg = fc_kp * KGP + kk;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const float4 h4 = H1s[kg * 64 + kh * 32 + fc_row];
+                const float4 w4 = Wfc4[(fc_o * KGH + kg) * 2 + kh];
+                sum += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (fc_kp == 0 && fc_rd.valid && t_of_h >= a.LA)
+            a.out[(size_t)fc_rd.out_off + (size_t)fc_o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sum + fc_bias, a.act);
+    };
+
+    __syncthreads();
+
+    for (int t = 0; t < Tp; ++t) {
+        // prefetch x(t+1) (consumed after the layer-0 MFMA phase)
+        float xr[KGX];
+        NormMD mdn = md;
+        const bool have_next = (t + 1 < Tp);
+        if (have_next) {
+            if (md_row) mdn = md_row[t + 1];
+#pragma unroll
+            for (int i = 0; i < KGX; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
+        }
+
+        f32x16 acc[NT];
+        // ---------------- layer 0: [x_t | h0_{t-1}] ----------------
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = bias_l0[n * 32];
+        mfma_groups<NT>(acc, breg, Xs + lane, KG0, wlane, gnext, KGT);
+        __syncthreads();
+        lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
+        if (have_next) {
+#pragma unroll
+            for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
+        }
+        if (t > 0) fc_store(t - 1);
+        __syncthreads();
+        // ---------------- layer 1: [h1_{t-1} | h0_t] ----------------
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = bias_l1[n * 32];
+        mfma_groups<NT>(acc, breg, H1s + lane, KGH, wlane, gnext, KGT);
+        mfma_groups<NT>(acc, breg, H0s + lane, KGH, wlane, gnext, KGT);
+        __syncthreads();
+        lstm_cell<ST, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
+    }
+    __syncthreads();
+    fc_store(Tp - 1);
+}
+
+// -------------------------------------------------------------------------------------------------
+size_t lstm_pack_floats(int H, int KX) {
+    const int NT = 4 * (H / 4 / 32);
+    const int KGT = KX / 8 + H / 8 + 2 * (H / 8);
+    return (size_t)4 * KGT * NT * 64 * 4;
+}
+
+void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1,
+                       const float* whh1, float* wpack) {
+    const int UW = H / 4, ST = UW / 32, NT = 4 * ST;
+    const int KGX = KX / 8, KGH = H / 8, KG0 = KGX + KGH, KGT = KG0 + 2 * KGH;
+    for (int wv = 0; wv < 4; ++wv)
+        for (int g = 0; g < KGT; ++g)
+            for (int n = 0; n < NT; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int p = 0; p < 4; ++p) {
+                        const int gate = n / ST, s = n % ST;
+                        const int wrow = gate * H + wv * UW + s * 32 + (lane & 31);
+                        float v = 0.0f;
+                        if (g < KG0) {
+                            const int k = 8 * g + 2 * p + (lane >> 5);
+                            if (k < KX) { if (k < NIN) v = wih0[(size_t)wrow * NIN + k]; }
+                            else v = whh0[(size_t)wrow * H + (k - KX)];
+                        } else {
+                            const int k = 8 * (g - KG0) + 2 * p + (lane >> 5);
+                            if (k < H) v = whh1[(size_t)wrow * H + k];
+                            else v = wih1[(size_t)wrow * H + (k - H)];
+                        }
+                        wpack[((((size_t)wv * KGT + g) * NT + n) * 64 + lane) * 4 + p] = v;
+                    }
+}
+
+void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    constexpr int HID = 384, KX = 40, OUT = 2;
+    constexpr int KGX = KX / 8, KGH = HID / 8;
+    const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * KGH * 2 * 16 + 32 * sizeof(RowDesc) +
+                        (size_t)2 * 4 * (4 * (HID / 4 / 32)) * 32 * 4;
+    static bool attr_set = false;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const int tiles = cdiv(a.num_rows, 32);
+    if (tiles <= 0) return;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, w, a);
+}
+
+}  // namespace fsnp

@@ -1,0 +1,116 @@
+// subband.hip - statistics of the sub-band input tensor without materialising it.
+//
+// The reference builds sb_input[b, f, j, t] = cat(unfold(att_mag, 15), fb_mag, fb_real, fb_imag)
+// (speech_enhance/fullsubnet_plus/model/fullsubnet_plus.py:167-188; BaseModel.unfold
+// speech_enhance/audio_zen/model/base_model.py:15-47) - a [B,257,34,T'] tensor, 143 MB at B=32 - and then
+// applies self.norm to it (fullsubnet_plus.py:189).  Here:
+//   offline norms   : sum / sumsq over the tensor == sum_r w_r * rowstat(att_mag[:, r]) + rowstats(fb*),
+//                     where w_r = number of (f, j) pairs whose reflect-padded neighbour index is r;
+//   cumulative norms: the reshape to [B*257, 34, T'] (base_model.py:237-238, 288-289) makes the running
+//                     statistics per sub-band sequence -> one (m_t, d_t) table row per sequence.
+// The LSTM kernel applies (x - m) / d while it gathers its input frame.
+#include "fsnp_common.h"
+
+namespace fsnp {
+
+#define FSNP_EPS 1.1920928955078125e-07f
+
+__device__ __forceinline__ NormMD sb_norm_md(int norm_type, double sum, double sq, double count) {
+    NormMD r;
+    const double mean = sum / count;
+    if (norm_type == FSNP_NORM_OFFLINE_LAPLACE) { r.m = 0.f; r.d = (float)mean + 1e-5f; }
+    else if (norm_type == FSNP_NORM_CUMULATIVE_LAPLACE) { r.m = 0.f; r.d = (float)mean + FSNP_EPS; }
+    else if (norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
+        double var = (sq - count * mean * mean) / (count - 1.0);
+        if (var < 0) var = 0;
+        r.m = (float)mean; r.d = (float)sqrt(var) + 1e-5f;
+    } else {
+        const double var = (sq - 2.0 * mean * sum) / count + mean * mean;
+        r.m = (float)mean; r.d = (float)sqrt(var + (double)FSNP_EPS);
+    }
+    return r;
+}
+
+constexpr int SB_ROWS = 16;
+__global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
+                                                               const float* __restrict__ fb, long fb_bs,
+                                                               const float* __restrict__ refl_w,
+                                                               double* __restrict__ acc, int Tp, int F, int FP) {
+    __shared__ double red[8];
+    const int b = blockIdx.y, t0 = blockIdx.x * SB_ROWS, t1 = min(t0 + SB_ROWS, Tp);
+    double s = 0.0, q = 0.0;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const double wr = refl_w[f];
+        for (int t = t0; t < t1; ++t) {
+            const long i = ((long)b * Tp + t) * FP + f;
+            const double a = att_mag[i];
+            s += wr * a;
+            q += wr * a * a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double v = fb[k * fb_bs + i];
+                s += v;
+                q += v * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + b * 2, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(acc + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
+__global__ void sb_offline_final_kernel(const double* __restrict__ acc, NormMD* __restrict__ md_utt, int B,
+                                        double count, int norm_type) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) md_utt[b] = sb_norm_md(norm_type, acc[b * 2], acc[b * 2 + 1], count);
+}
+
+// one thread per sub-band sequence, serial in t (cumulative norms only)
+__global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restrict__ att_mag,
+                                                           const float* __restrict__ fb, long fb_bs,
+                                                           const RowDesc* __restrict__ rows, NormMD* __restrict__ md_row,
+                                                           int num_rows, int Tp, int F, int FP, int nsbn, int nin,
+                                                           int norm_type) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= num_rows) return;
+    const RowDesc rd = rows[row];
+    if (!rd.valid) return;
+    double cs = 0.0, cq = 0.0;
+    const int nsb = 2 * nsbn + 1;
+    for (int t = 0; t < Tp; ++t) {
+        const long base = ((long)rd.b * Tp + t) * FP;
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < nsb; ++j) {
+            const double v = att_mag[base + reflect_index(rd.f - nsbn + j, F)];
+            s += v; q += v * v;
+        }
+        for (int k = 0; k < 3; ++k) {
+            const double v = fb[k * fb_bs + base + rd.f];
+            s += v; q += v * v;
+        }
+        cs += s; cq += q;
+        md_row[(long)row * Tp + t] = sb_norm_md(norm_type, cs, cq, (double)nin * (t + 1));
+    }
+}
+
+void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
+                          int num_rows, hipStream_t s) {
+    const long fb_bs = (long)d.B * d.Tp * d.FP;
+    if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
+        hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, SB_ROWS), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
+                           fb_bs, buf.refl_w, buf.acc, d.Tp, d.F, d.FP);
+        hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
+                           (double)d.F * d.NIN * d.Tp, norm_type);
+    } else {
+        hipLaunchKernelGGL(sb_cumulative_kernel, dim3(cdiv(num_rows, 64)), dim3(64), 0, s, buf.att_mag, buf.fb, fb_bs,
+                           rows, buf.md_row, num_rows, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, d.NIN, norm_type);
+    }
+}
+
+}  // namespace fsnp

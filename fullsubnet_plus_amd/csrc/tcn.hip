@@ -1,0 +1,331 @@
+// tcn.hip - the three full-band TCN sequence models on gfx950, all branches in each launch.
+//
+// Replaces SequenceModel.forward's TCN branch (speech_enhance/audio_zen/model/module/sequence_model.py:
+// 106-112; stack :48-57) and TCNBlock.forward (speech_enhance/audio_zen/model/module/causal_conv.py:96-108):
+//     y = conv1x1(x) -> PReLU -> GroupNorm(1, 512, eps=1e-8) -> depthwise dilated conv (k=3, non-causal)
+//       -> PReLU -> GroupNorm -> sconv (1x1) ;  x <- x + y            (x 8, dilations 1,2,5,9,1,2,5,9)
+//     fb = act(Linear(ReLU(x)))
+//
+// Layout: activations are time-major [branch][utt][t][channel], so a 1x1 conv over all frames of all
+// utterances is ONE row-major GEMM  C[M = B*T'][N] = A[M][K] * W[N][K]^T  on v_mfma_f32_32x32x2_f32
+// (exact fp32).  GroupNorm(1, C) needs statistics over the whole (C x T') plane of one utterance: the
+// producing kernel's epilogue accumulates (sum, sum of squares) in fp64 and adds them to a per-utterance
+// fp64 slot with one atomic pair per workgroup (row tiles never straddle utterances); the consuming
+// kernel applies the per-utterance scalars + per-channel affine while it loads its operand, so no
+// normalised tensor is ever written.
+#include "fsnp_common.h"
+
+namespace fsnp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_RELU = 2 };
+enum { EPI_PRELU_STATS = 0, EPI_RESIDUAL = 1, EPI_ACT = 2 };
+
+struct GemmArgs {
+    const float* A; long a_bs; int lda;        // A[branch][utt][t][lda]
+    const float* W; long w_bs; int ldw;        // W[branch][Npad][ldw], zero padded
+    const float* bias; long bias_bs;           // [branch][Npad]
+    float* C; long c_bs; int ldc;              // C[branch][utt][t][ldc]
+    const float* R; long r_bs; int ldr;        // residual (EPI_RESIDUAL)
+    const double* gn_in;                       // [branch][utt][2]   (PRO_GN)
+    const float* gamma; const float* beta; long gb_bs;  // [branch][K] (PRO_GN)
+    double* gn_out;                            // [branch][utt][2]   (EPI_PRELU_STATS)
+    const float* prelu; long prelu_bs;         // [branch] scalar slope (EPI_PRELU_STATS)
+    int K, N, Tp, B, act;
+    double gn_count;                           // elements per GroupNorm plane (PRO_GN)
+    float gn_eps;
+};
+
+constexpr int BM = 128, BN = 64, BK = 16;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * 4 + 2 * 2 * BN * 4 + 16];
+    float* As = smem;                       // [kg 2][kh 2][BM][4]
+    float* Bs = smem + 2 * 2 * BM * 4;      // [kg 2][kh 2][BN][4]
+    double* red = reinterpret_cast<double*>(smem + 2 * 2 * BM * 4 + 2 * 2 * BN * 4);  // [8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int branch = blockIdx.z;
+    const int tiles_per_utt = cdiv(g.Tp, BM);
+    const int utt = blockIdx.y / tiles_per_utt;
+    const int t0 = (blockIdx.y % tiles_per_utt) * BM;
+    const int n0 = blockIdx.x * BN;
+
+    const float* __restrict__ A = g.A + branch * g.a_bs + ((long)utt * g.Tp) * g.lda;
+    const float* __restrict__ W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
+
+    float mean = 0.f, rstd = 1.f;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    if constexpr (PRO == PRO_GN) {
+        const double* st = g.gn_in + ((long)branch * g.B + utt) * 2;
+        const double m = st[0] / g.gn_count;
+        const double var = st[1] / g.gn_count - m * m;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps));
+        gamma = g.gamma + branch * g.gb_bs;
+        beta = g.beta + branch * g.gb_bs;
+    }
+
+    // staging assignment: A rows ar0, ar0+64 ; k quad kq ; B column bc
+    const int kq = (tid & 3) * 4;
+    const int ar0 = tid >> 2;
+    const int bc = tid >> 2;
+    float4 areg[2], breg;
+
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = t0 + ar0 + 64 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < g.Tp && k < g.K) {
+                const float* p = A + (long)t * g.lda + k;
+                if (k + 4 <= g.lda) v = *reinterpret_cast<const float4*>(p);
+                else { v.x = p[0]; if (k + 1 < g.lda) v.y = p[1]; if (k + 2 < g.lda) v.z = p[2]; }
+                if constexpr (PRO == PRO_GN) {
+                    const float4 ga = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
+                    const float4 be = *reinterpret_cast<const float4*>(beta + k);
+                    v.x = (v.x - mean) * rstd * ga.x + be.x;
+                    v.y = (v.y - mean) * rstd * ga.y + be.y;
+                    v.z = (v.z - mean) * rstd * ga.z + be.z;
+                    v.w = (v.w - mean) * rstd * ga.w + be.w;
+                }
+                if constexpr (PRO == PRO_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (k + 1 >= g.K) v.y = 0.f;
+                if (k + 2 >= g.K) v.z = 0.f;
+                if (k + 3 >= g.K) v.w = 0.f;
+            }
+            areg[i] = v;
+        }
+        breg = *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k);   // padded: always in range
+    };
+    auto store_tiles = [&]() {
+        // element k = kq+e  ->  kg = k>>3, p = (k>>1)&3, kh = k&1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = ar0 + 64 * i;
+            const float e[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kq + q;
+                As[(((k >> 3) * 2 + (k & 1)) * BM + row) * 4 + ((k >> 1) & 3)] = e[q];
+            }
+        }
+        const float e[4] = {breg.x, breg.y, breg.z, breg.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kq + q;
+            Bs[(((k >> 3) * 2 + (k & 1)) * BN + bc) * 4 + ((k >> 1) & 3)] = e[q];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int ktiles = g.ldw / BK;
+    load_tiles(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < ktiles) load_tiles((kt + 1) * BK);
+        const float4* As4 = reinterpret_cast<const float4*>(As);
+        const float4* Bs4 = reinterpret_cast<const float4*>(Bs);
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            const float4 b4 = Bs4[(kg * 2 + (lane >> 5)) * BN + wn * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 a4 = As4[(kg * 2 + (lane >> 5)) * BM + wm * 64 + i * 32 + (lane & 31)];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const int col = n0 + wn * 32 + (lane & 31);
+    const bool col_ok = col < g.N;
+    const float bias = g.bias[branch * g.bias_bs + col];
+    float* __restrict__ C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
+    double s = 0.0, q = 0.0;
+    float slope = 0.f;
+    if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (t < g.Tp && col_ok) {
+                float v = acc[i][r] + bias;
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    v = v >= 0.f ? v : slope * v;
+                    s += (double)v;
+                    q += (double)v * (double)v;
+                }
+                if constexpr (EPI == EPI_RESIDUAL)
+                    v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
+                if constexpr (EPI == EPI_ACT) {
+                    if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
+                }
+                C[(long)t * g.ldc + col] = v;
+            }
+        }
+    if constexpr (EPI == EPI_PRELU_STATS) {
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+        __syncthreads();
+        if (tid == 0) {
+            double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+            atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
+            atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm1 -> depthwise dilated conv (k=3, zero padding = dilation) -> PReLU2 (+ GroupNorm2 statistics)
+struct DwArgs {
+    const float* Y1; float* Y2; long y_bs;      // [branch][utt][t][CH]
+    const double* gn_in; double* gn_out;        // [branch][utt][2]
+    const float* gamma; const float* beta;      // [branch][CH]
+    const float* w; const float* b;             // [branch][3][CH], [branch][CH]
+    const float* prelu;                         // [branch]
+    long cb_bs, w_bs, prelu_bs;
+    int CH, Tp, B, dil;
+    double gn_count; float gn_eps;
+};
+constexpr int DW_ROWS = 8;
+
+__global__ __launch_bounds__(256) void tcn_dwconv_kernel(DwArgs g) {
+    __shared__ double red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int branch = blockIdx.z, utt = blockIdx.y, t0 = blockIdx.x * DW_ROWS;
+    const double* st = g.gn_in + ((long)branch * g.B + utt) * 2;
+    const double m = st[0] / g.gn_count;
+    const double var = st[1] / g.gn_count - m * m;
+    const float mean = (float)m;
+    const float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps));
+    const float slope = g.prelu[branch * g.prelu_bs];
+    const float* __restrict__ Y1 = g.Y1 + branch * g.y_bs + (long)utt * g.Tp * g.CH;
+    float* __restrict__ Y2 = g.Y2 + branch * g.y_bs + (long)utt * g.Tp * g.CH;
+    const int quads = g.CH / 4;
+    double s = 0.0, q = 0.0;
+    for (int item = tid; item < DW_ROWS * quads; item += 256) {
+        const int c = (item % quads) * 4;
+        const int t = t0 + item / quads;
+        if (t >= g.Tp) continue;
+        const float4 ga = *reinterpret_cast<const float4*>(g.gamma + branch * g.cb_bs + c);
+        const float4 be = *reinterpret_cast<const float4*>(g.beta + branch * g.cb_bs + c);
+        float4 acc = *reinterpret_cast<const float4*>(g.b + branch * g.cb_bs + c);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tt = t + (j - 1) * g.dil;
+            if (tt < 0 || tt >= g.Tp) continue;     // zero padding of the NORMALISED tensor
+            const float4 y = *reinterpret_cast<const float4*>(Y1 + (long)tt * g.CH + c);
+            const float4 wj = *reinterpret_cast<const float4*>(g.w + branch * g.w_bs + (long)j * g.CH + c);
+            acc.x += wj.x * ((y.x - mean) * rstd * ga.x + be.x);
+            acc.y += wj.y * ((y.y - mean) * rstd * ga.y + be.y);
+            acc.z += wj.z * ((y.z - mean) * rstd * ga.z + be.z);
+            acc.w += wj.w * ((y.w - mean) * rstd * ga.w + be.w);
+        }
+        acc.x = acc.x >= 0.f ? acc.x : slope * acc.x;
+        acc.y = acc.y >= 0.f ? acc.y : slope * acc.y;
+        acc.z = acc.z >= 0.f ? acc.z : slope * acc.z;
+        acc.w = acc.w >= 0.f ? acc.w : slope * acc.w;
+        *reinterpret_cast<float4*>(Y2 + (long)t * g.CH + c) = acc;
+        s += (double)acc.x + (double)acc.y + (double)acc.z + (double)acc.w;
+        q += (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+        atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s) {
+    const long x_bs = (long)d.B * d.Tp * d.FP;
+    const long y_bs = (long)d.B * d.Tp * d.CH;
+    const int row_tiles = cdiv(d.Tp, BM) * d.B;
+    const double gn_count = (double)d.CH * d.Tp;
+    auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * 3) * d.B * 2; };
+
+    for (int blk = 0; blk < w.NB; ++blk) {
+        const float* xin = blk == 0 ? buf.att : buf.x;
+        {   // conv1x1 + PReLU1 (+ GN1 stats): y1[M][CH] = x[M][F] * W1^T
+            GemmArgs g{};
+            g.A = xin; g.a_bs = x_bs; g.lda = d.FP;
+            g.W = w.w1 + (long)blk * w.N1P * w.K1P; g.w_bs = (long)w.NB * w.N1P * w.K1P; g.ldw = w.K1P;
+            g.bias = w.b1 + (long)blk * w.N1P; g.bias_bs = (long)w.NB * w.N1P;
+            g.C = buf.y1; g.c_bs = y_bs; g.ldc = d.CH;
+            g.gn_out = gn_slot(blk, 0);
+            g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
+            g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
+            hipLaunchKernelGGL((tcn_gemm_kernel<PRO_NONE, EPI_PRELU_STATS>), dim3(w.N1P / BN, row_tiles, 3), dim3(256), 0, s, g);
+        }
+        {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
+            DwArgs g{};
+            g.Y1 = buf.y1; g.Y2 = buf.y2; g.y_bs = y_bs;
+            g.gn_in = gn_slot(blk, 0); g.gn_out = gn_slot(blk, 1);
+            g.gamma = w.g1w + (long)blk * d.CH; g.beta = w.g1b + (long)blk * d.CH;
+            g.b = w.db + (long)blk * d.CH; g.cb_bs = (long)w.NB * d.CH;
+            g.w = w.dw + (long)blk * 3 * d.CH; g.w_bs = (long)w.NB * 3 * d.CH;
+            g.prelu = w.a2 + blk; g.prelu_bs = w.NB;
+            g.CH = d.CH; g.Tp = d.Tp; g.B = d.B; g.dil = w.dilation[blk];
+            g.gn_count = gn_count; g.gn_eps = 1e-8f;
+            hipLaunchKernelGGL(tcn_dwconv_kernel, dim3(cdiv(d.Tp, DW_ROWS), d.B, 3), dim3(256), 0, s, g);
+        }
+        {   // GN2 (on load) -> sconv + residual: x[M][F] = xin + GN2(y2)[M][CH] * W2^T
+            GemmArgs g{};
+            g.A = buf.y2; g.a_bs = y_bs; g.lda = d.CH;
+            g.W = w.w2 + (long)blk * w.N2P * w.K2P; g.w_bs = (long)w.NB * w.N2P * w.K2P; g.ldw = w.K2P;
+            g.bias = w.b2 + (long)blk * w.N2P; g.bias_bs = (long)w.NB * w.N2P;
+            g.C = buf.x; g.c_bs = x_bs; g.ldc = d.FP;
+            g.R = xin; g.r_bs = x_bs; g.ldr = d.FP;
+            g.gn_in = gn_slot(blk, 1);
+            g.gamma = w.g2w + (long)blk * d.CH; g.beta = w.g2b + (long)blk * d.CH; g.gb_bs = (long)w.NB * d.CH;
+            g.K = d.CH; g.N = d.F; g.Tp = d.Tp; g.B = d.B;
+            g.gn_count = gn_count; g.gn_eps = 1e-8f;
+            hipLaunchKernelGGL((tcn_gemm_kernel<PRO_GN, EPI_RESIDUAL>), dim3(w.N2P / BN, row_tiles, 3), dim3(256), 0, s, g);
+        }
+        if (blk == 0 && buf.dbg_tcn0)
+            (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+    {   // ReLU (on load) -> Linear(F, F) -> activation
+        GemmArgs g{};
+        g.A = w.NB > 0 ? buf.x : buf.att; g.a_bs = x_bs; g.lda = d.FP;
+        g.W = w.wf; g.w_bs = (long)w.N2P * w.K1P; g.ldw = w.K1P;
+        g.bias = w.bf; g.bias_bs = w.N2P;
+        g.C = buf.fb; g.c_bs = x_bs; g.ldc = d.FP;
+        g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
+        hipLaunchKernelGGL((tcn_gemm_kernel<PRO_RELU, EPI_ACT>), dim3(w.N2P / BN, row_tiles, 3), dim3(256), 0, s, g);
+    }
+}
+
+}  // namespace fsnp

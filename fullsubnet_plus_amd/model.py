@@ -1,0 +1,325 @@
+"""FullSubNet+ as a drop-in ``nn.Module`` whose forward runs on libfsnp_hip.so.
+
+Mirrors the reference's plugin surface for the inference path:
+
+* constructor kwargs         speech_enhance/fullsubnet_plus/model/fullsubnet_plus.py:17-34
+* parameter tree (strict ``load_state_dict`` of reference checkpoints,
+  speech_enhance/audio_zen/inferencer/base_inferencer.py:100-107)
+* ``forward(noisy_mag, noisy_real, noisy_imag) -> [B, 2, F, T]``  fullsubnet_plus.py:122-209
+* attributes read by callers (``num_groups_in_drop_band``, ``look_ahead``, ...) fullsubnet_plus.py:111-117
+* error behaviour: ``AssertionError`` for bad input ranks / channel counts / B == 2
+  (fullsubnet_plus.py:136,141; acoustics/feature.py:263), ``NotImplementedError`` for
+  unknown options (base_model.py:328, sequence_model.py:72, fullsubnet_plus.py:70).
+
+The modules below only *hold parameters* with the reference's names; no torch op computes
+anything in ``forward``.  CPU tensors are rejected: there is deliberately no CPU fallback.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
+
+
+class _TSSEParams(nn.Module):
+    """Parameter holder named like ChannelTimeSenseSELayer (attention_model.py:49-76)."""
+
+    def __init__(self, num_channels, kersize, reduction_ratio=2):
+        super().__init__()
+        reduced = num_channels // reduction_ratio
+        for name, k in zip(("smallConv1d", "middleConv1d", "largeConv1d"), kersize):
+            setattr(self, name, nn.Sequential(nn.Conv1d(num_channels, num_channels, k, groups=num_channels)))
+        self.feature_concate_fc = nn.Linear(3, 1)
+        self.fc1 = nn.Linear(num_channels, reduced)
+        self.fc2 = nn.Linear(reduced, num_channels)
+
+
+class _TCNBlockParams(nn.Module):
+    """Parameter holder named like TCNBlock (causal_conv.py:68-94)."""
+
+    def __init__(self, channels, hidden, kernel_size=3):
+        super().__init__()
+        self.conv1x1 = nn.Conv1d(channels, hidden, 1)
+        self.prelu1 = nn.PReLU()
+        self.norm1 = nn.GroupNorm(1, hidden, eps=1e-8)
+        self.depthwise_conv = nn.Conv1d(hidden, hidden, kernel_size, groups=hidden)
+        self.prelu2 = nn.PReLU()
+        self.norm2 = nn.GroupNorm(1, hidden, eps=1e-8)
+        self.sconv = nn.Conv1d(hidden, channels, 1)
+
+
+class _FullBandParams(nn.Module):
+    """Parameter holder named like SequenceModel(sequence_model="TCN") (sequence_model.py:47-58,80-81)."""
+
+    def __init__(self, num_freqs, hidden):
+        super().__init__()
+        self.sequence_model = nn.Sequential(*[_TCNBlockParams(num_freqs, hidden) for _ in _TCN_DILATIONS])
+        self.fc_output_layer = nn.Linear(num_freqs, num_freqs)
+
+
+class _SubBandParams(nn.Module):
+    """Parameter holder named like SequenceModel(sequence_model="LSTM") (sequence_model.py:31-38,78-79)."""
+
+    def __init__(self, input_size, hidden, output_size):
+        super().__init__()
+        self.sequence_model = nn.LSTM(input_size, hidden, num_layers=2, batch_first=True)
+        self.fc_output_layer = nn.Linear(hidden, output_size)
+
+
+class _HipState:
+    """Owns the fsnp_handle (plain object: its finaliser must not go through nn.Module.__setattr__)."""
+
+    def __init__(self):
+        self.handle = None
+        self.device = None
+        self.packed_key = None
+
+    def close(self):
+        h, self.handle, self.device, self.packed_key = self.handle, None, None, None
+        if h is not None:
+            try:
+                _lib.load().fsnp_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # a copied / pickled module gets its own handle lazily
+    def __deepcopy__(self, memo):
+        return _HipState()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+
+def _reference_style_init(m):
+    """Behaviour of BaseModel.weight_init (base_model.py:332-397) for the module kinds on this path."""
+    if isinstance(m, nn.Conv1d):
+        nn.init.normal_(m.weight)
+        if m.bias is not None:
+            nn.init.normal_(m.bias)
+    elif isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight)
+        nn.init.normal_(m.bias)
+    elif isinstance(m, nn.LSTM):
+        for p in m.parameters():
+            (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p)
+
+
+class FullSubNet_Plus(nn.Module):
+    def __init__(self,
+                 num_freqs,
+                 look_ahead,
+                 sequence_model,
+                 fb_num_neighbors,
+                 sb_num_neighbors,
+                 fb_output_activate_function,
+                 sb_output_activate_function,
+                 fb_model_hidden_size,
+                 sb_model_hidden_size,
+                 channel_attention_model="SE",
+                 norm_type="offline_laplace_norm",
+                 num_groups_in_drop_band=2,
+                 output_size=2,
+                 subband_num=1,
+                 kersize=[3, 5, 10],
+                 weight_init=True,
+                 ):
+        super().__init__()
+        assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
+        if sequence_model != "LSTM":
+            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM only)")
+        if channel_attention_model != "TSSE":
+            raise NotImplementedError(f"HIP path: channel attention model {channel_attention_model} is not built yet (TSSE only)")
+        if subband_num != 1:
+            raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
+        if fb_num_neighbors != 0:
+            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
+        if norm_type not in _lib.NORM_TYPES:
+            raise NotImplementedError("You must set up a type of Norm. "
+                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
+        for act in (fb_output_activate_function, sb_output_activate_function):
+            if act and act not in _lib.ACTIVATIONS:
+                raise NotImplementedError(f"Not implemented activation function {act}")
+
+        self.num_channels = num_freqs
+        self.channel_attention = _TSSEParams(num_freqs, kersize)
+        self.channel_attention_real = _TSSEParams(num_freqs, kersize)
+        self.channel_attention_imag = _TSSEParams(num_freqs, kersize)
+        # NB: the reference hard-codes the TCNBlock hidden width to 512 (causal_conv.py:68) and ignores
+        # fb_model_hidden_size for the TCN full-band models (sequence_model.py:48-57).
+        self.fb_model = _FullBandParams(num_freqs, 512)
+        self.fb_model_real = _FullBandParams(num_freqs, 512)
+        self.fb_model_imag = _FullBandParams(num_freqs, 512)
+        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1),
+                                       sb_model_hidden_size, output_size)
+
+        self.subband_num = subband_num
+        self.sb_num_neighbors = sb_num_neighbors
+        self.fb_num_neighbors = fb_num_neighbors
+        self.look_ahead = look_ahead
+        self.norm_type = norm_type
+        self.num_groups_in_drop_band = num_groups_in_drop_band
+        self.output_size = output_size
+        self.num_freqs = num_freqs
+        self.kersize = list(kersize)
+        self.fb_output_activate_function = fb_output_activate_function
+        self.sb_output_activate_function = sb_output_activate_function
+        self.sb_model_hidden_size = sb_model_hidden_size
+        # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196);
+        # "full": every utterance keeps all bins (== the reference run per utterance), the inference workload.
+        self.batch_mode = "parity"
+
+        self._hip = _HipState()
+        if weight_init:
+            self.apply(_reference_style_init)
+
+    # ------------------------------------------------------------------ handle / weights
+    def _config(self):
+        cfg = _lib.FsnpConfig()
+        cfg.num_freqs = self.num_freqs
+        cfg.look_ahead = self.look_ahead
+        cfg.sb_num_neighbors = self.sb_num_neighbors
+        cfg.fb_num_neighbors = self.fb_num_neighbors
+        cfg.tcn_hidden = 512
+        cfg.num_tcn_blocks = len(_TCN_DILATIONS)
+        cfg.sb_hidden = self.sb_model_hidden_size
+        cfg.output_size = self.output_size
+        cfg.norm_type = _lib.NORM_TYPES[self.norm_type]
+        cfg.fb_act = _lib.ACTIVATIONS[self.fb_output_activate_function or None]
+        cfg.sb_act = _lib.ACTIVATIONS[self.sb_output_activate_function or None]
+        for i, k in enumerate(self.kersize):
+            cfg.kersize[i] = int(k)
+        cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
+        return cfg
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _ensure_handle(self, device):
+        lib = _lib.load()
+        st = self._hip
+        if st.handle is not None and st.device != device:
+            st.close()
+        if st.handle is None:
+            with torch.cuda.device(device):
+                hp = ctypes.c_void_p()
+                cfg = self._config()
+                _lib.check(lib.fsnp_create(ctypes.byref(cfg), ctypes.byref(hp)), "fsnp_create")
+            st.handle, st.device, st.packed_key = hp, device, None
+        key = self._weights_key()
+        if key != st.packed_key:
+            for name, tensor in self.state_dict().items():
+                t = tensor.detach().to("cpu", torch.float32).contiguous()
+                _lib.check(lib.fsnp_set_weight(st.handle, name.encode(), t.data_ptr(), t.numel()),
+                           f"fsnp_set_weight({name})")
+            with torch.cuda.device(device):
+                _lib.check(lib.fsnp_commit_weights(st.handle), "fsnp_commit_weights")
+            st.packed_key = key
+        return lib
+
+    @property
+    def _handle(self):
+        if self._hip.handle is None:
+            raise RuntimeError("no HIP handle yet: run a forward on a CUDA tensor first")
+        return self._hip.handle
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, noisy_mag, noisy_real, noisy_imag, batch_offset=0, global_batch=None):
+        """
+        Shapes:
+            noisy_mag / noisy_real / noisy_imag: [B, 1, F, T] fp32 CUDA tensors (any strides)
+            return: [B, 2, F, T]   (B == 1 or batch_mode == "full")
+                    [B, 2, F//2, T] with the reference's drop_band row order (B > 1, batch_mode == "parity")
+        batch_offset / global_batch: only for sharded batches (fullsubnet_plus_amd.dist).
+        """
+        assert noisy_mag.dim() == 4
+        batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
+        assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
+        assert noisy_real.shape == noisy_mag.shape and noisy_imag.shape == noisy_mag.shape
+        assert num_freqs == self.num_freqs, f"expected {self.num_freqs} frequency bins, got {num_freqs}"
+        if not noisy_mag.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; move the model and inputs to 'cuda'. "
+                               "There is deliberately no CPU fallback.")
+        device = noisy_mag.device
+        gb = batch_size if global_batch is None else int(global_batch)
+        parity = gb > 1 and self.batch_mode == "parity"
+        if parity:
+            assert gb > self.num_groups_in_drop_band, \
+                f"Batch size = {gb}, num_groups = {self.num_groups_in_drop_band}. " \
+                f"The batch size should larger than the num_groups."
+            if self.num_groups_in_drop_band != 2:
+                raise NotImplementedError("HIP path: drop_band with num_groups != 2 is not built yet")
+        ins = []
+        for t in (noisy_mag, noisy_real, noisy_imag):
+            if t.dtype != torch.float32:
+                t = t.float()
+            assert t.device == device
+            ins.append(t)
+        lib = self._ensure_handle(device)
+        out_f = num_freqs // 2 if parity else num_freqs
+        standalone = global_batch is None
+        out = torch.empty((gb if parity else batch_size, 2, out_f, num_frames), dtype=torch.float32, device=device)
+        if parity and not standalone:
+            out.zero_()     # a shard writes only its own rows of the global tensor
+        strides = (ctypes.c_int64 * 3 * 3)()
+        for i, t in enumerate(ins):
+            sb, _, sf, st = t.stride()
+            strides[i][0], strides[i][1], strides[i][2] = sb, sf, st
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.fsnp_forward(self._handle, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(),
+                                  ctypes.byref(strides), out.data_ptr(), batch_size, num_frames,
+                                  _lib.MODE_PARITY if parity else _lib.MODE_FULL, int(batch_offset), gb,
+                                  ctypes.c_void_p(stream))
+        _lib.check(rc, "fsnp_forward")
+        return out
+
+    # ------------------------------------------------------------------ test / bench helpers
+    def lstm2_fc(self, x):
+        """Fused sub-band LSTM + Linear alone (sequence_model.py:113-123): x [N, input, T] -> [N, 2, T]."""
+        assert x.dim() == 3 and x.is_cuda
+        lib = self._ensure_handle(x.device)
+        n, _, steps = x.shape
+        xt = x.permute(0, 2, 1).contiguous().float()
+        out = torch.empty((n, 2, steps), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsnp_lstm2_fc(self._handle, xt.data_ptr(), out.data_ptr(), n, steps,
+                                         ctypes.c_void_p(stream)), "fsnp_lstm2_fc")
+        return out
+
+    def read_stage(self, name, batch, frames):
+        """Stage buffer of the last forward, time-major: [B, T', F] (gates: [B, F])."""
+        lib = _lib.load()
+        rows = batch if name.startswith("gate_") else batch * (frames + self.look_ahead)
+        host = torch.empty((rows, self.num_freqs), dtype=torch.float32)
+        _lib.check(lib.fsnp_read_stage(self._handle, name.encode(), host.data_ptr(), host.numel()), "fsnp_read_stage")
+        return host if name.startswith("gate_") else host.view(batch, frames + self.look_ahead, self.num_freqs)
+
+    def set_timing(self, enable=True):
+        _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")
+
+    def get_timing(self, reset=True):
+        """-> {"lstm_ms", "fullband_ms", "forward_ms", "count"}: hipEvent sums on the forward's stream."""
+        ms = (ctypes.c_double * 3)()
+        cnt = (ctypes.c_int64 * 3)()
+        _lib.check(_lib.load().fsnp_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(cnt), int(reset)),
+                   "fsnp_get_timing")
+        return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "count": int(cnt[0])}
+
+    def forward_flops(self, batch, frames, parity=False):
+        return float(_lib.load().fsnp_forward_flops(self._handle, batch, frames, int(parity)))
+
+
+Model = FullSubNet_Plus  # the name BASELINE.json's north_star uses

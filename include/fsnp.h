@@ -1,0 +1,141 @@
+/*
+ * fsnp.h - C ABI of libfsnp_hip.so: the MI355X (gfx950) FullSubNet+ inference forward.
+ *
+ * The reference (RookieJunChen/FullSubNet-plus) is pure Python and has no FFI; its
+ * plugin boundary for this path is
+ *     initialize_module(config["model"]["path"], args=config["model"]["args"])
+ *         speech_enhance/audio_zen/inferencer/base_inferencer.py:99
+ *     model.load_state_dict(ckpt["model"])            base_inferencer.py:100-107
+ *     pred_crm = self.model(noisy_mag, noisy_real, noisy_imag)
+ *         speech_enhance/fullsubnet_plus/inferencer/inferencer.py:150
+ * Each entry point below states which of those steps it replaces.  The Python class
+ * fullsubnet_plus_amd.model.FullSubNet_Plus binds these with ctypes (see
+ * INTEGRATION.md); nothing here takes a torch type.
+ *
+ * All functions return 0 on success, non-zero on error (message: fsnp_last_error()).
+ * No function aborts.  A handle is not thread-safe; distinct handles are independent.
+ * All device work is enqueued on the caller's HIP stream; no device synchronisation
+ * happens inside fsnp_forward.
+ */
+#ifndef FSNP_H
+#define FSNP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fsnp_handle fsnp_handle;
+
+/* norm_type of FullSubNet_Plus.__init__ (fullsubnet_plus.py:28, base_model.py:318-330) */
+enum {
+    FSNP_NORM_OFFLINE_LAPLACE = 0,    /* base_model.py:210-225 */
+    FSNP_NORM_CUMULATIVE_LAPLACE = 1, /* base_model.py:227-258 */
+    FSNP_NORM_OFFLINE_GAUSSIAN = 2,   /* base_model.py:260-275 */
+    FSNP_NORM_CUMULATIVE_LAYER = 3    /* base_model.py:277-316 */
+};
+
+/* output activation of SequenceModel (sequence_model.py:85-96); 0 == TOML `false` */
+enum { FSNP_ACT_NONE = 0, FSNP_ACT_RELU = 1, FSNP_ACT_RELU6 = 2, FSNP_ACT_TANH = 3 };
+
+/* B > 1 semantics */
+enum {
+    FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,2,F,T]          */
+    FSNP_MODE_PARITY = 1 /* reproduces drop_band (feature.py:254-285): out [B,2,F/2,T],      */
+                         /* rows re-ordered even samples first - the reference's literal B>1 */
+};
+
+/* Mirrors the constructor kwargs of FullSubNet_Plus (fullsubnet_plus.py:17-34). */
+typedef struct fsnp_config {
+    int32_t num_freqs;          /* 257 */
+    int32_t look_ahead;         /* 2   */
+    int32_t sb_num_neighbors;   /* 15  */
+    int32_t fb_num_neighbors;   /* 0 (only 0 is supported by the HIP path) */
+    int32_t tcn_hidden;         /* 512: TCNBlock hidden_channel (causal_conv.py:68) */
+    int32_t num_tcn_blocks;     /* 8, dilations 1,2,5,9,1,2,5,9 (sequence_model.py:48-57) */
+    int32_t sb_hidden;          /* 384: sb_model_hidden_size */
+    int32_t output_size;        /* 2 */
+    int32_t norm_type;          /* FSNP_NORM_* */
+    int32_t fb_act;             /* FSNP_ACT_* : fb_output_activate_function */
+    int32_t sb_act;             /* FSNP_ACT_* : sb_output_activate_function */
+    int32_t kersize[3];         /* 3,5,10 : TSSE depthwise kernel sizes (attention_model.py:49) */
+    int32_t num_groups_in_drop_band; /* 2 (only 2 is supported in PARITY mode) */
+} fsnp_config;
+
+/* Replaces `FullSubNet_Plus(**model.args)` (base_inferencer.py:99).  Needs a visible
+ * gfx950 device; returns an error (never falls back to the CPU) otherwise. */
+int fsnp_create(const fsnp_config* cfg, fsnp_handle** out);
+void fsnp_destroy(fsnp_handle* h);
+
+/* Replaces `load_state_dict` (base_inferencer.py:107): hand over one tensor of the
+ * reference state_dict by its reference name (e.g.
+ * "sb_model.sequence_model.weight_hh_l0"), as contiguous fp32 in HOST memory with the
+ * reference's shape.  Unknown names or wrong sizes are errors (strict loading). */
+int fsnp_set_weight(fsnp_handle* h, const char* name, const float* host_data, int64_t numel);
+/* Packs everything into the device layouts (MFMA fragment order etc.).  Fails if any
+ * tensor of the parameter tree is missing.  Call again after changing weights. */
+int fsnp_commit_weights(fsnp_handle* h);
+/* Number of tensors / i-th tensor name+numel the handle expects (for strict loaders). */
+int fsnp_num_weights(const fsnp_handle* h);
+int fsnp_weight_info(const fsnp_handle* h, int index, const char** name, int64_t* numel);
+
+/* Device workspace (owned by the handle, grown on demand) needed for a [B,T] forward. */
+size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
+
+/* Replaces `self.model(noisy_mag, noisy_real, noisy_imag)` (inferencer.py:150;
+ * FullSubNet_Plus.forward fullsubnet_plus.py:122-209).
+ *   mag/real/imag : DEVICE pointers to the [B,1,F,T] fp32 inputs; strides[i] = element
+ *                   strides (batch, freq, time) of input i - torch.stft views are
+ *                   non-contiguous and are consumed in place (no .contiguous()).
+ *   out           : DEVICE pointer, contiguous fp32 [B,2,F,T] (FULL) or [B,2,F/2,T] (PARITY).
+ *   batch_offset/global_batch : this call's utterances are samples
+ *                   [batch_offset, batch_offset+batch) of a global batch (multi-GPU
+ *                   sharding of PARITY mode needs the global sample parity and the global
+ *                   row order; for single-GPU use 0 / batch).  In PARITY mode `out` is the
+ *                   GLOBAL [global_batch,2,F/2,T] tensor base and only this shard's rows
+ *                   are written.
+ *   hip_stream    : hipStream_t to enqueue on (NULL = default stream). */
+int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
+                 const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
+                 int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream);
+
+/* Stage-level entry point (unit tests, f-2 wiring): the fused two-layer LSTM + Linear
+ * of SequenceModel.forward (sequence_model.py:113-123) on a dense input.
+ *   x   : DEVICE fp32 [N, T, input_size]  (time-major rows, i.e. x.permute(0,2,1))
+ *   out : DEVICE fp32 [N, output_size, T] */
+int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
+                  void* hip_stream);
+
+/* Copy an internal stage buffer of the LAST forward to host (tests / debugging).
+ * names: "att_mag","att_real","att_imag" [B,T',F]; "fb_mag","fb_real","fb_imag" [B,T',F];
+ *        "tcn0_mag" [B,T',F] (after the first TCN block); "gate_mag|real|imag" [B,F].
+ * (time-major: element (b,t,f)).  Synchronises the device. */
+int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t numel);
+
+/* Per-kernel timing with hipEvents recorded on the forward's own stream.
+ * enable != 0 turns it on for subsequent forwards (adds event records only).
+ * fsnp_get_timing synchronises, then returns the accumulated milliseconds and launch
+ * counts since the last reset: index 0 = fused sub-band LSTM kernel, 1 = full-band
+ * (frontend+TCN) kernels, 2 = whole forward. */
+int fsnp_set_timing(fsnp_handle* h, int32_t enable);
+int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t reset);
+
+/* Static facts for roofline accounting: algorithmic FLOPs of one forward. */
+double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
+double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
+
+/* Test hook (host only, no GPU needed): run the LSTM weight packer that fsnp_commit_weights uses.
+ * out receives 4 * (kx/8 + 3*hidden/8) * (hidden/32) * 64 * 4 floats in MFMA B-fragment order
+ * [wave][k-group][tile][lane][k-pair] (layout documented in csrc/lstm.hip). */
+int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0,
+                         const float* wih1, const float* whh1, float* out, int64_t out_floats);
+
+const char* fsnp_last_error(void);
+const char* fsnp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSNP_H */

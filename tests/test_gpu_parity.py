@@ -1,0 +1,187 @@
+"""GPU parity tests (run on an MI355X through gpurun): the HIP forward, called through the C ABI,
+against (a) the golden vectors the REAL reference produced (tests/golden, oracle/make_golden.py) and
+(b) the torch-CPU oracle restatement (oracle/fsnp_torch.py) at BASELINE.json sizes.
+
+Tolerance: BASELINE.json's north_star states "within 1e-3 rel on fp32"; rel = max|hip - ref| / max|ref|.
+Every test asserts rel < 1e-3 (TOL) and records the measured value in gpurun_out/parity_report.json;
+tighter bounds are asserted where the kernels are expected to do much better.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fullsubnet_plus_amd import FullSubNet_Plus
+from oracle import fsnp_torch
+from oracle.make_golden import make_spec
+from oracle.ref_loader import DEFAULT_MODEL_ARGS
+from oracle.weights import make_inputs, make_state_dict
+from tests._util import Golden, golden_names, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+
+
+def _record(name, **kw):
+    REPORT[name] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in kw.items()}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _model(args, sd, mode="parity"):
+    m = FullSubNet_Plus(**args)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    m.batch_mode = mode
+    return m
+
+
+def _cuda(ts):
+    """Move to the GPU keeping the (non-contiguous, stft-like) strides."""
+    out = []
+    for t in ts:
+        g = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device="cuda")
+        g.copy_(t)
+        out.append(g)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("profile,n,steps", [("default", 70, 12), ("harsh", 33, 40), ("default", 256, 6)])
+def test_lstm2_fc_dense_vs_oracle(profile, n, steps):
+    """Fused LSTM kernel alone on dense inputs (ragged tile counts) vs torch.lstm + linear."""
+    sd = make_state_dict(3, profile)
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    rng = np.random.Generator(np.random.PCG64(1234 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    err = rel_err(got, want)
+    per_step = np.abs(got - want).max(axis=(0, 1)) / np.abs(want).max()
+    per_row = np.abs(got - want).max(axis=(1, 2)) / np.abs(want).max()
+    _record(f"lstm_dense_{profile}_{n}x{steps}", rel=err, first_steps=per_step[:4].tolist(),
+            worst_rows=np.argsort(-per_row)[:8].tolist(), worst_row_err=float(per_row.max()))
+    assert err < 2e-5, (err, per_step[:6], np.argsort(-per_row)[:8])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "stages" in n or "t30" in n])
+def test_stages_vs_reference(name):
+    """Intermediate buffers (TSSE output, full-band outputs) vs forward-hook captures of the reference."""
+    g = Golden(name)
+    m = _model(g.args, g.state_dict())
+    mag, real, imag = g.inputs()
+    B, T = mag.shape[0], mag.shape[-1]
+    m(*_cuda((mag, real, imag)))
+    errs = {}
+    for tag in ("att_mag", "att_real", "att_imag", "fb_mag", "fb_real", "fb_imag"):
+        want = g.arrays["stage_" + tag]                       # [B,F,T']
+        got = m.read_stage(tag, B, T).permute(0, 2, 1).numpy()
+        errs[tag] = rel_err(got, want)
+    _record(f"stages_{name}", **errs)
+    for tag, e in errs.items():
+        assert e < 2e-4, (tag, errs)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_vs_reference_golden(name):
+    """The reference's literal batched call (drop_band active for B > 1) == batch_mode 'parity'."""
+    g = Golden(name)
+    m = _model(g.args, g.state_dict(), "parity")
+    mag, real, imag = g.inputs()
+    out = m(*_cuda((mag, real, imag))).cpu().numpy()[:, :, ::g.sub, :]
+    want = g.arrays["out"]
+    assert out.shape == want.shape
+    err, err64 = rel_err(out, want), rel_err(out, g.arrays["out64"])
+    ref_self = rel_err(want, g.arrays["out64"])
+    _record(f"forward_{name}", rel_vs_ref32=err, rel_vs_ref64=err64, ref32_vs_ref64=ref_self)
+    assert err < TOL, (err, err64, ref_self)
+    if "full" in g.arrays:
+        m.batch_mode = "full"
+        full = m(*_cuda((mag, real, imag))).cpu().numpy()[:, :, ::g.sub, :]
+        errf = rel_err(full, g.arrays["full"])
+        _record(f"forward_full_{name}", rel_vs_ref32=errf)
+        assert errf < TOL, errf
+
+
+def test_batch2_raises_like_reference():
+    g = Golden("b4_t16_default")
+    m = _model(g.args, g.state_dict(), "parity")
+    mag, real, imag = _cuda(g.inputs())
+    with pytest.raises(AssertionError):
+        m(mag[:2], real[:2], imag[:2])
+
+
+def test_contiguous_and_strided_inputs_agree():
+    g = Golden("b1_t24_default_stages")
+    m = _model(g.args, g.state_dict())
+    mag, real, imag = _cuda(g.inputs())
+    a = m(mag, real, imag)
+    b = m(mag.contiguous(), real.contiguous(), imag.contiguous())
+    assert not real.is_contiguous()
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1]: batch = 32 x 2 s clips, full + parity, against the oracle on the same inputs
+@pytest.fixture(scope="module")
+def b32():
+    sd = make_state_dict(0, "default")
+    mag, real, imag = make_inputs(32, 2.0, 100)
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    full = m(*_cuda((mag, real, imag))).cpu()
+    return sd, (mag, real, imag), m, full
+
+
+def test_b32_full_vs_oracle(b32):
+    sd, (mag, real, imag), m, full = b32
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    want = fsnp_torch.forward_full(sd, mag[:8], real[:8], imag[:8]).numpy()   # 8 utterances keep the CPU leg short
+    err = rel_err(full[:8].numpy(), want)
+    _record("b32_2s_full_vs_oracle_first8", rel=err)
+    assert full.shape == (32, 2, 257, 126)
+    assert err < TOL, err
+
+
+def test_b32_parity_vs_oracle_and_subselection(b32):
+    sd, (mag, real, imag), m, full = b32
+    m.batch_mode = "parity"
+    par = m(*_cuda((mag, real, imag))).cpu().numpy()
+    m.batch_mode = "full"
+    want = fsnp_torch.forward(sd, mag, real, imag).numpy()                    # literal reference semantics
+    err = rel_err(par, want)
+    _record("b32_2s_parity_vs_oracle", rel=err)
+    assert par.shape == (32, 2, 128, 126)
+    assert err < TOL, err
+    # size-independent property: parity rows are a sub-selection of full rows
+    fulln = full.numpy()
+    for r in range(32):
+        s, p = (2 * r, 0) if r < 16 else (2 * (r - 16) + 1, 1)
+        assert np.abs(par[r] - fulln[s][:, p:256:2, :]).max() < 1e-5 * np.abs(fulln).max()
+
+
+def test_b32_batch_independence(b32):
+    """Size-independent property: utterances are independent, so row b of the batch == the B=1 run."""
+    sd, (mag, real, imag), m, full = b32
+    for b in (0, 13, 31):
+        one = m(*_cuda((mag[b:b + 1], real[b:b + 1], imag[b:b + 1]))).cpu()
+        assert rel_err(one.numpy(), full[b:b + 1].numpy()) < 1e-5
+
+
+def test_long_clip_cumulative_norms_vs_oracle():
+    """BASELINE.json configs[3] flavour: 10 s clips (T=626), cumulative norms, oracle on the same inputs."""
+    for norm in ("cumulative_layer_norm", "cumulative_laplace_norm"):
+        args = {**DEFAULT_MODEL_ARGS, "norm_type": norm}
+        sd = make_state_dict(11, "default")
+        mag, real, imag = make_inputs(2, 10.0, 200)
+        m = _model(args, sd, "full")
+        got = m(*_cuda((mag, real, imag))).cpu().numpy()
+        want = fsnp_torch.forward_full(sd, mag, real, imag, norm_type=norm).numpy()
+        err = rel_err(got, want)
+        _record(f"b2_10s_{norm}", rel=err)
+        assert err < TOL, (norm, err)

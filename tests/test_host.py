@@ -1,0 +1,150 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/fsnp.h
+declares, the nn.Module mirrors the reference's plugin surface, and the LSTM weight packer agrees
+with an emulation of the v_mfma_f32_32x32x2_f32 fragment layouts the kernel relies on."""
+import copy
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fullsubnet_plus_amd import FullSubNet_Plus, Model, _lib
+from oracle.ref_loader import DEFAULT_MODEL_ARGS
+from oracle.weights import make_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "fsnp.h")).read()
+    declared = set(re.findall(r"\b(fsnp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fsnp_handle", "fsnp_config"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.fsnp_version()
+
+
+def test_create_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    cfg = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)._config()
+    hp = ctypes.c_void_p()
+    rc = lib.fsnp_create(ctypes.byref(cfg), ctypes.byref(hp))
+    assert rc != 0 and not hp.value
+    assert b"no CPU fallback" in lib.fsnp_last_error() or b"HIP" in lib.fsnp_last_error()
+
+
+def test_module_has_reference_parameter_tree_and_strict_load():
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    sd = make_state_dict(0)
+    assert set(m.state_dict()) == set(sd)
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 8_675_102
+    assert Model is FullSubNet_Plus
+    for attr in ("num_groups_in_drop_band", "look_ahead", "sb_num_neighbors", "fb_num_neighbors", "output_size",
+                 "subband_num"):
+        assert hasattr(m, attr)
+    m2 = copy.deepcopy(m)
+    assert m2._hip is not m._hip
+
+
+def test_error_behaviour_matches_reference():
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    x = torch.zeros(1, 1, 257, 12)
+    with pytest.raises(AssertionError):
+        m(x[0], x[0], x[0])                       # fullsubnet_plus.py:136
+    with pytest.raises(AssertionError):
+        m(x.expand(1, 2, 257, 12), x, x)          # fullsubnet_plus.py:141
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, x, x)
+    with pytest.raises(NotImplementedError):      # base_model.py:328
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": "forgetting_norm"})
+    with pytest.raises(AssertionError):           # fullsubnet_plus.py:45
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "RNN"})
+    with pytest.raises(NotImplementedError):
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": "SE"})
+
+
+def test_weight_init_true_reinitialises():
+    torch.manual_seed(0)
+    m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "weight_init": True})
+    w = m.sb_model.sequence_model.weight_hh_l0
+    # orthogonal init (base_model.py:380-385): columns orthonormal
+    g = (w.T @ w).detach()
+    assert torch.allclose(g, torch.eye(384), atol=1e-4)
+
+
+def _emulate_mfma_gates(pack, A_lds, H, KX, layer, kgroups):
+    """Replays lstm.hip's inner loop in numpy: for every wave/tile/lane, accumulate
+    D[row][col] += A[row][k] * B[k][col] with the documented 32x32x2 f32 fragment maps
+    (A: lane l -> A[l&31][l>>5], B: lane l -> B[l>>5][l&31], C: col=l&31,
+    row=(r&3)+8*(r>>2)+4*(l>>5)).  Returns gates [32 rows][4H] in reference row order."""
+    UW, ST = H // 4, H // 4 // 32
+    NT = 4 * ST
+    KGX, KGH = KX // 8, H // 8
+    KG0, KGT = KGX + KGH, KGX + 3 * KGH
+    packv = pack.reshape(4, KGT, NT, 64, 4)
+    gates = np.zeros((32, 4 * H), dtype=np.float64)
+    g0 = 0 if layer == 0 else KG0
+    lanes = np.arange(64)
+    for wave in range(4):
+        for n in range(NT):
+            D = np.zeros((32, 32))
+            for gi in range(kgroups):
+                a4 = A_lds[gi]                      # [64 lanes][4]  (what ds_read_b128 returns per lane)
+                b4 = packv[wave, g0 + gi, n]        # [64 lanes][4]
+                for p in range(4):
+                    for kh in range(2):
+                        sel = lanes[lanes >> 5 == kh]
+                        arow = a4[sel, p]           # A[row = l&31][k]
+                        bcol = b4[sel, p]           # B[k][col = l&31]
+                        D += np.outer(arow, bcol)
+            gate, s = n // ST, n % ST
+            cols = gate * H + wave * UW + s * 32 + np.arange(32)
+            gates[:, cols] = D
+    return gates
+
+
+def test_lstm_pack_matches_mfma_fragment_emulation():
+    lib = _lib.load()
+    H, NIN, KX = 384, 34, 40
+    rng = np.random.default_rng(0)
+    wih0 = rng.standard_normal((4 * H, NIN)).astype(np.float32)
+    whh0 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    wih1 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    whh1 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    n = 4 * (KX // 8 + 3 * H // 8) * (H // 32) * 64 * 4
+    pack = np.zeros(n, dtype=np.float32)
+    rc = lib.fsnp_debug_lstm_pack(H, NIN, KX, wih0.ctypes.data, whh0.ctypes.data, wih1.ctypes.data,
+                                  whh1.ctypes.data, pack.ctypes.data, n)
+    assert rc == 0, lib.fsnp_last_error()
+
+    def a_frag(mat):  # mat [32 rows][K] -> LDS image [K/8][64 lanes][4] per lstm.hip:a_frag_index
+        K = mat.shape[1]
+        img = np.zeros((K // 8) * 64 * 4)
+        for row in range(32):
+            for k in range(K):
+                img[(((k >> 3) * 64) + ((k & 1) * 32) + row) * 4 + ((k >> 1) & 3)] = mat[row, k]
+        return img.reshape(K // 8, 64, 4)
+
+    x = rng.standard_normal((32, NIN))
+    h0 = rng.standard_normal((32, H))
+    h1 = rng.standard_normal((32, H))
+    xp = np.zeros((32, KX)); xp[:, :NIN] = x
+    # layer 0: K order [x | h0]
+    A0 = np.concatenate([a_frag(xp), a_frag(h0)], axis=0)
+    got0 = _emulate_mfma_gates(pack, A0, H, KX, 0, KX // 8 + H // 8)
+    want0 = x @ wih0.T.astype(np.float64) + h0 @ whh0.T.astype(np.float64)
+    assert np.abs(got0 - want0).max() < 1e-9
+    # layer 1: K order [h1 | h0]
+    A1 = np.concatenate([a_frag(h1), a_frag(h0)], axis=0)
+    got1 = _emulate_mfma_gates(pack, A1, H, KX, 1, 2 * (H // 8))
+    want1 = h1 @ whh1.T.astype(np.float64) + h0 @ wih1.T.astype(np.float64)
+    assert np.abs(got1 - want1).max() < 1e-9
