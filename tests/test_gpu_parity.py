@@ -34,6 +34,9 @@ def _record(name, **kw):
         json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
+torch.set_num_threads(min(16, os.cpu_count() or 1))   # the CPU oracle collapses when oversubscribed
+
+
 def _model(args, sd, mode="parity"):
     m = FullSubNet_Plus(**args)
     m.load_state_dict(sd, strict=True)
@@ -140,7 +143,7 @@ def b32():
 
 def test_b32_full_vs_oracle(b32):
     sd, (mag, real, imag), m, full = b32
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     want = fsnp_torch.forward_full(sd, mag[:8], real[:8], imag[:8]).numpy()   # 8 utterances keep the CPU leg short
     err = rel_err(full[:8].numpy(), want)
     _record("b32_2s_full_vs_oracle_first8", rel=err)
