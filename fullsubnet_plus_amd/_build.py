@@ -26,10 +26,12 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> libfsnp_hip.so"""
+    """hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -shared -fPIC csrc/*.hip -> libfsnp_hip.so
+    (-fno-slp-vectorize: the SLP pass pairs the LSTM kernel's per-tile VALU FMAs across tiles, which breaks
+    the refill-in-place weight pipeline and makes hipcc drain vmcnt(0) + copy 48 registers every k-group)."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

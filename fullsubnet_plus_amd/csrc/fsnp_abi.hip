@@ -64,6 +64,7 @@ struct fsnp_handle {
     Dims last_dims{};
     bool have_last = false;
     bool debug = false;
+    int num_cus = 256;
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;
@@ -128,16 +129,21 @@ static void build_specs(fsnp_handle* h) {
     add("sb_model.fc_output_layer.bias", h->cfg.output_size);
 }
 
-// rows of the sub-band problem: (utterance, frequency) -> output offset
-__global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_rows_pad, int B, int F, int T, int mode,
+// Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
+// base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
+__global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
                                   int batch_offset, int global_batch, int dense_out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= num_rows_pad) return;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= num_tiles * rt) return;
+    const int tile = slot / rt, sl = slot % rt;
+    const int base = num_rows / num_tiles, rem = num_rows % num_tiles;
+    const int cnt = base + (tile < rem ? 1 : 0);
+    const int n = tile * base + (tile < rem ? tile : rem) + sl;
     RowDesc r{0, 0, 0, 0};
-    if (n < num_rows) {
+    if (sl < cnt) {
         r.valid = 1;
-        if (dense_out) {               // fsnp_lstm2_fc: out[n][o][t]
-            r.b = 0; r.f = 0; r.out_off = n * 2 * T;
+        if (dense_out) {               // fsnp_lstm2_fc: x[n][t][:] -> out[n][o][t]
+            r.b = n; r.f = 0; r.out_off = n * 2 * T;
         } else if (mode == FSNP_MODE_FULL) {
             r.b = n / F; r.f = n % F;
             r.out_off = ((r.b * 2) * F + r.f) * T;
@@ -152,7 +158,7 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_rows_pad,
             r.out_off = ((orow * 2) * Fh + i) * T;
         }
     }
-    rows[n] = r;
+    rows[slot] = r;
 }
 
 static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
@@ -173,7 +179,8 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gate = take((size_t)3 * B * h->FP * 4);
     w.md = take((size_t)3 * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
-    const size_t nrows_pad = align_up((size_t)B * rows_per_utt(h, mode), 32);
+    const LstmPlan lp = plan_lstm_tiles(B * rows_per_utt(h, mode), h->num_cus);
+    const size_t nrows_pad = (size_t)lp.num_tiles * lp.rows_per_slot_tile;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
     w.rows = take(nrows_pad * sizeof(RowDesc));
@@ -242,6 +249,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     fsnp_handle* h = new fsnp_handle();
     h->cfg = *cfg;
     h->device = dev;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->F = cfg->num_freqs;
     h->FP = (int)align_up(cfg->num_freqs, 4);
     h->CH = cfg->tcn_hidden;
@@ -434,10 +442,11 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     FSNP_HIP_CHECK(hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, s));
 
     const int num_rows = batch * rows_per_utt(h, mode);
-    const int num_rows_pad = (int)align_up(num_rows, 32);
+    const LstmPlan lp = plan_lstm_tiles(num_rows, h->num_cus);
+    const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
-    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_rows_pad, 256)), dim3(256), 0, s, rows, num_rows, num_rows_pad,
-                       batch, h->F, frames, mode, batch_offset, global_batch, 0);
+    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_rows, lp.num_tiles,
+                       lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
 
     FrontendBuffers fbuf;
     fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
@@ -458,7 +467,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
     sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
     sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
-    launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_rows, s);
+    launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[1], s));
 
     LstmArgs a{};
@@ -468,7 +477,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     a.rows = rows; a.md_utt = sbuf.md_utt; a.md_row = sbuf.md_row; a.dense = nullptr;
     a.out = out;
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
-    a.num_rows = num_rows; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
+    a.num_rows = num_rows; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.act = h->cfg.sb_act;
     launch_lstm(h->lw, a, s);
     if (h->timing) {
@@ -486,14 +495,17 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     if (num_seq <= 0 || steps <= 0) { set_error("fsnp_lstm2_fc: empty input"); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_HIP_CHECK(hipSetDevice(h->device));
-    const int pad = (int)align_up(num_seq, 32);
-    if (ensure_workspace(h, (size_t)pad * sizeof(RowDesc))) return 4;
+    if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
+    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
+    const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
+    if (ensure_workspace(h, (size_t)num_slots * sizeof(RowDesc))) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
-    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(pad, 256)), dim3(256), 0, s, rows, num_seq, pad, 1, 1, steps, 0, 0, 1, 1);
+    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_seq, lp.num_tiles,
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
-    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
+    a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
     launch_lstm(h->lw, a, s);
     FSNP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -547,6 +559,12 @@ int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t rese
     h->timing_recs.clear();
     for (int i = 0; i < 3; ++i) { ms[i] = h->acc_ms[i]; count[i] = h->acc_cnt[i]; }
     if (reset) for (int i = 0; i < 3; ++i) { h->acc_ms[i] = 0; h->acc_cnt[i] = 0; }
+    return 0;
+}
+
+int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus) {
+    if (!h || num_cus <= 0) { set_error("fsnp_debug_set_num_cus: bad argument"); return 1; }
+    h->num_cus = num_cus;
     return 0;
 }
 

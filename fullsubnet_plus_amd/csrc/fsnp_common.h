@@ -97,10 +97,11 @@ struct SubbandBuffers {
     NormMD* md_utt;        // [B]
     NormMD* md_row;        // [Nrows][Tp] (cumulative norms only)
 };
-struct RowDesc { int b, f, out_off, valid; };  // one sub-band sequence
+// one sub-band sequence slot.  b = utterance (gather mode) or sequence index (dense mode)
+struct RowDesc { int b, f, out_off, valid; };
 
 void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
-                          int num_rows, hipStream_t s);
+                          int num_slots, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile
@@ -125,10 +126,14 @@ struct LstmArgs {
     float* out;            // out[row.out_off + o*out_stride_o + (t-LA)]
     long out_stride_o;
     int num_rows;          // valid rows
+    int num_tiles;         // workgroups; rows[] holds num_tiles * (32 + ex) slots
+    int ex;                // VALU rows per tile: 0, 1, 2 or 4
     int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
     int act;               // FSNP_ACT_* on the Linear output
 };
 
+struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
+LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_pack_floats(int H, int KX);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack

@@ -23,6 +23,12 @@
 //                 k-group (12 x 1 KiB loads) ahead, continuously across phase boundaries.
 //   * A operand : x_t, h0, h1 live in LDS in A-fragment order ([k-group][k parity][row][4 k-pairs]) so
 //                 one ds_read_b128 per k-group feeds 48 MFMAs.
+//   * extra rows: a tile may carry up to EX more sequences (rows 32..32+EX-1).  Their gate pre-activations
+//                 are plain v_fma_f32 on the VALU pipe, issued between the MFMAs and reusing the very same
+//                 B registers (lane = (k parity, column), two half-wave partial sums combined once per
+//                 layer).  The VALU is otherwise idle while the matrix pipe is busy, so the extra rows
+//                 are almost free; they exist to kill the tail: B=32 gives 8224 = 257 x 32 sequences,
+//                 i.e. one tile more than the chip has CUs - 33-row tiles finish in ONE round instead of two.
 // fp32 throughout: v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain.
 #include "fsnp_common.h"
 
@@ -45,22 +51,44 @@ __host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
     return (((k >> 3) * 64) + ((k & 1) * 32) + row) * 4 + ((k >> 1) & 3);
 }
 
+// float index of extra-row element (e, k) inside an E-image ([k-group][k parity][EX][4 k-pairs])
+template <int EX>
+__host__ __device__ __forceinline__ int e_frag_index(int e, int k) {
+    return ((((k >> 3) * 2) + (k & 1)) * EX + e) * 4 + ((k >> 1) & 3);
+}
+
 // Consume `ngroups` k-groups: A from LDS (A already offset by lane), B from the rotating register
 // buffer `b` (always holding the group about to be used); refills b from the weight stream.
-template <int NT>
-__device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float4 (&b)[NT], const float4* __restrict__ A,
-                                            int ngroups, const float4* __restrict__ wlane, int& gnext,
-                                            int groups_total) {
+// AE (offset by (lane>>5)*EX) is the E-image of the extra rows; accx their per-lane partial sums.
+template <int NT, int EX>
+__device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
+                                            const float4* __restrict__ A, const float4* __restrict__ AE, int ngroups,
+                                            const float4* __restrict__ wlane, int& gnext, int groups_total) {
     float4 a = A[0];
+    float4 ae[EX > 0 ? EX : 1];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) ae[e] = AE[e];
     for (int g = 0; g < ngroups; ++g) {
-        const float4 an = A[(g + 1 < ngroups ? g + 1 : g) * 64];
+        const int gn = (g + 1 < ngroups ? g + 1 : g);
+        const float4 an = A[gn * 64];
+        float4 aen[EX > 0 ? EX : 1];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) aen[e] = AE[gn * 2 * EX + e];
         const float4* __restrict__ wn = wlane + (size_t)gnext * (NT * 64);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].x, b[n].x, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].y, b[n].y, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].z, b[n].z, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].w, b[n].w, accx[e][n]);
             // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
             // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
             // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
@@ -69,6 +97,8 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float4 (&b)[NT], 
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
         a = an;
+#pragma unroll
+        for (int e = 0; e < EX; ++e) ae[e] = aen[e];
     }
 }
 
@@ -93,77 +123,120 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST]
     }
 }
 
-template <int HID, int KX, int OUT>
+// Extra rows: combine the two half-wave partial sums, add the bias, update c, write h into the E-image.
+template <int ST, int UW, int EX, int NT>
+__device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][NT], float (&cx)[EX > 0 ? EX : 1][ST],
+                                                const float* __restrict__ bias, float* __restrict__ He, int wave,
+                                                int lane) {
+#pragma unroll
+    for (int e = 0; e < EX; ++e)
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            float g4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = accx[e][q * ST + s];
+                g4[q] = v + __shfl_xor(v, 32) + bias[(q * ST + s) * 32];
+            }
+            const float cn = fast_sigmoid(g4[1]) * cx[e][s] + fast_sigmoid(g4[0]) * fast_tanh(g4[2]);
+            cx[e][s] = cn;
+            const float h = fast_sigmoid(g4[3]) * fast_tanh(cn);
+            if (lane < 32) He[e_frag_index<EX>(e, wave * UW + s * 32 + lane)] = h;
+        }
+}
+
+template <int HID, int KX, int OUT, int EX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
+    static_assert(EX >= 0 && EX <= 4, "at most 4 VALU rows per tile (one FC wave per extra row)");
     constexpr int UW = HID / 4, ST = UW / 32, NT = 4 * ST;
     static_assert(UW % 32 == 0, "hidden/4 must be a multiple of 32");
     constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH, KG1 = 2 * KGH, KGT = KG0 + KG1;
     static_assert(KGH % 4 == 0, "FC k-split");
+    constexpr int RT = 32 + EX;                 // row slots per tile
+    constexpr int EXA = EX > 0 ? EX : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4* Xs = reinterpret_cast<float4*>(smem_raw);   // [KGX][64]
-    float4* H0s = Xs + KGX * 64;                         // [KGH][64]
-    float4* H1s = H0s + KGH * 64;                        // [KGH][64]
-    float4* Wfc4 = H1s + KGH * 64;                       // [OUT][KGH][2]
-    RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [32]
-    float* Bs = reinterpret_cast<float*>(rows_s + 32);                   // [2][4][NT][32]
+    float4* Xs = reinterpret_cast<float4*>(smem_raw);   // [KGX][64]           A image of x_t (rows 0..31)
+    float4* H0s = Xs + KGX * 64;                         // [KGH][64]           h0
+    float4* H1s = H0s + KGH * 64;                        // [KGH][64]           h1
+    float4* XEs = H1s + KGH * 64;                        // [KGX][2][EX]        E image of x_t (extra rows)
+    float4* HE0s = XEs + KGX * 2 * EX;                   // [KGH][2][EX]
+    float4* HE1s = HE0s + KGH * 2 * EX;                  // [KGH][2][EX]
+    float4* Wfc4 = HE1s + KGH * 2 * EX;                  // [OUT][KGH][2]
+    RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [RT]
+    float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [2][4][NT][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * 32;
+    const int slot0 = blockIdx.x * RT;
     const int Tp = a.Tp;
 
-    for (int i = tid; i < (KGX + 2 * KGH) * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (KGX + 2 * KGH) * (64 + 2 * EX); i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < OUT * KGH * 2; i += 256) {
         const int o = i / (KGH * 2), kg = (i >> 1) % KGH, kh = i & 1;
         const float* wr = w.wfc + (size_t)o * HID + kg * 8 + kh;
         Wfc4[i] = make_float4(wr[0], wr[2], wr[4], wr[6]);
     }
-    if (tid < 32) rows_s[tid] = a.rows[row0 + tid];
+    if (tid < RT) rows_s[tid] = a.rows[slot0 + tid];
     for (int i = tid; i < 2 * 4 * NT * 32; i += 256) {
         const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) & 3, layer = i / (32 * NT * 4);
         Bs[i] = w.bias[layer * 4 * HID + (n / ST) * HID + wv * UW + (n % ST) * 32 + col];
     }
     __syncthreads();
 
-    // ---- per-thread gather plan: row = tid & 31, features j = (tid >> 5) + 8 i ------------------
-    // 32-bit float offsets from one wave-uniform base (att_mag, or this tile's dense rows); -1 = zero.
-    const int grow = tid & 31;
-    const RowDesc rd = rows_s[grow];
+    // ---- gather plan.  main rows: row = tid & 31, features j = (tid >> 5) + 8 i.
+    //      extra rows: thread tid < EX*KX owns (e = tid / KX, j = tid % KX).
+    // 32-bit float offsets from one uniform base (att_mag, or the dense input); -1 = zero.
     const bool dense = a.dense != nullptr;
-    const float* __restrict__ gbase = dense ? a.dense + (size_t)row0 * Tp * w.NIN : a.att_mag;
+    const float* __restrict__ gbase = dense ? a.dense : a.att_mag;
     const int gstep = dense ? w.NIN : a.FP;
+    auto plan = [&](const RowDesc& rd, int j) -> int {
+        if (!rd.valid || j >= w.NIN) return -1;
+        if (dense) return rd.b * Tp * w.NIN + j;           // rd.b = sequence index in dense mode
+        const int base = rd.b * Tp * a.FP;
+        const int nsb = 2 * a.NSBN + 1;
+        return (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
+                         : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
+    };
+    auto row_md = [&](const RowDesc& rd, int slot, NormMD& md, const NormMD*& md_row) {
+        md.m = 0.0f; md.d = 1.0f; md_row = nullptr;
+        if (dense || !rd.valid) return;
+        if (a.md_row != nullptr) md_row = a.md_row + (size_t)slot * Tp;
+        else md = a.md_utt[rd.b];
+    };
+    const int grow = tid & 31;
     int goff[KGX];
+    NormMD md; const NormMD* md_row;
+    {
+        const RowDesc rd = rows_s[grow];
 #pragma unroll
-    for (int i = 0; i < KGX; ++i) {
-        const int j = (tid >> 5) + 8 * i;
-        int off = -1;
-        if (rd.valid && j < w.NIN) {
-            if (dense) {
-                off = grow * Tp * w.NIN + j;
-            } else {
-                const int base = rd.b * Tp * a.FP;
-                const int nsb = 2 * a.NSBN + 1;
-                off = (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
-                                : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
-            }
-        }
-        goff[i] = off;
+        for (int i = 0; i < KGX; ++i) goff[i] = plan(rd, (tid >> 5) + 8 * i);
+        row_md(rd, slot0 + grow, md, md_row);
     }
     const int xdst0 = a_frag_index(grow, tid >> 5);   // feature j = (tid>>5) + 8 i  ->  + i * 256 floats
-    NormMD md = {0.0f, 1.0f};
-    if (!dense && rd.valid && a.md_row == nullptr) md = a.md_utt[rd.b];
-    const NormMD* md_row = (!dense && rd.valid && a.md_row != nullptr) ? a.md_row + (size_t)(row0 + grow) * Tp : nullptr;
+    int goffx = -1, xdstx = 0;
+    NormMD mdx = {0.0f, 1.0f}; const NormMD* mdx_row = nullptr;
+    if (EX > 0 && tid < EX * KX) {
+        const int e = tid / KX, j = tid % KX;
+        const RowDesc rd = rows_s[32 + e];
+        goffx = plan(rd, j);
+        xdstx = e_frag_index<EXA>(e, j);
+        row_md(rd, slot0 + 32 + e, mdx, mdx_row);
+    }
 
     float* Xf = reinterpret_cast<float*>(Xs);
+    float* XEf = reinterpret_cast<float*>(XEs);
     {   // x(0)
-        NormMD m0 = md;
-        if (md_row) m0 = md_row[0];
+        const NormMD m0 = md_row ? md_row[0] : md;
 #pragma unroll
         for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
+        if (EX > 0 && tid < EX * KX) {
+            const NormMD mx = mdx_row ? mdx_row[0] : mdx;
+            XEf[xdstx] = goffx >= 0 ? (gbase[goffx] - mx.m) / mx.d : 0.0f;
+        }
     }
 
     // ---- register state -----------------------------------------------------------------------------
@@ -171,10 +244,14 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     const float* __restrict__ bias_l0 = Bs + ((0 * 4 + wave) * NT) * 32 + (lane & 31);
     const float* __restrict__ bias_l1 = Bs + ((1 * 4 + wave) * NT) * 32 + (lane & 31);
     f32x16 c0[ST], c1[ST];
+    float cx0[EXA][ST], cx1[EXA][ST];
 #pragma unroll
-    for (int s = 0; s < ST; ++s)
+    for (int s = 0; s < ST; ++s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0[s][r] = 0.0f; c1[s][r] = 0.0f; }
+#pragma unroll
+        for (int e = 0; e < EXA; ++e) { cx0[e][s] = 0.0f; cx1[e][s] = 0.0f; }
+    }
 
     const float4* __restrict__ wlane = reinterpret_cast<const float4*>(w.wpack) + (size_t)wave * KGT * NT * 64 + lane;
     float4 breg[NT];
@@ -182,12 +259,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     for (int n = 0; n < NT; ++n) breg[n] = wlane[n * 64];   // group 0
     int gnext = 1;
 
-    // FC lane mapping: 8 rows x 2 outputs x 4 k-parts per wave
+    // FC lane mapping (rows 0..31): 8 rows x 2 outputs x 4 k-parts per wave
     const int fc_row = wave * 8 + (lane & 7);
     const int fc_o = (lane >> 3) & 1;
     const int fc_kp = lane >> 4;
-    const float fc_bias = w.bfc[fc_o];
     const RowDesc fc_rd = rows_s[fc_row];
+    // FC lane mapping (extra row e = wave): output = lane >> 5, k = (lane & 31) + 32 i
+    const RowDesc fcx_rd = (EX > 0 && wave < EX) ? rows_s[32 + (wave < EX ? wave : 0)] : RowDesc{0, 0, 0, 0};
 
     auto fc_store = [&](int t_of_h) {
         constexpr int KGP = KGH / 4;
@@ -205,46 +283,78 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         if (fc_kp == 0 && fc_rd.valid && t_of_h >= a.LA)
-            a.out[(size_t)fc_rd.out_off + (size_t)fc_o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sum + fc_bias, a.act);
+            a.out[(size_t)fc_rd.out_off + (size_t)fc_o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sum + w.bfc[fc_o], a.act);
+        if (EX > 0 && wave < EX) {
+            const int o = lane >> 5;
+            const float* he = reinterpret_cast<const float*>(HE1s);
+            float sx = 0.0f;
+#pragma unroll 4
+            for (int i = 0; i < HID / 32; ++i) {
+                const int k = (lane & 31) + 32 * i;
+                sx += he[e_frag_index<EXA>(wave, k)] * w.wfc[o * HID + k];
+            }
+#pragma unroll
+            for (int m = 16; m > 0; m >>= 1) sx += __shfl_xor(sx, m);
+            if ((lane & 31) == 0 && fcx_rd.valid && t_of_h >= a.LA)
+                a.out[(size_t)fcx_rd.out_off + (size_t)o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sx + w.bfc[o], a.act);
+        }
     };
+
+    const float4* AEx = XEs + (lane >> 5) * EX;      // E images, offset by this lane's k parity
+    const float4* AEh0 = HE0s + (lane >> 5) * EX;
+    const float4* AEh1 = HE1s + (lane >> 5) * EX;
 
     __syncthreads();
 
     for (int t = 0; t < Tp; ++t) {
         // prefetch x(t+1) (consumed after the layer-0 MFMA phase)
-        float xr[KGX];
-        NormMD mdn = md;
+        float xr[KGX], xrx = 0.0f;
+        NormMD mdn = md, mdxn = mdx;
         const bool have_next = (t + 1 < Tp);
         if (have_next) {
             if (md_row) mdn = md_row[t + 1];
 #pragma unroll
             for (int i = 0; i < KGX; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
+            if (EX > 0 && tid < EX * KX) {
+                if (mdx_row) mdxn = mdx_row[t + 1];
+                xrx = goffx >= 0 ? gbase[goffx + (t + 1) * gstep] : 0.0f;
+            }
         }
 
         f32x16 acc[NT];
+        float accx[EXA][NT];
         // ---------------- layer 0: [x_t | h0_{t-1}] ----------------
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = bias_l0[n * 32];
-        mfma_groups<NT>(acc, breg, Xs + lane, KG0, wlane, gnext, KGT);
+#pragma unroll
+            for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
+        }
+        mfma_groups<NT, EX>(acc, accx, breg, Xs + lane, AEx, KG0, wlane, gnext, KGT);
         __syncthreads();
         lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
+        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
+            if (EX > 0 && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
         }
         if (t > 0) fc_store(t - 1);
         __syncthreads();
         // ---------------- layer 1: [h1_{t-1} | h0_t] ----------------
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = bias_l1[n * 32];
-        mfma_groups<NT>(acc, breg, H1s + lane, KGH, wlane, gnext, KGT);
-        mfma_groups<NT>(acc, breg, H0s + lane, KGH, wlane, gnext, KGT);
+#pragma unroll
+            for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
+        }
+        mfma_groups<NT, EX>(acc, accx, breg, H1s + lane, AEh1, KGH, wlane, gnext, KGT);
+        mfma_groups<NT, EX>(acc, accx, breg, H0s + lane, AEh0, KGH, wlane, gnext, KGT);
         __syncthreads();
         lstm_cell<ST, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
+        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx1, bias_l1, reinterpret_cast<float*>(HE1s), wave, lane);
     }
     __syncthreads();
     fc_store(Tp - 1);
@@ -282,20 +392,49 @@ void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* w
                     }
 }
 
-void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+template <int EX>
+static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40, OUT = 2;
-    constexpr int KGX = KX / 8, KGH = HID / 8;
-    const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * KGH * 2 * 16 + 32 * sizeof(RowDesc) +
-                        (size_t)2 * 4 * (4 * (HID / 4 / 32)) * 32 * 4;
+    constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / 4 / 32);
+    const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
+                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * 4 * NT * 32 * 4;
     static bool attr_set = false;
-    auto kern = lstm2_fc_kernel<HID, KX, OUT>;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    const int tiles = cdiv(a.num_rows, 32);
-    if (tiles <= 0) return;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, w, a);
+    hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+}
+
+void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (a.num_tiles <= 0) return;
+    switch (a.ex) {
+        case 0: launch_lstm_ex<0>(w, a, s); break;
+        case 1: launch_lstm_ex<1>(w, a, s); break;
+        case 2: launch_lstm_ex<2>(w, a, s); break;
+        default: launch_lstm_ex<4>(w, a, s); break;
+    }
+}
+
+// Tile plan: a tile = 32 MFMA rows + up to ex VALU rows.  All tiles cost the same time whatever their
+// row count, so the makespan is rounds = ceil(tiles / CUs); pick the smallest ex in {0,1,2,4} that
+// minimises rounds, then spread the rows evenly over rounds * CUs tiles.
+LstmPlan plan_lstm_tiles(int num_rows, int num_cus) {
+    LstmPlan p{};
+    if (num_rows <= 32 * num_cus) {
+        p.ex = 0; p.num_tiles = cdiv(num_rows, 32);
+    } else {
+        const int cand[4] = {0, 1, 2, 4};
+        int best_rounds = 1 << 30;
+        for (int i = 0; i < 4; ++i) {
+            const int rounds = cdiv(cdiv(num_rows, 32 + cand[i]), num_cus);
+            if (rounds < best_rounds) { best_rounds = rounds; p.ex = cand[i]; }
+        }
+        p.num_tiles = best_rounds * num_cus;
+    }
+    p.rows_per_slot_tile = 32 + p.ex;
+    return p;
 }
 
 }  // namespace fsnp

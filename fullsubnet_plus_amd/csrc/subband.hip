@@ -75,10 +75,10 @@ __global__ void sb_offline_final_kernel(const double* __restrict__ acc, NormMD* 
 __global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restrict__ att_mag,
                                                            const float* __restrict__ fb, long fb_bs,
                                                            const RowDesc* __restrict__ rows, NormMD* __restrict__ md_row,
-                                                           int num_rows, int Tp, int F, int FP, int nsbn, int nin,
+                                                           int num_slots, int Tp, int F, int FP, int nsbn, int nin,
                                                            int norm_type) {
     const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= num_rows) return;
+    if (row >= num_slots) return;
     const RowDesc rd = rows[row];
     if (!rd.valid) return;
     double cs = 0.0, cq = 0.0;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restri
 }
 
 void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
-                          int num_rows, hipStream_t s) {
+                          int num_slots, hipStream_t s) {
     const long fb_bs = (long)d.B * d.Tp * d.FP;
     if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
         hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, SB_ROWS), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
@@ -108,8 +108,8 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);
     } else {
-        hipLaunchKernelGGL(sb_cumulative_kernel, dim3(cdiv(num_rows, 64)), dim3(64), 0, s, buf.att_mag, buf.fb, fb_bs,
-                           rows, buf.md_row, num_rows, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, d.NIN, norm_type);
+        hipLaunchKernelGGL(sb_cumulative_kernel, dim3(cdiv(num_slots, 64)), dim3(64), 0, s, buf.att_mag, buf.fb, fb_bs,
+                           rows, buf.md_row, num_slots, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, d.NIN, norm_type);
     }
 }
 

@@ -307,6 +307,14 @@ class FullSubNet_Plus(nn.Module):
         _lib.check(lib.fsnp_read_stage(self._handle, name.encode(), host.data_ptr(), host.numel()), "fsnp_read_stage")
         return host if name.startswith("gate_") else host.view(batch, frames + self.look_ahead, self.num_freqs)
 
+    def debug_set_num_cus(self, num_cus, device="cuda"):
+        """Test hook: plan LSTM tiles as if the chip had `num_cus` CUs (exercises multi-round / VALU-row tiles)."""
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        lib = self._ensure_handle(dev)
+        _lib.check(lib.fsnp_debug_set_num_cus(self._handle, int(num_cus)), "fsnp_debug_set_num_cus")
+
     def set_timing(self, enable=True):
         _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")
 

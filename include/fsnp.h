@@ -126,6 +126,11 @@ int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t rese
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 
+/* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =
+ * 32 MFMA rows + up to 4 VALU rows; see csrc/lstm.hip plan_lstm_tiles), so that small inputs exercise
+ * the multi-round / extra-row tile shapes. */
+int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus);
+
 /* Test hook (host only, no GPU needed): run the LSTM weight packer that fsnp_commit_weights uses.
  * out receives 4 * (kx/8 + 3*hidden/8) * (hidden/32) * 64 * 4 floats in MFMA B-fragment order
  * [wave][k-group][tile][lane][k-pair] (layout documented in csrc/lstm.hip). */

@@ -73,6 +73,33 @@ def test_lstm2_fc_dense_vs_oracle(profile, n, steps):
     assert err < 2e-5, (err, per_step[:6], np.argsort(-per_row)[:8])
 
 
+@pytest.mark.parametrize("n,cus,steps", [(66, 2, 9), (67, 2, 9), (70, 2, 9), (200, 2, 5), (257, 8, 7)])
+def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
+    """Tiles with 1/2/4 extra VALU rows and several rounds (planner driven by a fake CU count)."""
+    sd = make_state_dict(5, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    m.debug_set_num_cus(cus)
+    rng = np.random.Generator(np.random.PCG64(99 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    per_row = np.abs(got - want).max(axis=(1, 2)) / np.abs(want).max()
+    _record(f"lstm_valu_rows_{n}_cus{cus}", rel=float(per_row.max()), worst_rows=np.argsort(-per_row)[:6].tolist())
+    assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
+
+
+@pytest.mark.parametrize("name", ["b1_t24_harsh_stages", "b1_t30_cum_layer", "b5_t16_default"])
+def test_forward_with_valu_rows(name):
+    """Whole forward with 33-row tiles (257 rows on a pretend 8-CU chip == B=32 on 256 CUs in miniature)."""
+    g = Golden(name)
+    m = _model(g.args, g.state_dict(), "parity")
+    m.debug_set_num_cus(8 if g.meta["inp"]["B"] == 1 else 16)
+    out = m(*_cuda(g.inputs())).cpu().numpy()
+    err = rel_err(out, g.arrays["out"])
+    _record(f"forward_valu_rows_{name}", rel_vs_ref32=err)
+    assert err < TOL, err
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names() if "stages" in n or "t30" in n])
 def test_stages_vs_reference(name):
     """Intermediate buffers (TSSE output, full-band outputs) vs forward-hook captures of the reference."""
