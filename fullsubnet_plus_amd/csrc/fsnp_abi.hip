@@ -562,6 +562,31 @@ int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t rese
     return 0;
 }
 
+int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
+                            uint64_t* host_stamps, int64_t num_stamps) {
+    if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_lstm_profile: null argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
+    if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
+    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
+    const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
+    const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
+    if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8)) return 4;
+    RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
+    unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
+    h->have_last = false;
+    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, 0, rows, num_seq, lp.num_tiles,
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
+    LstmArgs a{};
+    a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
+    a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.F = 1;
+    a.act = h->cfg.sb_act; a.prof = dprof;
+    launch_lstm(h->lw, a, 0);
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
+    FSNP_HIP_CHECK(hipMemcpy(host_stamps, dprof, (size_t)num_stamps * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus) {
     if (!h || num_cus <= 0) { set_error("fsnp_debug_set_num_cus: bad argument"); return 1; }
     h->num_cus = num_cus;

@@ -130,6 +130,7 @@ struct LstmArgs {
     int ex;                // VALU rows per tile: 0, 1, 2 or 4
     int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
     int act;               // FSNP_ACT_* on the Linear output
+    unsigned long long* prof;  // optional [Tp][8] s_memtime stamps of workgroup 0 (debug)
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };

@@ -78,17 +78,19 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].x, b[n].x, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].y, b[n].y, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].z, b[n].z, accx[e][n]);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+            // VALU rows: issued behind the tile's 4 back-to-back MFMAs (never between two MFMAs of one
+            // accumulator chain), they run on the idle VALU pipe while the matrix pipe drains.
 #pragma unroll
-            for (int e = 0; e < EX; ++e) accx[e][n] = fmaf(ae[e].w, b[n].w, accx[e][n]);
+            for (int e = 0; e < EX; ++e) {
+                float v = accx[e][n];
+                v = fmaf(ae[e].x, b[n].x, v);
+                v = fmaf(ae[e].y, b[n].y, v);
+                v = fmaf(ae[e].z, b[n].z, v);
+                accx[e][n] = fmaf(ae[e].w, b[n].w, v);
+            }
             // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
             // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
             // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
@@ -145,7 +147,7 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
         }
 }
 
-template <int HID, int KX, int OUT, int EX>
+template <int HID, int KX, int OUT, int EX, bool PROF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
@@ -306,7 +308,20 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 
     __syncthreads();
 
+    // optional phase profile (debug ABI): workgroup 0, thread 0 stamps s_memtime at 8 points per step
+    // (compile-time variant: the stamp branches would otherwise wreck the production kernel's register allocation)
+    // Branch-free: thread 0 of workgroup 0 stamps the real slots, every other thread a private dump slot.
+    unsigned long long* prof = nullptr;
+    int prof_stride = 0;
+    if constexpr (PROF) {
+        const bool rec = blockIdx.x == 0 && tid == 0;
+        prof = a.prof + (rec ? 0 : (size_t)Tp * 8 + (size_t)blockIdx.x * 256 + tid);
+        prof_stride = rec ? 8 : 0;
+    }
+#define FSNP_STAMP(i) do { if constexpr (PROF) prof[t * prof_stride + (prof_stride ? (i) : 0)] = __builtin_amdgcn_s_memtime(); } while (0)
+
     for (int t = 0; t < Tp; ++t) {
+        FSNP_STAMP(0);
         // prefetch x(t+1) (consumed after the layer-0 MFMA phase)
         float xr[KGX], xrx = 0.0f;
         NormMD mdn = md, mdxn = mdx;
@@ -332,7 +347,9 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
         mfma_groups<NT, EX>(acc, accx, breg, Xs + lane, AEx, KG0, wlane, gnext, KGT);
+        FSNP_STAMP(1);
         __syncthreads();
+        FSNP_STAMP(2);
         lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
         if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
         if (have_next) {
@@ -341,7 +358,9 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
             if (EX > 0 && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
         }
         if (t > 0) fc_store(t - 1);
+        FSNP_STAMP(3);
         __syncthreads();
+        FSNP_STAMP(4);
         // ---------------- layer 1: [h1_{t-1} | h0_t] ----------------
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -352,10 +371,14 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         }
         mfma_groups<NT, EX>(acc, accx, breg, H1s + lane, AEh1, KGH, wlane, gnext, KGT);
         mfma_groups<NT, EX>(acc, accx, breg, H0s + lane, AEh0, KGH, wlane, gnext, KGT);
+        FSNP_STAMP(5);
         __syncthreads();
+        FSNP_STAMP(6);
         lstm_cell<ST, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
         if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx1, bias_l1, reinterpret_cast<float*>(HE1s), wave, lane);
+        FSNP_STAMP(7);
     }
+#undef FSNP_STAMP
     __syncthreads();
     fc_store(Tp - 1);
 }
@@ -399,7 +422,13 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
                         (32 + EX) * sizeof(RowDesc) + (size_t)2 * 4 * NT * 32 * 4;
     static bool attr_set = false;
-    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX>;
+    if (a.prof != nullptr) {
+        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+        return;
+    }
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;

@@ -126,6 +126,12 @@ int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t rese
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 
+/* Profiling hook: fsnp_lstm2_fc on the default stream + s_memtime stamps of workgroup 0 at 8 points of
+ * every step (0 step start, 1 layer-0 MFMA done, 2 past barrier, 3 cell-0/x/FC done, 4 past barrier,
+ * 5 layer-1 MFMA done, 6 past barrier, 7 cell-1 done).  host_stamps receives steps*8 values. Synchronises. */
+int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
+                            uint64_t* host_stamps, int64_t num_stamps);
+
 /* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =
  * 32 MFMA rows + up to 4 VALU rows; see csrc/lstm.hip plan_lstm_tiles), so that small inputs exercise
  * the multi-round / extra-row tile shapes. */
