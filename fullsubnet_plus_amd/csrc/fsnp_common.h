@@ -106,7 +106,9 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 // ---------------------------------------------------------------------------------------------
 // lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile
 struct LstmWeights {
-    const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream]
+    const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
+    const float* wpack48; // same with the input block padded to KX = 48 (even group counts for prefetch_groups = 2)
+    int prefetch_groups; // 1 or 2 k-groups of weights in flight ahead of the MFMAs
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
     const float* bfc;    // [OUT]

@@ -82,7 +82,9 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
             // VALU rows: issued behind the tile's 4 back-to-back MFMAs (never between two MFMAs of one
-            // accumulator chain), they run on the idle VALU pipe while the matrix pipe drains.
+            // accumulator chain - hipcc's scheduler puts them there unless fenced, +7 % kernel time), they
+            // run on the idle VALU pipe while the matrix pipe drains.
+            if (EX > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < EX; ++e) {
                 float v = accx[e][n];
@@ -101,6 +103,59 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
         a = an;
 #pragma unroll
         for (int e = 0; e < EX; ++e) ae[e] = aen[e];
+    }
+}
+
+// One k-group: 12 tiles x (4 MFMAs, VALU rows, refill of the consumed registers with group `gload`).
+template <int NT, int EX>
+__device__ __forceinline__ void mfma_one_group(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
+                                               const float4 a, const float4 (&ae)[EX > 0 ? EX : 1],
+                                               const float4* __restrict__ wn) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+        if (EX > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) {
+            float v = accx[e][n];
+            v = fmaf(ae[e].x, b[n].x, v);
+            v = fmaf(ae[e].y, b[n].y, v);
+            v = fmaf(ae[e].z, b[n].z, v);
+            accx[e][n] = fmaf(ae[e].w, b[n].w, v);
+        }
+        b[n] = wn[n * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Two-groups-ahead variant: b0 holds the group about to be used, b1 the one after it; each is refilled in
+// place with the group two ahead.  ngroups must be even (KX is padded to 48 so that every segment is).
+template <int NT, int EX>
+__device__ __forceinline__ void mfma_groups_pf2(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b0)[NT],
+                                                float4 (&b1)[NT], const float4* __restrict__ A,
+                                                const float4* __restrict__ AE, int ngroups,
+                                                const float4* __restrict__ wlane, int& gnext, int groups_total) {
+    constexpr int EXA = EX > 0 ? EX : 1;
+    float4 a = A[0];
+    float4 ae[EXA];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) ae[e] = AE[e];
+    for (int g = 0; g < ngroups; g += 2) {
+        float4 an = A[(g + 1) * 64];
+        float4 aen[EXA];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) aen[e] = AE[(g + 1) * 2 * EX + e];
+        mfma_one_group<NT, EX>(acc, accx, b0, a, ae, wlane + (size_t)gnext * (NT * 64));
+        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
+        const int g2 = (g + 2 < ngroups ? g + 2 : g + 1);
+        a = A[g2 * 64];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) ae[e] = AE[g2 * 2 * EX + e];
+        mfma_one_group<NT, EX>(acc, accx, b1, an, aen, wlane + (size_t)gnext * (NT * 64));
+        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
     }
 }
 
@@ -147,7 +202,7 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
         }
 }
 
-template <int HID, int KX, int OUT, int EX, bool PROF>
+template <int HID, int KX, int OUT, int EX, bool PROF, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
@@ -256,10 +311,20 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     }
 
     const float4* __restrict__ wlane = reinterpret_cast<const float4*>(w.wpack) + (size_t)wave * KGT * NT * 64 + lane;
-    float4 breg[NT];
+    float4 breg[NT], breg1[PF == 2 ? NT : 1];
 #pragma unroll
     for (int n = 0; n < NT; ++n) breg[n] = wlane[n * 64];   // group 0
     int gnext = 1;
+    if constexpr (PF == 2) {
+        static_assert(PF != 2 || (KG0 % 2 == 0 && KGH % 2 == 0), "pf2 needs even group counts");
+#pragma unroll
+        for (int n = 0; n < NT; ++n) breg1[n] = wlane[(NT + n) * 64];   // group 1
+        gnext = 2;
+    }
+    auto run_groups = [&](f32x16 (&acc_)[NT], float (&accx_)[EXA][NT], const float4* A_, const float4* AE_, int ng) {
+        if constexpr (PF == 2) mfma_groups_pf2<NT, EX>(acc_, accx_, breg, breg1, A_, AE_, ng, wlane, gnext, KGT);
+        else mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, wlane, gnext, KGT);
+    };
 
     // FC lane mapping (rows 0..31): 8 rows x 2 outputs x 4 k-parts per wave
     const int fc_row = wave * 8 + (lane & 7);
@@ -346,7 +411,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
-        mfma_groups<NT, EX>(acc, accx, breg, Xs + lane, AEx, KG0, wlane, gnext, KGT);
+        run_groups(acc, accx, Xs + lane, AEx, KG0);
         FSNP_STAMP(1);
         __syncthreads();
         FSNP_STAMP(2);
@@ -369,8 +434,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
-        mfma_groups<NT, EX>(acc, accx, breg, H1s + lane, AEh1, KGH, wlane, gnext, KGT);
-        mfma_groups<NT, EX>(acc, accx, breg, H0s + lane, AEh0, KGH, wlane, gnext, KGT);
+        run_groups(acc, accx, H1s + lane, AEh1, KGH);
+        run_groups(acc, accx, H0s + lane, AEh0, KGH);
         FSNP_STAMP(5);
         __syncthreads();
         FSNP_STAMP(6);
@@ -415,35 +480,44 @@ void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* w
                     }
 }
 
-template <int EX>
+template <int EX, int PF>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, KX = 40, OUT = 2;
+    constexpr int HID = 384, KX = PF == 2 ? 48 : 40, OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / 4 / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
                         (32 + EX) * sizeof(RowDesc) + (size_t)2 * 4 * NT * 32 * 4;
-    static bool attr_set = false;
+    LstmWeights wv = w;
+    wv.KX = KX;
+    wv.wpack = PF == 2 ? w.wpack48 : w.wpack;
     if (a.prof != nullptr) {
-        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true>;
+        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, PF>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
         return;
     }
-    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false>;
+    static bool attr_set = false;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, PF>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+    hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
+}
+
+template <int PF>
+static void launch_lstm_pf(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    switch (a.ex) {
+        case 0: launch_lstm_ex<0, PF>(w, a, s); break;
+        case 1: launch_lstm_ex<1, PF>(w, a, s); break;
+        case 2: launch_lstm_ex<2, PF>(w, a, s); break;
+        default: launch_lstm_ex<4, PF>(w, a, s); break;
+    }
 }
 
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (a.num_tiles <= 0) return;
-    switch (a.ex) {
-        case 0: launch_lstm_ex<0>(w, a, s); break;
-        case 1: launch_lstm_ex<1>(w, a, s); break;
-        case 2: launch_lstm_ex<2>(w, a, s); break;
-        default: launch_lstm_ex<4>(w, a, s); break;
-    }
+    if (w.prefetch_groups == 2) launch_lstm_pf<2>(w, a, s);
+    else launch_lstm_pf<1>(w, a, s);
 }
 
 // Tile plan: a tile = 32 MFMA rows + up to ex VALU rows.  All tiles cost the same time whatever their

@@ -315,6 +315,14 @@ class FullSubNet_Plus(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_num_cus(self._handle, int(num_cus)), "fsnp_debug_set_num_cus")
 
+    def debug_set_lstm_prefetch(self, groups, device="cuda"):
+        """Tuning hook: weight k-groups in flight ahead of the MFMAs in the fused LSTM kernel (1 or 2)."""
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        lib = self._ensure_handle(dev)
+        _lib.check(lib.fsnp_debug_set_lstm_prefetch(self._handle, int(groups)), "fsnp_debug_set_lstm_prefetch")
+
     def set_timing(self, enable=True):
         _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")
 

@@ -132,6 +132,10 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
+/* Tuning hook: number of 8-deep k-groups of LSTM weights kept in flight ahead of the MFMAs (1 or 2;
+ * also settable with the environment variable FSNP_LSTM_PREFETCH at fsnp_create time). */
+int fsnp_debug_set_lstm_prefetch(fsnp_handle* h, int32_t groups);
+
 /* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =
  * 32 MFMA rows + up to 4 VALU rows; see csrc/lstm.hip plan_lstm_tiles), so that small inputs exercise
  * the multi-round / extra-row tile shapes. */

@@ -88,6 +88,22 @@ def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
     assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
 
 
+@pytest.mark.parametrize("n,cus,steps", [(70, 256, 11), (67, 2, 8), (257, 8, 6)])
+def test_lstm2_fc_prefetch2_variant(n, cus, steps):
+    """The 2-groups-ahead weight pipeline (KX padded to 48) must give the same numbers."""
+    sd = make_state_dict(6, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    m.debug_set_num_cus(cus)
+    m.debug_set_lstm_prefetch(2)
+    rng = np.random.Generator(np.random.PCG64(7 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    err = rel_err(got, want)
+    _record(f"lstm_prefetch2_{n}_cus{cus}", rel=err)
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("name", ["b1_t24_harsh_stages", "b1_t30_cum_layer", "b5_t16_default"])
 def test_forward_with_valu_rows(name):
     """Whole forward with 33-row tiles (257 rows on a pretend 8-CU chip == B=32 on 256 CUs in miniature)."""
