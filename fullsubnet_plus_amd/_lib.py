@@ -40,9 +40,9 @@ SYMBOLS = {
     "fsnp_forward_flops": (ctypes.c_double, [c_vp, c_i32, c_i32, c_i32]),
     "fsnp_lstm_flops": (ctypes.c_double, [c_vp, c_i64, c_i32]),
     "fsnp_debug_lstm_profile": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64]),
-    "fsnp_debug_set_lstm_prefetch": (c_i32, [c_vp, c_i32]),
+    "fsnp_debug_set_lstm_waves": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_num_cus": (c_i32, [c_vp, c_i32]),
-    "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_last_error": (ctypes.c_char_p, []),
     "fsnp_version": (ctypes.c_char_p, []),
 }

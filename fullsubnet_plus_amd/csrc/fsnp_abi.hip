@@ -65,7 +65,7 @@ struct fsnp_handle {
     bool have_last = false;
     bool debug = false;
     int num_cus = 256;
-    int lstm_prefetch_groups = 1;
+    int lstm_waves = 12;
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;
@@ -261,9 +261,9 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->NB = cfg->num_tcn_blocks;
     h->Fr = cfg->num_freqs / 2;
     build_specs(h);
-    const char* pf = getenv("FSNP_LSTM_PREFETCH");
-    if (pf && pf[0] == '2') h->lstm_prefetch_groups = 2;
-    if (pf && pf[0] == '1') h->lstm_prefetch_groups = 1;
+    const char* nw = getenv("FSNP_LSTM_WAVES");
+    if (nw && atoi(nw) == 4) h->lstm_waves = 4;
+    if (nw && atoi(nw) == 12) h->lstm_waves = 12;
     const char* dbg = getenv("FSNP_DEBUG_STAGES");
     h->debug = dbg && dbg[0] == '1';
     *out = h;
@@ -368,12 +368,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     // ---- LSTM: MFMA B-fragment order + summed biases
     const std::string s = "sb_model.sequence_model.";
-    const size_t o_wpack = alloc(lstm_pack_floats(H, h->KX));
-    lstm_pack_weights(H, h->NIN, h->KX, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+    const size_t o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
+    lstm_pack_weights(H, h->NIN, h->KX, 4, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                       W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack);
-    const size_t o_wpack48 = alloc(lstm_pack_floats(H, 48));
-    lstm_pack_weights(H, h->NIN, 48, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                      W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack48);
+    const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
+    lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                      W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
     const size_t o_lbias = alloc((size_t)2 * 4 * H);
     for (int l = 0; l < 2; ++l) {
         const auto& bi = W(s + "bias_ih_l" + std::to_string(l));
@@ -404,7 +404,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
     h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
-    h->lw.wpack = d + o_wpack; h->lw.wpack48 = d + o_wpack48; h->lw.prefetch_groups = h->lstm_prefetch_groups; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
+    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
     h->d_refl_w = d + o_refl;
     h->committed = true;
@@ -594,10 +594,10 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     return 0;
 }
 
-int fsnp_debug_set_lstm_prefetch(fsnp_handle* h, int32_t groups) {
-    if (!h || (groups != 1 && groups != 2)) { set_error("fsnp_debug_set_lstm_prefetch: groups must be 1 or 2"); return 1; }
-    h->lstm_prefetch_groups = groups;
-    h->lw.prefetch_groups = groups;
+int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves) {
+    if (!h || (waves != 4 && waves != 12)) { set_error("fsnp_debug_set_lstm_waves: waves must be 4 or 12"); return 1; }
+    h->lstm_waves = waves;
+    h->lw.waves = waves;
     return 0;
 }
 
@@ -607,15 +607,15 @@ int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus) {
     return 0;
 }
 
-int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0,
+int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t waves, const float* wih0, const float* whh0,
                          const float* wih1, const float* whh1, float* out, int64_t out_floats) {
     if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_pack: null argument"); return 1; }
-    if (hidden % 128 != 0 || kx % 8 != 0 || input_size > kx) { set_error("fsnp_debug_lstm_pack: bad sizes"); return 2; }
-    if ((int64_t)lstm_pack_floats(hidden, kx) != out_floats) {
-        set_error("fsnp_debug_lstm_pack: need %lld floats", (long long)lstm_pack_floats(hidden, kx));
+    if (waves <= 0 || hidden % (32 * waves) != 0 || kx % 8 != 0 || input_size > kx) { set_error("fsnp_debug_lstm_pack: bad sizes"); return 2; }
+    if ((int64_t)lstm_pack_floats(hidden, kx, waves) != out_floats) {
+        set_error("fsnp_debug_lstm_pack: need %lld floats", (long long)lstm_pack_floats(hidden, kx, waves));
         return 2;
     }
-    lstm_pack_weights(hidden, input_size, kx, wih0, whh0, wih1, whh1, out);
+    lstm_pack_weights(hidden, input_size, kx, waves, wih0, whh0, wih1, whh1, out);
     return 0;
 }
 

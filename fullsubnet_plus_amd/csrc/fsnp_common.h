@@ -107,8 +107,8 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 // lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile
 struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
-    const float* wpack48; // same with the input block padded to KX = 48 (even group counts for prefetch_groups = 2)
-    int prefetch_groups; // 1 or 2 k-groups of weights in flight ahead of the MFMAs
+    const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
+    int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
     const float* bfc;    // [OUT]
@@ -138,9 +138,9 @@ struct LstmArgs {
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
-size_t lstm_pack_floats(int H, int KX);  // size of wpack in floats
+size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
-void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1,
+void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
                        const float* whh1, float* wpack);
 
 // ---------------------------------------------------------------------------------------------

@@ -10,7 +10,9 @@
 // time-major [utt][t][freq] full-band buffers each step, and writes its 2 mask values straight into
 // out[b, o, f, t - look_ahead].
 //
-// Mapping (one workgroup = 4 waves = one per SIMD, one workgroup per CU, 512 registers per lane):
+// Mapping (one workgroup per CU; NW = 4 waves (one per SIMD, 512 registers) or NW = 12 (three per SIMD,
+// 168 registers: measured on gfx950, a wave's own loads / LDS reads / VALU ops each ADD 7-23 cycles to its
+// MFMA stream - tools/ubench/mfma_issue.hip - so only OTHER waves' MFMAs can cover them); described for NW = 4:
 //   * rows      : 32 independent sequences per workgroup = the M of v_mfma_f32_32x32x2_f32.
 //   * columns   : wave w owns hidden units [w*H/4, (w+1)*H/4) of BOTH layers, i.e. 4 gates x 96 units
 //                 = 12 accumulator tiles of 32 columns (192 accumulator registers); the i/f/g/o values
@@ -106,59 +108,6 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
     }
 }
 
-// One k-group: 12 tiles x (4 MFMAs, VALU rows, refill of the consumed registers with group `gload`).
-template <int NT, int EX>
-__device__ __forceinline__ void mfma_one_group(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
-                                               const float4 a, const float4 (&ae)[EX > 0 ? EX : 1],
-                                               const float4* __restrict__ wn) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
-        if (EX > 0) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < EX; ++e) {
-            float v = accx[e][n];
-            v = fmaf(ae[e].x, b[n].x, v);
-            v = fmaf(ae[e].y, b[n].y, v);
-            v = fmaf(ae[e].z, b[n].z, v);
-            accx[e][n] = fmaf(ae[e].w, b[n].w, v);
-        }
-        b[n] = wn[n * 64];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Two-groups-ahead variant: b0 holds the group about to be used, b1 the one after it; each is refilled in
-// place with the group two ahead.  ngroups must be even (KX is padded to 48 so that every segment is).
-template <int NT, int EX>
-__device__ __forceinline__ void mfma_groups_pf2(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b0)[NT],
-                                                float4 (&b1)[NT], const float4* __restrict__ A,
-                                                const float4* __restrict__ AE, int ngroups,
-                                                const float4* __restrict__ wlane, int& gnext, int groups_total) {
-    constexpr int EXA = EX > 0 ? EX : 1;
-    float4 a = A[0];
-    float4 ae[EXA];
-#pragma unroll
-    for (int e = 0; e < EX; ++e) ae[e] = AE[e];
-    for (int g = 0; g < ngroups; g += 2) {
-        float4 an = A[(g + 1) * 64];
-        float4 aen[EXA];
-#pragma unroll
-        for (int e = 0; e < EX; ++e) aen[e] = AE[(g + 1) * 2 * EX + e];
-        mfma_one_group<NT, EX>(acc, accx, b0, a, ae, wlane + (size_t)gnext * (NT * 64));
-        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
-        const int g2 = (g + 2 < ngroups ? g + 2 : g + 1);
-        a = A[g2 * 64];
-#pragma unroll
-        for (int e = 0; e < EX; ++e) ae[e] = AE[g2 * 2 * EX + e];
-        mfma_one_group<NT, EX>(acc, accx, b1, an, aen, wlane + (size_t)gnext * (NT * 64));
-        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
-    }
-}
-
 template <int ST, int UW>
 __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST], float* __restrict__ Hs, int wave,
                                           int lane) {
@@ -202,13 +151,15 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
         }
 }
 
-template <int HID, int KX, int OUT, int EX, bool PROF, int PF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int HID, int KX, int OUT, int EX, bool PROF, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
     static_assert(EX >= 0 && EX <= 4, "at most 4 VALU rows per tile (one FC wave per extra row)");
-    constexpr int UW = HID / 4, ST = UW / 32, NT = 4 * ST;
-    static_assert(UW % 32 == 0, "hidden/4 must be a multiple of 32");
+    static_assert(NW % 4 == 0 && NW >= 4, "whole waves per SIMD");
+    constexpr int NTHR = 64 * NW;
+    constexpr int UW = HID / NW, ST = UW / 32, NT = 4 * ST;   // hidden units, 32-unit blocks, tiles per wave
+    static_assert(UW % 32 == 0 && UW * NW == HID, "hidden/NW must be a multiple of 32");
     constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH, KG1 = 2 * KGH, KGT = KG0 + KG1;
     static_assert(KGH % 4 == 0, "FC k-split");
     constexpr int RT = 32 + EX;                 // row slots per tile
@@ -223,7 +174,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     float4* HE1s = HE0s + KGH * 2 * EX;                  // [KGH][2][EX]
     float4* Wfc4 = HE1s + KGH * 2 * EX;                  // [OUT][KGH][2]
     RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [RT]
-    float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [2][4][NT][32]
+    float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [2][NW][NT][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -231,15 +182,15 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     const int slot0 = blockIdx.x * RT;
     const int Tp = a.Tp;
 
-    for (int i = tid; i < (KGX + 2 * KGH) * (64 + 2 * EX); i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < OUT * KGH * 2; i += 256) {
+    for (int i = tid; i < (KGX + 2 * KGH) * (64 + 2 * EX); i += NTHR) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < OUT * KGH * 2; i += NTHR) {
         const int o = i / (KGH * 2), kg = (i >> 1) % KGH, kh = i & 1;
         const float* wr = w.wfc + (size_t)o * HID + kg * 8 + kh;
         Wfc4[i] = make_float4(wr[0], wr[2], wr[4], wr[6]);
     }
     if (tid < RT) rows_s[tid] = a.rows[slot0 + tid];
-    for (int i = tid; i < 2 * 4 * NT * 32; i += 256) {
-        const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) & 3, layer = i / (32 * NT * 4);
+    for (int i = tid; i < 2 * NW * NT * 32; i += NTHR) {
+        const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) % NW, layer = i / (32 * NT * NW);
         Bs[i] = w.bias[layer * 4 * HID + (n / ST) * HID + wv * UW + (n % ST) * 32 + col];
     }
     __syncthreads();
@@ -264,16 +215,21 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         if (a.md_row != nullptr) md_row = a.md_row + (size_t)slot * Tp;
         else md = a.md_utt[rd.b];
     };
+    // main rows: NTHR/32 feature lanes; thread owns row = tid & 31, features j = (tid >> 5) + (NTHR/32) i
+    constexpr int JSTEP = NTHR / 32, NG = (KX + JSTEP - 1) / JSTEP;
     const int grow = tid & 31;
-    int goff[KGX];
+    int goff[NG], xdst[NG];
     NormMD md; const NormMD* md_row;
     {
         const RowDesc rd = rows_s[grow];
 #pragma unroll
-        for (int i = 0; i < KGX; ++i) goff[i] = plan(rd, (tid >> 5) + 8 * i);
+        for (int i = 0; i < NG; ++i) {
+            const int j = (tid >> 5) + JSTEP * i;
+            goff[i] = j < KX ? plan(rd, j) : -2;          // -2: this thread has no element i
+            xdst[i] = a_frag_index(grow, j < KX ? j : 0);
+        }
         row_md(rd, slot0 + grow, md, md_row);
     }
-    const int xdst0 = a_frag_index(grow, tid >> 5);   // feature j = (tid>>5) + 8 i  ->  + i * 256 floats
     int goffx = -1, xdstx = 0;
     NormMD mdx = {0.0f, 1.0f}; const NormMD* mdx_row = nullptr;
     if (EX > 0 && tid < EX * KX) {
@@ -289,7 +245,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     {   // x(0)
         const NormMD m0 = md_row ? md_row[0] : md;
 #pragma unroll
-        for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
+        for (int i = 0; i < NG; ++i)
+            if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
         if (EX > 0 && tid < EX * KX) {
             const NormMD mx = mdx_row ? mdx_row[0] : mdx;
             XEf[xdstx] = goffx >= 0 ? (gbase[goffx] - mx.m) / mx.d : 0.0f;
@@ -311,23 +268,16 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     }
 
     const float4* __restrict__ wlane = reinterpret_cast<const float4*>(w.wpack) + (size_t)wave * KGT * NT * 64 + lane;
-    float4 breg[NT], breg1[PF == 2 ? NT : 1];
+    float4 breg[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) breg[n] = wlane[n * 64];   // group 0
     int gnext = 1;
-    if constexpr (PF == 2) {
-        static_assert(PF != 2 || (KG0 % 2 == 0 && KGH % 2 == 0), "pf2 needs even group counts");
-#pragma unroll
-        for (int n = 0; n < NT; ++n) breg1[n] = wlane[(NT + n) * 64];   // group 1
-        gnext = 2;
-    }
     auto run_groups = [&](f32x16 (&acc_)[NT], float (&accx_)[EXA][NT], const float4* A_, const float4* AE_, int ng) {
-        if constexpr (PF == 2) mfma_groups_pf2<NT, EX>(acc_, accx_, breg, breg1, A_, AE_, ng, wlane, gnext, KGT);
-        else mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, wlane, gnext, KGT);
+        mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, wlane, gnext, KGT);
     };
 
     // FC lane mapping (rows 0..31): 8 rows x 2 outputs x 4 k-parts per wave
-    const int fc_row = wave * 8 + (lane & 7);
+    const int fc_row = (wave & 3) * 8 + (lane & 7);
     const int fc_o = (lane >> 3) & 1;
     const int fc_kp = lane >> 4;
     const RowDesc fc_rd = rows_s[fc_row];
@@ -335,6 +285,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     const RowDesc fcx_rd = (EX > 0 && wave < EX) ? rows_s[32 + (wave < EX ? wave : 0)] : RowDesc{0, 0, 0, 0};
 
     auto fc_store = [&](int t_of_h) {
+      if (wave < 4) {
         constexpr int KGP = KGH / 4;
         float sum = 0.0f;
 #pragma unroll 4
@@ -351,6 +302,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         sum += __shfl_xor(sum, 32);
         if (fc_kp == 0 && fc_rd.valid && t_of_h >= a.LA)
             a.out[(size_t)fc_rd.out_off + (size_t)fc_o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sum + w.bfc[fc_o], a.act);
+      }
         if (EX > 0 && wave < EX) {
             const int o = lane >> 5;
             const float* he = reinterpret_cast<const float*>(HE1s);
@@ -388,13 +340,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     for (int t = 0; t < Tp; ++t) {
         FSNP_STAMP(0);
         // prefetch x(t+1) (consumed after the layer-0 MFMA phase)
-        float xr[KGX], xrx = 0.0f;
+        float xr[NG], xrx = 0.0f;
         NormMD mdn = md, mdxn = mdx;
         const bool have_next = (t + 1 < Tp);
         if (have_next) {
             if (md_row) mdn = md_row[t + 1];
 #pragma unroll
-            for (int i = 0; i < KGX; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
+            for (int i = 0; i < NG; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
             if (EX > 0 && tid < EX * KX) {
                 if (mdx_row) mdxn = mdx_row[t + 1];
                 xrx = goffx >= 0 ? gbase[goffx + (t + 1) * gstep] : 0.0f;
@@ -419,7 +371,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
         if (have_next) {
 #pragma unroll
-            for (int i = 0; i < KGX; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
+            for (int i = 0; i < NG; ++i)
+                if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
             if (EX > 0 && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
         }
         if (t > 0) fc_store(t - 1);
@@ -449,17 +402,19 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-size_t lstm_pack_floats(int H, int KX) {
-    const int NT = 4 * (H / 4 / 32);
+size_t lstm_pack_floats(int H, int KX, int NW) {
+    const int NT = 4 * (H / NW / 32);
     const int KGT = KX / 8 + H / 8 + 2 * (H / 8);
-    return (size_t)4 * KGT * NT * 64 * 4;
+    return (size_t)NW * KGT * NT * 64 * 4;
 }
 
-void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1,
+// [wave][k-group][tile][lane][k-pair]: wave wv owns hidden units [wv*H/NW, (wv+1)*H/NW); tile n = gate*ST + s
+// holds columns unit = wv*UW + 32 s + (lane & 31) of gate `gate`; k = 8 g + 2 p + (lane >> 5).
+void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
                        const float* whh1, float* wpack) {
-    const int UW = H / 4, ST = UW / 32, NT = 4 * ST;
+    const int UW = H / NW, ST = UW / 32, NT = 4 * ST;
     const int KGX = KX / 8, KGH = H / 8, KG0 = KGX + KGH, KGT = KG0 + 2 * KGH;
-    for (int wv = 0; wv < 4; ++wv)
+    for (int wv = 0; wv < NW; ++wv)
         for (int g = 0; g < KGT; ++g)
             for (int n = 0; n < NT; ++n)
                 for (int lane = 0; lane < 64; ++lane)
@@ -480,44 +435,43 @@ void lstm_pack_weights(int H, int NIN, int KX, const float* wih0, const float* w
                     }
 }
 
-template <int EX, int PF>
+template <int EX, int NW>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, KX = PF == 2 ? 48 : 40, OUT = 2;
-    constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / 4 / 32);
+    constexpr int HID = 384, KX = 40, OUT = 2;
+    constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
-                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * 4 * NT * 32 * 4;
+                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4;
     LstmWeights wv = w;
-    wv.KX = KX;
-    wv.wpack = PF == 2 ? w.wpack48 : w.wpack;
+    wv.wpack = NW == 12 ? w.wpack12 : w.wpack;
     if (a.prof != nullptr) {
-        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, PF>;
+        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
+        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
         return;
     }
     static bool attr_set = false;
-    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, PF>;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
+    hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
 }
 
-template <int PF>
-static void launch_lstm_pf(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+template <int NW>
+static void launch_lstm_nw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     switch (a.ex) {
-        case 0: launch_lstm_ex<0, PF>(w, a, s); break;
-        case 1: launch_lstm_ex<1, PF>(w, a, s); break;
-        case 2: launch_lstm_ex<2, PF>(w, a, s); break;
-        default: launch_lstm_ex<4, PF>(w, a, s); break;
+        case 0: launch_lstm_ex<0, NW>(w, a, s); break;
+        case 1: launch_lstm_ex<1, NW>(w, a, s); break;
+        case 2: launch_lstm_ex<2, NW>(w, a, s); break;
+        default: launch_lstm_ex<4, NW>(w, a, s); break;
     }
 }
 
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (a.num_tiles <= 0) return;
-    if (w.prefetch_groups == 2) launch_lstm_pf<2>(w, a, s);
-    else launch_lstm_pf<1>(w, a, s);
+    if (w.waves == 12) launch_lstm_nw<12>(w, a, s);
+    else launch_lstm_nw<4>(w, a, s);
 }
 
 // Tile plan: a tile = 32 MFMA rows + up to ex VALU rows.  All tiles cost the same time whatever their

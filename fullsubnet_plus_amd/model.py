@@ -315,13 +315,13 @@ class FullSubNet_Plus(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_num_cus(self._handle, int(num_cus)), "fsnp_debug_set_num_cus")
 
-    def debug_set_lstm_prefetch(self, groups, device="cuda"):
-        """Tuning hook: weight k-groups in flight ahead of the MFMAs in the fused LSTM kernel (1 or 2)."""
+    def debug_set_lstm_waves(self, waves, device="cuda"):
+        """Tuning hook: waves per workgroup of the fused LSTM kernel (12 = three per SIMD, or 4)."""
         dev = torch.device(device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         lib = self._ensure_handle(dev)
-        _lib.check(lib.fsnp_debug_set_lstm_prefetch(self._handle, int(groups)), "fsnp_debug_set_lstm_prefetch")
+        _lib.check(lib.fsnp_debug_set_lstm_waves(self._handle, int(waves)), "fsnp_debug_set_lstm_waves")
 
     def set_timing(self, enable=True):
         _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")

@@ -132,9 +132,9 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
-/* Tuning hook: number of 8-deep k-groups of LSTM weights kept in flight ahead of the MFMAs (1 or 2;
- * also settable with the environment variable FSNP_LSTM_PREFETCH at fsnp_create time). */
-int fsnp_debug_set_lstm_prefetch(fsnp_handle* h, int32_t groups);
+/* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD, default) or 4 (one per
+ * SIMD); also settable with the environment variable FSNP_LSTM_WAVES at fsnp_create time. */
+int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves);
 
 /* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =
  * 32 MFMA rows + up to 4 VALU rows; see csrc/lstm.hip plan_lstm_tiles), so that small inputs exercise
@@ -142,9 +142,9 @@ int fsnp_debug_set_lstm_prefetch(fsnp_handle* h, int32_t groups);
 int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus);
 
 /* Test hook (host only, no GPU needed): run the LSTM weight packer that fsnp_commit_weights uses.
- * out receives 4 * (kx/8 + 3*hidden/8) * (hidden/32) * 64 * 4 floats in MFMA B-fragment order
- * [wave][k-group][tile][lane][k-pair] (layout documented in csrc/lstm.hip). */
-int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0,
+ * out receives (kx/8 + 3*hidden/8) * (hidden/32) * 4 * 64 * 4 floats in MFMA B-fragment order
+ * [wave][k-group][tile][lane][k-pair] for a `waves`-wave workgroup (layout documented in csrc/lstm.hip). */
+int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t waves, const float* wih0, const float* whh0,
                          const float* wih1, const float* whh1, float* out, int64_t out_floats);
 
 const char* fsnp_last_error(void);

@@ -88,19 +88,21 @@ def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
     assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
 
 
-@pytest.mark.parametrize("n,cus,steps", [(70, 256, 11), (67, 2, 8), (257, 8, 6)])
-def test_lstm2_fc_prefetch2_variant(n, cus, steps):
-    """The 2-groups-ahead weight pipeline (KX padded to 48) must give the same numbers."""
+@pytest.mark.parametrize("waves", [4, 12])
+@pytest.mark.parametrize("n,cus,steps", [(70, 256, 11), (66, 2, 8), (67, 2, 8), (257, 7, 6)])
+def test_lstm2_fc_wave_variants(waves, n, cus, steps):
+    """Both workgroup shapes of the fused LSTM kernel (4 waves = 1/SIMD, 12 waves = 3/SIMD), with and without
+    VALU rows, must agree with the oracle."""
     sd = make_state_dict(6, "default")
     m = _model(DEFAULT_MODEL_ARGS, sd)
     m.debug_set_num_cus(cus)
-    m.debug_set_lstm_prefetch(2)
+    m.debug_set_lstm_waves(waves)
     rng = np.random.Generator(np.random.PCG64(7 + n))
     x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
     want = fsnp_torch.lstm2_fc(x, sd).numpy()
     got = m.lstm2_fc(x.cuda()).cpu().numpy()
     err = rel_err(got, want)
-    _record(f"lstm_prefetch2_{n}_cus{cus}", rel=err)
+    _record(f"lstm_waves{waves}_{n}_cus{cus}", rel=err)
     assert err < 2e-5, err
 
 

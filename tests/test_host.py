@@ -81,20 +81,20 @@ def test_weight_init_true_reinitialises():
     assert torch.allclose(g, torch.eye(384), atol=1e-4)
 
 
-def _emulate_mfma_gates(pack, A_lds, H, KX, layer, kgroups):
+def _emulate_mfma_gates(pack, A_lds, H, KX, layer, kgroups, NW=4):
     """Replays lstm.hip's inner loop in numpy: for every wave/tile/lane, accumulate
     D[row][col] += A[row][k] * B[k][col] with the documented 32x32x2 f32 fragment maps
     (A: lane l -> A[l&31][l>>5], B: lane l -> B[l>>5][l&31], C: col=l&31,
     row=(r&3)+8*(r>>2)+4*(l>>5)).  Returns gates [32 rows][4H] in reference row order."""
-    UW, ST = H // 4, H // 4 // 32
+    UW, ST = H // NW, H // NW // 32
     NT = 4 * ST
     KGX, KGH = KX // 8, H // 8
     KG0, KGT = KGX + KGH, KGX + 3 * KGH
-    packv = pack.reshape(4, KGT, NT, 64, 4)
+    packv = pack.reshape(NW, KGT, NT, 64, 4)
     gates = np.zeros((32, 4 * H), dtype=np.float64)
     g0 = 0 if layer == 0 else KG0
     lanes = np.arange(64)
-    for wave in range(4):
+    for wave in range(NW):
         for n in range(NT):
             D = np.zeros((32, 32))
             for gi in range(kgroups):
@@ -112,7 +112,8 @@ def _emulate_mfma_gates(pack, A_lds, H, KX, layer, kgroups):
     return gates
 
 
-def test_lstm_pack_matches_mfma_fragment_emulation():
+@pytest.mark.parametrize("NW", [4, 12])
+def test_lstm_pack_matches_mfma_fragment_emulation(NW):
     lib = _lib.load()
     H, NIN, KX = 384, 34, 40
     rng = np.random.default_rng(0)
@@ -120,9 +121,9 @@ def test_lstm_pack_matches_mfma_fragment_emulation():
     whh0 = rng.standard_normal((4 * H, H)).astype(np.float32)
     wih1 = rng.standard_normal((4 * H, H)).astype(np.float32)
     whh1 = rng.standard_normal((4 * H, H)).astype(np.float32)
-    n = 4 * (KX // 8 + 3 * H // 8) * (H // 32) * 64 * 4
+    n = (KX // 8 + 3 * H // 8) * (H // 32) * 4 * 64 * 4
     pack = np.zeros(n, dtype=np.float32)
-    rc = lib.fsnp_debug_lstm_pack(H, NIN, KX, wih0.ctypes.data, whh0.ctypes.data, wih1.ctypes.data,
+    rc = lib.fsnp_debug_lstm_pack(H, NIN, KX, NW, wih0.ctypes.data, whh0.ctypes.data, wih1.ctypes.data,
                                   whh1.ctypes.data, pack.ctypes.data, n)
     assert rc == 0, lib.fsnp_last_error()
 
@@ -140,11 +141,30 @@ def test_lstm_pack_matches_mfma_fragment_emulation():
     xp = np.zeros((32, KX)); xp[:, :NIN] = x
     # layer 0: K order [x | h0]
     A0 = np.concatenate([a_frag(xp), a_frag(h0)], axis=0)
-    got0 = _emulate_mfma_gates(pack, A0, H, KX, 0, KX // 8 + H // 8)
+    got0 = _emulate_mfma_gates(pack, A0, H, KX, 0, KX // 8 + H // 8, NW)
     want0 = x @ wih0.T.astype(np.float64) + h0 @ whh0.T.astype(np.float64)
     assert np.abs(got0 - want0).max() < 1e-9
     # layer 1: K order [h1 | h0]
     A1 = np.concatenate([a_frag(h1), a_frag(h0)], axis=0)
-    got1 = _emulate_mfma_gates(pack, A1, H, KX, 1, 2 * (H // 8))
+    got1 = _emulate_mfma_gates(pack, A1, H, KX, 1, 2 * (H // 8), NW)
     want1 = h1 @ whh1.T.astype(np.float64) + h0 @ wih1.T.astype(np.float64)
     assert np.abs(got1 - want1).max() < 1e-9
+
+
+def test_lstm_hot_loops_have_no_scratch_or_drain():
+    """Static check of hipcc's gfx950 assembly (tools/check_lstm_asm.py): the k-group loops of every
+    lstm2_fc_kernel instantiation keep the refill-in-place weight pipeline (no scratch traffic; no
+    vmcnt(0) drain in the production EX=0 kernels)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse()
+    assert len(res) >= 8
+    for key, loops in res.items():
+        assert len(loops) == 3, (key, loops)                      # layer 0, layer 1 (h1 part), layer 1 (h0 part)
+        for l in loops:
+            assert l["scratch"] == 0, (key, l)
+            assert l["mfma"] % 16 == 0 and l["gload"] * 4 == l["mfma"], (key, l)
+            if "_EX0_" in key:
+                assert l["drain"] == 0, (key, l)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Static check of the fused LSTM kernel's hot loops in the gfx950 assembly hipcc emits.
+
+For every instantiation of lstm2_fc_kernel: each depth-2 loop (the k-group loops) must contain MFMAs,
+no scratch access and no full `s_waitcnt vmcnt(0)` drain, i.e. the refill-in-place weight pipeline survived
+the compiler.  Used by tests/test_host.py (CPU, hipcc cross-compiles) and by hand while tuning."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "lstm.hip")
+
+
+def analyse(flags=("-fno-slp-vectorize",)):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "lstm.s")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", SRC, "-o", out]
+        subprocess.run(cmd, check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp15lstm2_fc_kernelI\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        tag = re.search(r"Li384ELi(\d+)ELi2ELi(\d)ELb(\d)ELi(\d+)E", name)
+        key = f"KX{tag.group(1)}_EX{tag.group(2)}_PROF{tag.group(3)}_NW{tag.group(4)}"
+        loops = []
+        for i, l in enumerate(body):
+            if "Inner Loop Header: Depth=2" not in l:
+                continue
+            lab = None
+            for k in range(i, max(i - 4, 0), -1):
+                mm = re.match(r"^(\.LBB\d+_\d+):", body[k])
+                if mm:
+                    lab = mm.group(1)
+                    break
+            end = next(k for k in range(i, len(body)) if re.search(r"s_cbranch_\w+ " + re.escape(lab) + r"\b", body[k]))
+            seg = body[i:end]
+            cnt = lambda pat: sum(1 for x in seg if re.search(pat, x))
+            loops.append(dict(mfma=cnt(r"v_mfma"), scratch=cnt(r"scratch_"), drain=cnt(r"vmcnt\(0\)"),
+                              gload=cnt(r"global_load_dwordx4"), valu=cnt(r"\bv_fma|\bv_fmac"), lines=len(seg)))
+        res[key] = [l for l in loops if l["mfma"] > 0]
+    return res
+
+
+if __name__ == "__main__":
+    r = analyse()
+    bad = 0
+    for k in sorted(r):
+        for l in r[k]:
+            ok = l["scratch"] == 0 and l["drain"] == 0
+            bad += not ok
+            print(k, l, "" if ok else "  <-- BAD")
+    sys.exit(1 if bad else 0)

@@ -16,7 +16,7 @@ def main():
     out = torch.empty(n, 2, steps, device="cuda")
     m.lstm2_fc(x.permute(0, 2, 1)[:64])          # creates the handle
     if len(sys.argv) > 3:
-        m.debug_set_lstm_prefetch(int(sys.argv[3]))
+        m.debug_set_lstm_waves(int(sys.argv[3]))
     lib = _lib.load()
     stamps = np.zeros(steps * 8, dtype=np.uint64)
     for rep in range(2):
@@ -26,7 +26,7 @@ def main():
     names = ["L0 mfma", "barrier", "cell0+x+fc", "barrier", "L1 mfma", "barrier", "cell1"]
     d = np.diff(s, axis=1)[4:]                     # skip warm-up steps
     step = (s[5:, 0] - s[4:-1, 0])
-    res = {"rows": n, "steps": steps, "prefetch": int(sys.argv[3]) if len(sys.argv) > 3 else 1, "ticks_per_step": float(step.mean())}
+    res = {"rows": n, "steps": steps, "waves": int(sys.argv[3]) if len(sys.argv) > 3 else 12, "ticks_per_step": float(step.mean())}
     for i, nm in enumerate(names):
         res[f"{i}:{nm}"] = float(d[:, i].mean())
     res["gap_to_next_step"] = float((s[5:, 0] - s[4:-1, 7]).mean())
