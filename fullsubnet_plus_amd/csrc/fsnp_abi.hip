@@ -65,7 +65,7 @@ struct fsnp_handle {
     bool have_last = false;
     bool debug = false;
     int num_cus = 256;
-    int lstm_waves = 12;
+    int lstm_waves = 4;
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;

@@ -62,10 +62,23 @@ __host__ __device__ __forceinline__ int e_frag_index(int e, int k) {
 // Consume `ngroups` k-groups: A from LDS (A already offset by lane), B from the rotating register
 // buffer `b` (always holding the group about to be used); refills b from the weight stream.
 // AE (offset by (lane>>5)*EX) is the E-image of the extra rows; accx their per-lane partial sums.
+// One 1 KiB weight fragment (tile n of k-group g) of this wave's stream: SRD in SGPRs, constant per-lane
+// voffset (lane * 16), everything else in the scalar offset - no VALU address math in the hot loop, and the
+// cheapest load form measured next to MFMAs (tools/ubench/mfma_issue.hip: 18 vs 23.5 pipe cycles).
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;
+};
+template <int NT>
+__device__ __forceinline__ float4 wload(const WStream& ws, int g, int n) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, (g * NT + n) * 1024, 0);
+    return __builtin_bit_cast(float4, v);
+}
+
 template <int NT, int EX>
 __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
                                             const float4* __restrict__ A, const float4* __restrict__ AE, int ngroups,
-                                            const float4* __restrict__ wlane, int& gnext, int groups_total) {
+                                            const WStream& ws, int& gnext, int groups_total) {
     float4 a = A[0];
     float4 ae[EX > 0 ? EX : 1];
 #pragma unroll
@@ -76,7 +89,6 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
         float4 aen[EX > 0 ? EX : 1];
 #pragma unroll
         for (int e = 0; e < EX; ++e) aen[e] = AE[gn * 2 * EX + e];
-        const float4* __restrict__ wn = wlane + (size_t)gnext * (NT * 64);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
@@ -98,7 +110,7 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
             // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
             // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
             // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
-            b[n] = wn[n * 64];
+            b[n] = wload<NT>(ws, gnext, n);
             __builtin_amdgcn_sched_barrier(0);
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
@@ -254,9 +266,9 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     }
 
     // ---- register state -----------------------------------------------------------------------------
-    // biases sit in LDS in (layer, wave, tile, column) order: Bs[((layer*4 + wave)*NT + n)*32 + col]
-    const float* __restrict__ bias_l0 = Bs + ((0 * 4 + wave) * NT) * 32 + (lane & 31);
-    const float* __restrict__ bias_l1 = Bs + ((1 * 4 + wave) * NT) * 32 + (lane & 31);
+    // biases sit in LDS in (layer, wave, tile, column) order: Bs[((layer*NW + wave)*NT + n)*32 + col]
+    const float* __restrict__ bias_l0 = Bs + ((0 * NW + wave) * NT) * 32 + (lane & 31);
+    const float* __restrict__ bias_l1 = Bs + ((1 * NW + wave) * NT) * 32 + (lane & 31);
     f32x16 c0[ST], c1[ST];
     float cx0[EXA][ST], cx1[EXA][ST];
 #pragma unroll
@@ -267,13 +279,16 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         for (int e = 0; e < EXA; ++e) { cx0[e][s] = 0.0f; cx1[e][s] = 0.0f; }
     }
 
-    const float4* __restrict__ wlane = reinterpret_cast<const float4*>(w.wpack) + (size_t)wave * KGT * NT * 64 + lane;
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.wpack) + (size_t)wave * KGT * NT * 256, 0,
+                                                KGT * NT * 1024, 0x00020000);
+    ws.voff = lane * 16;
     float4 breg[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) breg[n] = wlane[n * 64];   // group 0
+    for (int n = 0; n < NT; ++n) breg[n] = wload<NT>(ws, 0, n);   // group 0
     int gnext = 1;
     auto run_groups = [&](f32x16 (&acc_)[NT], float (&accx_)[EXA][NT], const float4* A_, const float4* AE_, int ng) {
-        mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, wlane, gnext, KGT);
+        mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, ws, gnext, KGT);
     };
 
     // FC lane mapping (rows 0..31): 8 rows x 2 outputs x 4 k-parts per wave

@@ -166,5 +166,5 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
         for l in loops:
             assert l["scratch"] == 0, (key, l)
             assert l["mfma"] % 16 == 0 and l["gload"] * 4 == l["mfma"], (key, l)
-            if "_EX0_" in key:
+            if "_NW4" in key and ("_EX0_" in key or "_EX1_" in key):   # the production kernels
                 assert l["drain"] == 0, (key, l)

@@ -39,7 +39,7 @@ def analyse(flags=("-fno-slp-vectorize",)):
             seg = body[i:end]
             cnt = lambda pat: sum(1 for x in seg if re.search(pat, x))
             loops.append(dict(mfma=cnt(r"v_mfma"), scratch=cnt(r"scratch_"), drain=cnt(r"vmcnt\(0\)"),
-                              gload=cnt(r"global_load_dwordx4"), valu=cnt(r"\bv_fma|\bv_fmac"), lines=len(seg)))
+                              gload=cnt(r"global_load_dwordx4|buffer_load_dwordx4"), valu=cnt(r"\bv_fma|\bv_fmac"), lines=len(seg)))
         res[key] = [l for l in loops if l["mfma"] > 0]
     return res
 
