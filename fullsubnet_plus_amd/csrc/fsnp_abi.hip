@@ -65,7 +65,7 @@ struct fsnp_handle {
     bool have_last = false;
     bool debug = false;
     int num_cus = 256;
-    int lstm_waves = 4;
+    int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;
@@ -595,7 +595,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 }
 
 int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves) {
-    if (!h || (waves != 4 && waves != 12)) { set_error("fsnp_debug_set_lstm_waves: waves must be 4 or 12"); return 1; }
+    if (!h || (waves != 0 && waves != 4 && waves != 12)) { set_error("fsnp_debug_set_lstm_waves: waves must be 0 (auto), 4 or 12"); return 1; }
     h->lstm_waves = waves;
     h->lw.waves = waves;
     return 0;

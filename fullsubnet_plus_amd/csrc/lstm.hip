@@ -485,7 +485,10 @@ static void launch_lstm_nw(const LstmWeights& w, const LstmArgs& a, hipStream_t 
 
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (a.num_tiles <= 0) return;
-    if (w.waves == 12) launch_lstm_nw<12>(w, a, s);
+    // measured (profiles/r01_lstm_phase_ab.md): with VALU rows the 12-wave shape is 10 % faster, without them
+    // both shapes tie and the 4-wave one needs no spills
+    const int waves = w.waves != 0 ? w.waves : (a.ex > 0 ? 12 : 4);
+    if (waves == 12) launch_lstm_nw<12>(w, a, s);
     else launch_lstm_nw<4>(w, a, s);
 }
 

@@ -132,8 +132,9 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
-/* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD) or 4 (one per
- * SIMD, default); also settable with the environment variable FSNP_LSTM_WAVES at fsnp_create time. */
+/* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
+ * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the
+ * environment variable FSNP_LSTM_WAVES at fsnp_create time. */
 int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves);
 
 /* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =

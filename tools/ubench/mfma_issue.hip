@@ -33,6 +33,13 @@ void kern(const float* __restrict__ gin, float* __restrict__ gout, unsigned long
     float4 la = reinterpret_cast<const float4*>(lds)[tid];
     float4 gb = reinterpret_cast<const float4*>(gin)[tid];
     float vx[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pk0 = {0.f, 0.f}, pa = {gin[tid], gin[tid + 1]}, pb = {gin[tid + 2], gin[tid + 3]};
+    f32x4 m4[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m4[n][r] = 0.f;
     const float4* lp = reinterpret_cast<const float4*>(lds) + (tid & 63);
     const float4* gp = reinterpret_cast<const float4*>(gin) + tid;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gin), 0, 1 << 20, 0x00020000);
@@ -182,6 +189,73 @@ void kern(const float* __restrict__ gin, float* __restrict__ gout, unsigned long
                 l1 = reinterpret_cast<const float*>(lp)[(it + n) & 63]; SB();
             }
             a += l1 * 1e-30f;
+        } else if constexpr (P == 23) {  // 16x16x4 round robin over 24 acc + 1 independent v_fmac after EVERY mfma
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < 24; ++n) { MF16(acc4[n], a, b); SB(); vx[n & 3] = fmaf(a, b, vx[n & 3]); SB(); }
+        } else if constexpr (P == 24) {  // 16x16x4 round robin + 1 v_fmac after every 2nd mfma
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < 24; ++n) { MF16(acc4[n], a, b); SB(); if (n & 1) { vx[n & 3] = fmaf(a, b, vx[n & 3]); SB(); } }
+        } else if constexpr (P == 25) {  // 16x16x4 round robin + one raw_buffer_load_b128 per 8 mfma (same bytes/flop as LSTM)
+            const float4 prev = gb;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < 24; ++n) {
+                    MF16(acc4[n], a, b); SB();
+                    if ((n & 7) == 7) {
+                        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ((it + n + p) & 7) * 4096, 0));
+                        gb = make_float4(t[0], t[1], t[2], t[3]); SB();
+                    }
+                }
+            b += prev.x * 1e-30f;
+        } else if constexpr (P == 26) {  // 32x32x2: 12 acc round robin + 1 v_fmac after every mfma
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int n = 0; n < 12; ++n) { MF(acc[n], a, b); SB(); vx[n & 3] = fmaf(a, b, vx[n & 3]); SB(); }
+        } else if constexpr (P == 27) {  // 16x16x4: 2 interleaved chains + 1 v_fmac after every pair
+#pragma unroll
+            for (int n = 0; n < 48; ++n) { MF16(acc4[0], a, b); MF16(acc4[1], a, b); SB(); vx[n & 3] = fmaf(a, b, vx[n & 3]); SB(); }
+        } else if constexpr (P == 28) {  // A + 2 v_pk_fma_f32 after each chain (same FLOPs as 4 v_fmac)
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB();
+                pk0 = __builtin_elementwise_fma(pa, pb, pk0); pk0 = __builtin_elementwise_fma(pa, pb, pk0); SB();
+            }
+        } else if constexpr (P == 29) {  // A + 4 x v_mfma_f32_4x4x1_16b_f32 after each chain (4 extra rows x 64 (k,col))
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB();
+                m4[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[n & 3], 0, 0, 0);
+                m4[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[n & 3], 0, 0, 0);
+                m4[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[n & 3], 0, 0, 0);
+                m4[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[n & 3], 0, 0, 0); SB();
+            }
+        } else if constexpr (P == 30) {  // A + 4 x 4x4x1 on 4 DIFFERENT accumulators after each chain
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB();
+                m4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[0], 0, 0, 0);
+                m4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[1], 0, 0, 0);
+                m4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[2], 0, 0, 0);
+                m4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[3], 0, 0, 0); SB();
+            }
+        } else if constexpr (P == 31) {  // A + 1 x 4x4x1 after each chain
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB();
+                m4[n & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, m4[n & 3], 0, 0, 0); SB();
+            }
+        } else if constexpr (P == 32) {  // 48 v_fmac in ONE batch after the 48 MFMAs
+#pragma unroll
+            for (int n = 0; n < 12; ++n) { MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB(); }
+#pragma unroll
+            for (int n = 0; n < 48; ++n) vx[n & 3] = fmaf(a, b, vx[n & 3]);
+            SB();
         } else if constexpr (P == 15) {  // Q: 12 accumulators x chains of 4, with 1 s_nop after each chain
 #pragma unroll
             for (int n = 0; n < 12; ++n) {
@@ -191,7 +265,7 @@ void kern(const float* __restrict__ gin, float* __restrict__ gout, unsigned long
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    float s = a + b + la.y + gb.y + vx[0] + vx[1] + vx[2] + vx[3];
+    float s = a + b + la.y + gb.y + vx[0] + vx[1] + vx[2] + vx[3] + pk0[0] + pk0[1] + m4[0][0] + m4[1][1] + m4[2][2] + m4[3][3];
 #pragma unroll
     for (int n = 0; n < 12; ++n) s += acc[n][0] + acc[n][7];
 #pragma unroll
@@ -237,6 +311,16 @@ int main() {
         run<19>("U  A + global_load_dword (4 B/lane)", 48, 64, din, dout, dt, blocks);
         run<21>("W  A + ds_read_b64", 48, 64, din, dout, dt, blocks);
         run<22>("X  A + ds_read_b32", 48, 64, din, dout, dt, blocks);
+        run<26>("Y  32x32x2 round-robin + 1 v_fmac after every mfma (48 fmac)", 48, 64, din, dout, dt, blocks);
+        run<23>("Z1 16x16x4 round-robin + 1 v_fmac after every mfma (96 fmac)", 96, 32, din, dout, dt, blocks);
+        run<24>("Z2 16x16x4 round-robin + 1 v_fmac after every 2nd mfma (48 fmac)", 96, 32, din, dout, dt, blocks);
+        run<27>("Z3 16x16x4 2 chains + 1 v_fmac per pair (48 fmac)", 96, 32, din, dout, dt, blocks);
+        run<25>("Z4 16x16x4 round-robin + 12 buffer_load_b128 per 96 mfma", 96, 32, din, dout, dt, blocks);
+        run<28>("P1 A + 2 v_pk_fma_f32 after each chain", 48, 64, din, dout, dt, blocks);
+        run<29>("P2 A + 4 x mfma_4x4x1 (same acc) after each chain", 48, 64, din, dout, dt, blocks);
+        run<30>("P3 A + 4 x mfma_4x4x1 (4 acc) after each chain", 48, 64, din, dout, dt, blocks);
+        run<31>("P4 A + 1 x mfma_4x4x1 after each chain", 48, 64, din, dout, dt, blocks);
+        run<32>("P5 A + 48 v_fmac in one batch per 48 mfma", 48, 64, din, dout, dt, blocks);
         run<13>("N  A + global_load + 4 indep v_fmac after each chain", 48, 64, din, dout, dt, blocks);
         run<10>("K  16x16x4: 24 acc x chain4", 96, 32, din, dout, dt, blocks);
         run<11>("L  16x16x4: 2 interleaved chains", 96, 32, din, dout, dt, blocks);
