@@ -162,6 +162,12 @@ def main():
     lstm_ms = timing["lstm_ms"] / max(timing["count"], 1)
     achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms > 0 else 0.0
 
+    traffic = None   # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes
+    pmc_path = os.path.join(ROOT, "profiles", "lstm_pmc.json")
+    if os.path.exists(pmc_path) and B == 32 and abs(args.seconds - 2.0) < 1e-9 and args.mode == "full":
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+
     result = {
         "metric": "STFT frames/sec (257-bin, 2 s clips), FullSubNet+ forward",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +178,7 @@ def main():
                    "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)"},
         "roofline": {"bound": "mfma", "kernel": "lstm2_fc_kernel<384,40,2>", "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "traffic": None, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
+                     "traffic": traffic, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
                      "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
     }

@@ -1,0 +1,63 @@
+"""Batch sharding of the forward across the GPUs of one node (one process per GPU).
+
+Utterances are independent (every statistic on the path is per utterance: base_model.py:221, the TSSE pool,
+GroupNorm(1), the per-sequence LSTM), so the forward shards over the batch with NO collective in the data path.
+The only traffic is the optional gather of the masks, `torch.distributed.all_gather_into_tensor` on the "nccl"
+backend (= RCCL over xGMI on ROCm); on CPU-only boxes the same code runs on "gloo" for tests.
+
+In the reference's literal B>1 semantics ("parity" mode = drop_band, acoustics/feature.py:254-285) the frequency
+parity and the output row of a sample depend on its GLOBAL batch index, so a shard passes (batch_offset,
+global_batch) down to fsnp_forward and receives its rows of the global [B,2,F//2,T] tensor.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch, rank, world_size):
+    """Contiguous, balanced split: rank r owns samples [lo, hi)."""
+    base, rem = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def parity_output_row(sample, global_batch):
+    """Row of the reference's drop_band output that holds global sample `sample` (even samples first)."""
+    n0 = (global_batch + 1) // 2
+    return sample // 2 if sample % 2 == 0 else n0 + (sample - 1) // 2
+
+
+def forward_sharded(model, noisy_mag, noisy_real, noisy_imag, gather=True, group=None):
+    """Every rank passes the FULL-batch tensors' own shard (already on its device) or the full batch; here each
+    rank receives the global batch on its device and computes only its shard.
+
+    Returns the global mask tensor on every rank if `gather`, else this rank's rows:
+      full mode   -> [hi-lo, 2, F, T]
+      parity mode -> the global [B, 2, F//2, T] with only this rank's rows filled.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = noisy_mag.shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    parity = B > 1 and model.batch_mode == "parity"
+    sl = slice(lo, hi)
+    if hi > lo:
+        out = model(noisy_mag[sl], noisy_real[sl], noisy_imag[sl], batch_offset=lo, global_batch=B)
+    else:
+        F = model.num_freqs // 2 if parity else model.num_freqs
+        out = torch.zeros((B if parity else 0, 2, F, noisy_mag.shape[-1]), dtype=torch.float32, device=noisy_mag.device)
+    if not gather or world == 1:
+        return out
+    if parity:
+        # every rank holds a zero-initialised global tensor with only its rows written: a sum is the gather
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+    sizes = [shard_bounds(B, r, world) for r in range(world)]
+    rows = max(h - l for l, h in sizes)
+    if out.shape[0] < rows:                     # ragged split: pad to the largest shard, trim after the gather
+        pad = torch.zeros((rows - out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+        out = torch.cat([out, pad], dim=0)
+    full = torch.empty((world * rows,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+    dist.all_gather_into_tensor(full, out.contiguous(), group=group)
+    if all(h - l == rows for l, h in sizes):
+        return full
+    return torch.cat([full[r * rows: r * rows + (h - l)] for r, (l, h) in enumerate(sizes)], dim=0)
