@@ -32,7 +32,7 @@ struct WeightSpec {
 
 struct Workspace {
     // offsets in bytes from the workspace base
-    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, mig_state, zero_begin, fsum, gn, sb_acc, mig_flags, zero_end,
+    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, zero_begin, fsum, gn, sb_acc, zero_end,
         dbg_tcn0, total;
 };
 
@@ -65,8 +65,6 @@ struct fsnp_handle {
     bool have_last = false;
     bool debug = false;
     int num_cus = 256;
-    bool allow_migration = true;
-    unsigned* d_err = nullptr;   // [0] = a row-migration hand-off timed out
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
     bool timing = false;
@@ -135,22 +133,15 @@ static void build_specs(fsnp_handle* h) {
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
 // base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
 __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
-                                  int batch_offset, int global_batch, int dense_out, int mig_rows, int mig_w) {
+                                  int batch_offset, int global_batch, int dense_out) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= num_tiles * rt) return;
     const int tile = slot / rt, sl = slot % rt;
-    int n, live;
-    if (mig_rows > 0) {   // row migration: every tile is full; slot 32 of chain tile c carries leftover sequence c / mig_w
-        n = sl < 32 ? tile * 32 + sl : 32 * num_tiles + tile / mig_w;
-        live = sl < 32 || tile < mig_rows * mig_w;
-    } else {
-        const int base = num_rows / num_tiles, rem = num_rows % num_tiles;
-        const int cnt = base + (tile < rem ? 1 : 0);
-        n = tile * base + (tile < rem ? tile : rem) + sl;
-        live = sl < cnt;
-    }
+    const int base = num_rows / num_tiles, rem = num_rows % num_tiles;
+    const int cnt = base + (tile < rem ? 1 : 0);
+    const int n = tile * base + (tile < rem ? tile : rem) + sl;
     RowDesc r{0, 0, 0, 0};
-    if (live) {
+    if (sl < cnt) {
         r.valid = 1;
         if (dense_out) {               // fsnp_lstm2_fc: x[n][t][:] -> out[n][o][t]
             r.b = n; r.f = 0; r.out_off = n * 2 * T;
@@ -189,18 +180,16 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gate = take((size_t)3 * B * h->FP * 4);
     w.md = take((size_t)3 * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
-    const LstmPlan lp = plan_lstm_tiles(B * rows_per_utt(h, mode), h->num_cus, h->allow_migration);
+    const LstmPlan lp = plan_lstm_tiles(B * rows_per_utt(h, mode), h->num_cus);
     const size_t nrows_pad = (size_t)lp.num_tiles * lp.rows_per_slot_tile;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
     w.rows = take(nrows_pad * sizeof(RowDesc));
     w.frame = take((size_t)3 * B * Tp * 2 * 8);
-    w.mig_state = take((size_t)lp.mig_rows * 4 * h->H * 4);
     w.zero_begin = o;
     w.fsum = take((size_t)3 * B * h->FP * 8);
     w.gn = take((size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
-    w.mig_flags = take(lp.mig_rows > 0 ? (size_t)lp.num_tiles * 4 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
     w.total = o;
@@ -213,21 +202,6 @@ static int ensure_workspace(fsnp_handle* h, size_t bytes) {
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes));
     h->ws_bytes = bytes;
     return 0;
-}
-
-// Fill the row-migration fields of LstmArgs; `base` = start of a region holding [state | flags] (dense entry points)
-// or nullptr when the caller sets the pointers itself.
-static void set_migration(const fsnp_handle* h, LstmArgs& a, const LstmPlan& lp, int steps, unsigned char* base) {
-    a.mig_rows = lp.mig_rows; a.mig_w = lp.mig_w;
-    a.mig_len = lp.mig_rows > 0 ? cdiv(steps, lp.mig_w) : 0;
-    a.mig_error = h->d_err;
-    if (base && lp.mig_rows > 0) {
-        a.mig_state = reinterpret_cast<float*>(base);
-        a.mig_flags = reinterpret_cast<unsigned*>(base + align_up((size_t)lp.mig_rows * 4 * h->H * 4, 256));
-    }
-}
-static size_t migration_bytes(const fsnp_handle* h, const LstmPlan& lp) {
-    return lp.mig_rows > 0 ? align_up((size_t)lp.mig_rows * 4 * h->H * 4, 256) + align_up((size_t)lp.num_tiles * 4, 256) : 0;
 }
 
 static double lstm_flops_per_step(const fsnp_handle* h) {
@@ -287,13 +261,6 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->NB = cfg->num_tcn_blocks;
     h->Fr = cfg->num_freqs / 2;
     build_specs(h);
-    const char* mg = getenv("FSNP_LSTM_MIGRATION");
-    if (mg && mg[0] == '0') h->allow_migration = false;
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_err), 256) != hipSuccess || hipMemset(h->d_err, 0, 256) != hipSuccess) {
-        set_error("hipMalloc of the error word failed");
-        delete h;
-        return 4;
-    }
     const char* nw = getenv("FSNP_LSTM_WAVES");
     if (nw && atoi(nw) == 4) h->lstm_waves = 4;
     if (nw && atoi(nw) == 12) h->lstm_waves = 12;
@@ -308,7 +275,6 @@ void fsnp_destroy(fsnp_handle* h) {
     (void)hipDeviceSynchronize();
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_weights) (void)hipFree(h->d_weights);
-    if (h->d_err) (void)hipFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
     delete h;
@@ -483,11 +449,11 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     FSNP_HIP_CHECK(hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, s));
 
     const int num_rows = batch * rows_per_utt(h, mode);
-    const LstmPlan lp = plan_lstm_tiles(num_rows, h->num_cus, h->allow_migration);
+    const LstmPlan lp = plan_lstm_tiles(num_rows, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_rows, lp.num_tiles,
-                       lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0, lp.mig_rows, lp.mig_w);
+                       lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
 
     FrontendBuffers fbuf;
     fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
@@ -518,8 +484,6 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     a.rows = rows; a.md_utt = sbuf.md_utt; a.md_row = sbuf.md_row; a.dense = nullptr;
     a.out = out;
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
-    set_migration(h, a, lp, d.Tp, nullptr);
-    a.mig_state = fptr(w.mig_state); a.mig_flags = reinterpret_cast<unsigned*>(base + w.mig_flags);
     a.num_rows = num_rows; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.act = h->cfg.sb_act;
     launch_lstm(h->lw, a, s);
@@ -539,18 +503,15 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
-    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus, h->allow_migration);
+    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
-    const size_t mig_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    if (ensure_workspace(h, mig_off + migration_bytes(h, lp))) return 4;
+    if (ensure_workspace(h, (size_t)num_slots * sizeof(RowDesc))) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
-    if (lp.mig_rows > 0) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + mig_off, 0, migration_bytes(h, lp), s));
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, lp.mig_rows, lp.mig_w);
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
-    set_migration(h, a, lp, steps, h->ws + mig_off);
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
     launch_lstm(h->lw, a, s);
     FSNP_HIP_CHECK(hipGetLastError());
@@ -614,46 +575,22 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
     FSNP_HIP_CHECK(hipSetDevice(h->device));
-    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus, h->allow_migration);
+    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
-    const size_t mig_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    const size_t stamp_off = mig_off + migration_bytes(h, lp);
-    if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 768) * 8)) return 4;
-    if (lp.mig_rows > 0) FSNP_HIP_CHECK(hipMemset(h->ws + mig_off, 0, migration_bytes(h, lp)));
+    const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
+    if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8)) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
     h->have_last = false;
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, 0, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, lp.mig_rows, lp.mig_w);
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
-    set_migration(h, a, lp, steps, h->ws + mig_off);
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.F = 1;
     a.act = h->cfg.sb_act; a.prof = dprof;
     launch_lstm(h->lw, a, 0);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     FSNP_HIP_CHECK(hipMemcpy(host_stamps, dprof, (size_t)num_stamps * 8, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int fsnp_check_errors(fsnp_handle* h) {
-    if (!h) { set_error("null handle"); return 1; }
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
-    FSNP_HIP_CHECK(hipDeviceSynchronize());
-    unsigned e = 0;
-    FSNP_HIP_CHECK(hipMemcpy(&e, h->d_err, 4, hipMemcpyDeviceToHost));
-    if (e != 0) {
-        (void)hipMemset(h->d_err, 0, 4);
-        set_error("LSTM row-migration hand-off timed out (a workgroup of the one-round launch was not resident); "
-                  "results of that forward are invalid - set FSNP_LSTM_MIGRATION=0");
-        return 5;
-    }
-    return 0;
-}
-
-int fsnp_debug_set_lstm_migration(fsnp_handle* h, int32_t enable) {
-    if (!h) { set_error("null handle"); return 1; }
-    h->allow_migration = enable != 0;
     return 0;
 }
 

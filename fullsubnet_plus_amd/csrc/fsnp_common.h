@@ -133,15 +133,10 @@ struct LstmArgs {
     int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
     int act;               // FSNP_ACT_* on the Linear output
     unsigned long long* prof;  // optional [Tp][8] s_memtime stamps of workgroup 0 (debug)
-    // row migration (mig_rows > 0): leftover sequence j travels along tiles [j*mig_w, (j+1)*mig_w), mig_len steps each
-    int mig_rows, mig_w, mig_len;
-    float* mig_state;          // [mig_rows][4][H]  h0, h1, c0, c1 of the travelling sequences
-    unsigned* mig_flags;       // [num_tiles] 1 = this tile has published its sequence (zeroed per launch)
-    unsigned* mig_error;       // set to 1 if a hand-off wait timed out
 };
 
-struct LstmPlan { int num_tiles, ex, rows_per_slot_tile, mig_rows, mig_w; };
-LstmPlan plan_lstm_tiles(int num_rows, int num_cus, bool allow_migration);
+struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
+LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack

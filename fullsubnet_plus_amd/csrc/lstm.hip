@@ -163,16 +163,10 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
         }
 }
 
-// MIG (row migration, EX == 1 only): the tile's VALU row is live only for steps [ex_t0, ex_t1); the leftover
-// sequence it carries is handed from tile to tile (state = h0, h1, c0, c1 through global memory, agent-scope
-// release/acquire + one flag per tile), so each of the L leftover sequences of a one-round launch is served by
-// W = tiles / L consecutive tiles for ceil(T'/W) steps each and every tile pays the VALU-row cost for 1/W of
-// the steps only.  All tiles must be co-resident (grid <= CUs; one workgroup per CU by LDS size); spins are bounded.
-template <int HID, int KX, int OUT, int EX, bool PROF, int NW, bool MIG>
+template <int HID, int KX, int OUT, int EX, bool PROF, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
-    static_assert(!MIG || EX == 1, "row migration carries exactly one VALU row per tile");
     static_assert(EX >= 0 && EX <= 4, "at most 4 VALU rows per tile (one FC wave per extra row)");
     static_assert(NW % 4 == 0 && NW >= 4, "whole waves per SIMD");
     constexpr int NTHR = 64 * NW;
@@ -212,20 +206,6 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         Bs[i] = w.bias[layer * 4 * HID + (n / ST) * HID + wv * UW + (n % ST) * 32 + col];
     }
     __syncthreads();
-
-    // ---- live window of the VALU row (whole sequence unless it migrates)
-    int ex_t0 = 0, ex_t1 = Tp, mig_chain = -1;
-    if constexpr (MIG) {
-        ex_t0 = ex_t1 = Tp;
-        if ((int)blockIdx.x < a.mig_rows * a.mig_w) {
-            const int seg = blockIdx.x % a.mig_w;
-            if (seg * a.mig_len < Tp) {
-                mig_chain = blockIdx.x / a.mig_w;
-                ex_t0 = seg * a.mig_len;
-                ex_t1 = min(ex_t0 + a.mig_len, Tp);
-            }
-        }
-    }
 
     // ---- gather plan.  main rows: row = tid & 31, features j = (tid >> 5) + 8 i.
     //      extra rows: thread tid < EX*KX owns (e = tid / KX, j = tid % KX).
@@ -279,7 +259,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
-        if (EX > 0 && tid < EX * KX && ex_t0 == 0) {
+        if (EX > 0 && tid < EX * KX) {
             const NormMD mx = mdx_row ? mdx_row[0] : mdx;
             XEf[xdstx] = goffx >= 0 ? (gbase[goffx] - mx.m) / mx.d : 0.0f;
         }
@@ -307,14 +287,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) breg[n] = wload<NT>(ws, 0, n);   // group 0
     int gnext = 1;
-    auto run_groups = [&](f32x16 (&acc_)[NT], float (&accx_)[EXA][NT], const float4* A_, const float4* AE_, int ng,
-                          bool live) {
-        if constexpr (MIG) {
-            if (live) mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, ws, gnext, KGT);
-            else mfma_groups<NT, 0>(acc_, accx_, breg, A_, AE_, ng, ws, gnext, KGT);
-        } else {
-            mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, ws, gnext, KGT);
-        }
+    auto run_groups = [&](f32x16 (&acc_)[NT], float (&accx_)[EXA][NT], const float4* A_, const float4* AE_, int ng) {
+        mfma_groups<NT, EX>(acc_, accx_, breg, A_, AE_, ng, ws, gnext, KGT);
     };
 
     // FC lane mapping (rows 0..31): 8 rows x 2 outputs x 4 k-parts per wave
@@ -344,7 +318,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         if (fc_kp == 0 && fc_rd.valid && t_of_h >= a.LA)
             a.out[(size_t)fc_rd.out_off + (size_t)fc_o * a.out_stride_o + (t_of_h - a.LA)] = apply_act(sum + w.bfc[fc_o], a.act);
       }
-        if (EX > 0 && wave < EX && t_of_h >= ex_t0 && t_of_h < ex_t1) {
+        if (EX > 0 && wave < EX) {
             const int o = lane >> 5;
             const float* he = reinterpret_cast<const float*>(HE1s);
             float sx = 0.0f;
@@ -380,48 +354,15 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 
     for (int t = 0; t < Tp; ++t) {
         FSNP_STAMP(0);
-        const bool live = EX > 0 && t >= ex_t0 && t < ex_t1;          // is the VALU row computed this step?
-        if constexpr (MIG) {
-            if (t == ex_t0 && t > 0 && mig_chain >= 0) {
-                // ---- take the sequence over from the previous tile of the chain (MI355X_MICROARCH.md hand-off recipe:
-                //      one relaxed poller, ONE agent acquire, barrier, then plain vector loads)
-                if (tid == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(a.mig_flags + blockIdx.x - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                        __builtin_amdgcn_s_sleep(16);
-                        if (++spins > (1u << 22)) {               // ~ seconds: give up, flag the launch as failed
-                            __hip_atomic_store(a.mig_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-                const float* st = a.mig_state + (size_t)mig_chain * 4 * HID;
-                float* he0 = reinterpret_cast<float*>(HE0s);
-                float* he1 = reinterpret_cast<float*>(HE1s);
-                for (int k = tid; k < HID; k += NTHR) {
-                    he0[e_frag_index<EXA>(0, k)] = st[k];
-                    he1[e_frag_index<EXA>(0, k)] = st[HID + k];
-                }
-#pragma unroll
-                for (int s = 0; s < ST; ++s) {
-                    cx0[0][s] = st[2 * HID + wave * UW + s * 32 + (lane & 31)];
-                    cx1[0][s] = st[3 * HID + wave * UW + s * 32 + (lane & 31)];
-                }
-                __syncthreads();
-            }
-        }
         // prefetch x(t+1) (consumed after the layer-0 MFMA phase)
         float xr[NG], xrx = 0.0f;
         NormMD mdn = md, mdxn = mdx;
         const bool have_next = (t + 1 < Tp);
-        const bool have_next_x = EX > 0 && t + 1 >= ex_t0 && t + 1 < ex_t1;
         if (have_next) {
             if (md_row) mdn = md_row[t + 1];
 #pragma unroll
             for (int i = 0; i < NG; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
-            if (have_next_x && tid < EX * KX) {
+            if (EX > 0 && tid < EX * KX) {
                 if (mdx_row) mdxn = mdx_row[t + 1];
                 xrx = goffx >= 0 ? gbase[goffx + (t + 1) * gstep] : 0.0f;
             }
@@ -437,17 +378,17 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
-        run_groups(acc, accx, Xs + lane, AEx, KG0, live);
+        run_groups(acc, accx, Xs + lane, AEx, KG0);
         FSNP_STAMP(1);
         __syncthreads();
         FSNP_STAMP(2);
         lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
-        if (EX > 0 && live) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
+        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < NG; ++i)
                 if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
-            if (have_next_x && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
+            if (EX > 0 && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
         }
         if (t > 0) fc_store(t - 1);
         FSNP_STAMP(3);
@@ -461,40 +402,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
-        run_groups(acc, accx, H1s + lane, AEh1, KGH, live);
-        run_groups(acc, accx, H0s + lane, AEh0, KGH, live);
+        run_groups(acc, accx, H1s + lane, AEh1, KGH);
+        run_groups(acc, accx, H0s + lane, AEh0, KGH);
         FSNP_STAMP(5);
         __syncthreads();
         FSNP_STAMP(6);
         lstm_cell<ST, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
-        if (EX > 0 && live) lstm_cell_extra<ST, UW, EX, NT>(accx, cx1, bias_l1, reinterpret_cast<float*>(HE1s), wave, lane);
-        if constexpr (MIG) {
-            if (t == ex_t1 - 1 && ex_t1 < Tp && mig_chain >= 0) {
-                // ---- hand the sequence to the next tile: plain stores, every wave drains, ONE agent release, flag
-                __syncthreads();
-                float* st = a.mig_state + (size_t)mig_chain * 4 * HID;
-                const float* he0 = reinterpret_cast<const float*>(HE0s);
-                const float* he1 = reinterpret_cast<const float*>(HE1s);
-                for (int k = tid; k < HID; k += NTHR) {
-                    st[k] = he0[e_frag_index<EXA>(0, k)];
-                    st[HID + k] = he1[e_frag_index<EXA>(0, k)];
-                }
-                if (lane < 32) {
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) {
-                        st[2 * HID + wave * UW + s * 32 + lane] = cx0[0][s];
-                        st[3 * HID + wave * UW + s * 32 + lane] = cx1[0][s];
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(a.mig_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
+        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx1, bias_l1, reinterpret_cast<float*>(HE1s), wave, lane);
         FSNP_STAMP(7);
     }
 #undef FSNP_STAMP
@@ -536,7 +450,7 @@ void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const 
                     }
 }
 
-template <int EX, int NW, bool MIG>
+template <int EX, int NW>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
@@ -545,13 +459,13 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
     LstmWeights wv = w;
     wv.wpack = NW == 12 ? w.wpack12 : w.wpack;
     if (a.prof != nullptr) {
-        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW, MIG>;
+        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
         return;
     }
     static bool attr_set = false;
-    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW, MIG>;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -562,19 +476,15 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
 template <int NW>
 static void launch_lstm_nw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     switch (a.ex) {
-        case 0: launch_lstm_ex<0, NW, false>(w, a, s); break;
-        case 1: launch_lstm_ex<1, NW, false>(w, a, s); break;
-        case 2: launch_lstm_ex<2, NW, false>(w, a, s); break;
-        default: launch_lstm_ex<4, NW, false>(w, a, s); break;
+        case 0: launch_lstm_ex<0, NW>(w, a, s); break;
+        case 1: launch_lstm_ex<1, NW>(w, a, s); break;
+        case 2: launch_lstm_ex<2, NW>(w, a, s); break;
+        default: launch_lstm_ex<4, NW>(w, a, s); break;
     }
 }
 
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (a.num_tiles <= 0) return;
-    if (a.mig_rows > 0) {                       // row migration: EX = 1, 12 waves
-        launch_lstm_ex<1, 12, true>(w, a, s);
-        return;
-    }
     // measured (profiles/r01_lstm_phase_ab.md): with VALU rows the 12-wave shape is 10 % faster, without them
     // both shapes tie and the 4-wave one needs no spills
     const int waves = w.waves != 0 ? w.waves : (a.ex > 0 ? 12 : 4);
@@ -583,20 +493,12 @@ void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
 }
 
 // Tile plan: a tile = 32 MFMA rows + up to ex VALU rows.  All tiles cost the same time whatever their
-// row count, so the makespan is rounds = ceil(tiles / CUs).
-//  * rows <= 32 CUs                : packed 32-row tiles, one round, no VALU rows;
-//  * one round + L <= CUs leftover : ROW MIGRATION - every tile is full (32 rows) and the L leftover sequences
-//                                    travel along chains of W = CUs / L tiles (see the kernel's MIG comment);
-//  * otherwise                     : smallest ex in {0,1,2,4} that minimises the number of rounds, rows spread
-//                                    evenly over rounds * CUs tiles.
-LstmPlan plan_lstm_tiles(int num_rows, int num_cus, bool allow_migration) {
+// row count, so the makespan is rounds = ceil(tiles / CUs); pick the smallest ex in {0,1,2,4} that
+// minimises rounds, then spread the rows evenly over rounds * CUs tiles.
+LstmPlan plan_lstm_tiles(int num_rows, int num_cus) {
     LstmPlan p{};
     if (num_rows <= 32 * num_cus) {
         p.ex = 0; p.num_tiles = cdiv(num_rows, 32);
-    } else if (allow_migration && num_rows - 32 * num_cus <= num_cus && num_cus / (num_rows - 32 * num_cus) >= 2) {
-        p.ex = 1; p.num_tiles = num_cus;
-        p.mig_rows = num_rows - 32 * num_cus;
-        p.mig_w = num_cus / p.mig_rows;
     } else {
         const int cand[4] = {0, 1, 2, 4};
         int best_rounds = 1 << 30;

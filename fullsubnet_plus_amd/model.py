@@ -323,18 +323,6 @@ class FullSubNet_Plus(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_lstm_waves(self._handle, int(waves)), "fsnp_debug_set_lstm_waves")
 
-    def debug_set_lstm_migration(self, enable, device="cuda"):
-        """Tuning hook: allow / forbid the row-migration tile plan of the fused LSTM kernel."""
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
-        _lib.check(lib.fsnp_debug_set_lstm_migration(self._handle, int(bool(enable))), "fsnp_debug_set_lstm_migration")
-
-    def check_errors(self):
-        """Synchronise and raise if an earlier forward failed on the device (see fsnp_check_errors)."""
-        _lib.check(_lib.load().fsnp_check_errors(self._handle), "fsnp_check_errors")
-
     def set_timing(self, enable=True):
         _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")
 

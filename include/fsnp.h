@@ -132,14 +132,6 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
-/* Synchronises the device and reports asynchronous kernel-side failures of earlier forwards (today: a
- * timed-out row-migration hand-off in the LSTM kernel).  0 = none. */
-int fsnp_check_errors(fsnp_handle* h);
-
-/* Tuning hook: allow (default) / forbid the row-migration tile plan of the fused LSTM kernel (also the
- * environment variable FSNP_LSTM_MIGRATION=0 at fsnp_create time). */
-int fsnp_debug_set_lstm_migration(fsnp_handle* h, int32_t enable);
-
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
  * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the
  * environment variable FSNP_LSTM_WAVES at fsnp_create time. */

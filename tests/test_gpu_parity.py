@@ -88,26 +88,6 @@ def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
     assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
 
 
-@pytest.mark.parametrize("n,cus,steps", [(257, 8, 20), (258, 8, 21), (260, 8, 7), (130, 4, 33), (257, 8, 3)])
-def test_lstm2_fc_row_migration(n, cus, steps):
-    """One-round launches with L leftover sequences travelling along chains of cus/L tiles (agent-scope
-    hand-offs between workgroups), against the oracle; migration off must give the same numbers."""
-    sd = make_state_dict(8, "harsh")
-    m = _model(DEFAULT_MODEL_ARGS, sd)
-    m.debug_set_num_cus(cus)
-    rng = np.random.Generator(np.random.PCG64(31 + n))
-    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
-    want = fsnp_torch.lstm2_fc(x, sd).numpy()
-    got = m.lstm2_fc(x.cuda()).cpu().numpy()
-    m.check_errors()
-    per_row = np.abs(got - want).max(axis=(1, 2)) / np.abs(want).max()
-    _record(f"lstm_migration_{n}_cus{cus}_T{steps}", rel=float(per_row.max()), worst_rows=np.argsort(-per_row)[:4].tolist())
-    assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
-    m.debug_set_lstm_migration(False)
-    got2 = m.lstm2_fc(x.cuda()).cpu().numpy()
-    assert rel_err(got2, want) < 2e-5
-
-
 @pytest.mark.parametrize("waves", [4, 12])
 @pytest.mark.parametrize("n,cus,steps", [(70, 256, 11), (66, 2, 8), (67, 2, 8), (257, 7, 6)])
 def test_lstm2_fc_wave_variants(waves, n, cus, steps):
@@ -116,7 +96,6 @@ def test_lstm2_fc_wave_variants(waves, n, cus, steps):
     sd = make_state_dict(6, "default")
     m = _model(DEFAULT_MODEL_ARGS, sd)
     m.debug_set_num_cus(cus)
-    m.debug_set_lstm_migration(False)
     m.debug_set_lstm_waves(waves)
     rng = np.random.Generator(np.random.PCG64(7 + n))
     x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
@@ -133,13 +112,10 @@ def test_forward_with_valu_rows(name):
     g = Golden(name)
     m = _model(g.args, g.state_dict(), "parity")
     m.debug_set_num_cus(8 if g.meta["inp"]["B"] == 1 else 16)
-    for mig in (True, False):                  # row-migration plan, then static VALU rows
-        m.debug_set_lstm_migration(mig)
-        out = m(*_cuda(g.inputs())).cpu().numpy()
-        m.check_errors()
-        err = rel_err(out, g.arrays["out"])
-        _record(f"forward_valu_rows_{name}_mig{int(mig)}", rel_vs_ref32=err)
-        assert err < TOL, (mig, err)
+    out = m(*_cuda(g.inputs())).cpu().numpy()
+    err = rel_err(out, g.arrays["out"])
+    _record(f"forward_valu_rows_{name}", rel_vs_ref32=err)
+    assert err < TOL, err
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if "stages" in n or "t30" in n])
