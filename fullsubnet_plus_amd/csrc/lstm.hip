@@ -89,29 +89,49 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
         float4 aen[EX > 0 ? EX : 1];
 #pragma unroll
         for (int e = 0; e < EX; ++e) aen[e] = AE[gn * 2 * EX + e];
+        if constexpr (EX == 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
-            // VALU rows: issued behind the tile's 4 back-to-back MFMAs (never between two MFMAs of one
-            // accumulator chain - hipcc's scheduler puts them there unless fenced, +7 % kernel time), they
-            // run on the idle VALU pipe while the matrix pipe drains.
-            if (EX > 0) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < EX; ++e) {
-                float v = accx[e][n];
-                v = fmaf(ae[e].x, b[n].x, v);
-                v = fmaf(ae[e].y, b[n].y, v);
-                v = fmaf(ae[e].z, b[n].z, v);
-                accx[e][n] = fmaf(ae[e].w, b[n].w, v);
+            for (int n = 0; n < NT; ++n) {
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+                // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
+                // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
+                // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
+                b[n] = wload<NT>(ws, gnext, n);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // refill the just-consumed registers with the same tile of the NEXT k-group, and pin the
-            // (4 x MFMA, refill) order per tile: left alone hipcc hoists all 48 MFMAs above the refills,
-            // needs 96 B registers, parks the refills in AGPRs and drains vmcnt(0) every group.
-            b[n] = wload<NT>(ws, gnext, n);
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // With VALU rows the group is processed in two halves: MFMA chains of the half, then ALL its
+            // v_fma in one batch (a batched v_fma costs ~5 matrix-pipe cycles, an isolated one ~13 -
+            // tools/ubench/mfma_issue.hip), then the half's refills (half a group = >1500 cycles ahead of use).
+            constexpr int HALF = NT / 2;
+#pragma unroll
+            for (int hb = 0; hb < NT; hb += HALF) {
+#pragma unroll
+                for (int n = hb; n < hb + HALF; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = hb; n < hb + HALF; ++n)
+#pragma unroll
+                    for (int e = 0; e < EX; ++e) {
+                        float v = accx[e][n];
+                        v = fmaf(ae[e].x, b[n].x, v);
+                        v = fmaf(ae[e].y, b[n].y, v);
+                        v = fmaf(ae[e].z, b[n].z, v);
+                        accx[e][n] = fmaf(ae[e].w, b[n].w, v);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = hb; n < hb + HALF; ++n) b[n] = wload<NT>(ws, gnext, n);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
         a = an;
