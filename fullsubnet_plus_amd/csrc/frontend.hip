@@ -150,35 +150,42 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-// one workgroup per (branch, utt)
+// one workgroup per (branch, utt).  The (kmax-1) first and last normalised frames are staged in LDS so that every
+// thread's prefix / suffix sums come from shared memory instead of 2*(kmax-1) dependent global round trips.
 __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     extern __shared__ float sh[];
-    float* sq = sh;            // [F]  squeeze
-    float* hid = sh + g.FP;    // [F/2]
+    const int F = g.F, Tp = g.Tp, Fr = F / 2, FP = g.FP;
+    constexpr int MAXK = 16;
+    float* sq = sh;                    // [FP]  squeeze
+    float* hid = sh + FP;              // [FP]  (F/2 used)
+    float* edge = sh + 2 * FP;         // [2][MAXK][FP] normalised first / last frames
     const int branch = blockIdx.y, b = blockIdx.x;
     const long ub = (long)branch * g.B + b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int F = g.F, Tp = g.Tp, Fr = F / 2;
-    constexpr int MAXK = 16;
+    const int kmax = max(max(g.w.ksize[0], g.w.ksize[1]), g.w.ksize[2]);
 
+    for (int i = tid; i < 2 * (kmax - 1) * F; i += 256) {
+        const int side = i / ((kmax - 1) * F), r = (i / F) % (kmax - 1), f = i % F;
+        const int t = side == 0 ? r : Tp - 1 - r;                    // r-th frame from the start / from the end
+        const NormMD m = g.md[ub * Tp + t];
+        edge[(side * MAXK + r) * FP + f] = (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d;
+    }
+    __syncthreads();
     for (int f = tid; f < F; f += 256) {
-        // prefix[j] = sum of the first j normalised frames, suffix[j] = sum of the last j
-        double pre[MAXK], suf[MAXK];
-        pre[0] = 0.0; suf[0] = 0.0;
-        const int kmax = max(max(g.w.ksize[0], g.w.ksize[1]), g.w.ksize[2]);
-        for (int j = 1; j < kmax; ++j) {
-            const NormMD a = g.md[ub * Tp + (j - 1)];
-            const NormMD z = g.md[ub * Tp + (Tp - j)];
-            pre[j] = pre[j - 1] + (double)((g.raw[(ub * Tp + (j - 1)) * g.FP + f] - a.m) / a.d);
-            suf[j] = suf[j - 1] + (double)((g.raw[(ub * Tp + (Tp - j)) * g.FP + f] - z.m) / z.d);
-        }
-        const double S = g.fsum[ub * g.FP + f];
+        const double S = g.fsum[ub * FP + f];
+        const float* first = edge + f;                       // first[r * FP] = r-th normalised frame
+        const float* last = edge + (long)MAXK * FP + f;      // last[r * FP]  = r-th frame from the end
         float squeeze = g.w.cat_b[branch][0];
         for (int c = 0; c < 3; ++c) {
             const int K = g.w.ksize[c];
             const float* wk = g.w.conv_w[branch][c] + (long)f * K;
-            double acc = 0.0;
-            for (int j = 0; j < K; ++j) acc += (double)wk[j] * (S - pre[j] - suf[K - 1 - j]);
+            // tap j sees frames [j, j + T' - K]: everything but the first j and the last K-1-j frames
+            double pj = 0.0, sj = 0.0, acc = 0.0;
+            for (int r = 0; r < K - 1; ++r) sj += (double)last[r * FP];
+            for (int j = 0; j < K; ++j) {
+                acc += (double)wk[j] * (S - pj - sj);
+                if (j + 1 < K) { pj += (double)first[j * FP]; sj -= (double)last[(K - 2 - j) * FP]; }
+            }
             float feat = (float)(acc / (double)(Tp - K + 1)) + g.w.conv_b[branch][c][f];
             feat = fmaxf(feat, 0.f);
             squeeze += g.w.cat_w[branch][c] * feat;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         float acc = 0.f;
         for (int f = lane; f < Fr; f += 64) acc += wr[f] * hid[f];
         acc = wave_sum_f(acc);
-        if (lane == 0) g.gate[ub * g.FP + o] = 1.0f / (1.0f + expf(-(acc + g.w.fc2_b[branch][o])));
+        if (lane == 0) g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-(acc + g.w.fc2_b[branch][o])));
     }
 }
 
@@ -238,7 +245,7 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
     GateArgs g;
     g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;
     g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
-    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(256), (size_t)(d.FP + d.F / 2 + 4) * sizeof(float), s, g);
+    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(256), (size_t)(2 + 2 * 16) * d.FP * sizeof(float), s, g);
     const long rows = 3L * d.B * d.Tp;
     const long total = rows * d.FP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -330,7 +330,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
         o_fc2w[a] = put(p + ".fc2.weight"); o_fc2b[a] = put(p + ".fc2.bias");
     }
     // ---- TCN: zero-padded row-major [N pad 64][K pad 16] GEMM operands, [branch][block] major
-    const int N1P = (int)align_up(CH, 64), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, 64), K2P = (int)align_up(CH, 16);
+    const int BN1 = tcn_pick_bn(CH), BN2 = tcn_pick_bn(F);
+    const int N1P = (int)align_up(CH, BN1), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, BN2), K2P = (int)align_up(CH, 16);
     const size_t o_w1 = alloc((size_t)3 * NB * N1P * K1P), o_b1 = alloc((size_t)3 * NB * N1P), o_a1 = alloc(3 * NB + 1);
     const size_t o_g1w = alloc((size_t)3 * NB * CH), o_g1b = alloc((size_t)3 * NB * CH);
     const size_t o_dw = alloc((size_t)3 * NB * 3 * CH), o_db = alloc((size_t)3 * NB * CH), o_a2 = alloc(3 * NB + 1);
@@ -402,7 +403,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w1 = d + o_w1; h->tw.b1 = d + o_b1; h->tw.a1 = d + o_a1; h->tw.g1w = d + o_g1w; h->tw.g1b = d + o_g1b;
     h->tw.dw = d + o_dw; h->tw.db = d + o_db; h->tw.a2 = d + o_a2; h->tw.g2w = d + o_g2w; h->tw.g2b = d + o_g2b;
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
-    h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
+    h->tw.BN1 = BN1; h->tw.BN2 = BN2; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;

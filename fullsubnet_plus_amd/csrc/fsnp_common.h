@@ -72,6 +72,7 @@ struct TcnWeights {
     const float* wf;     // [3][N2P][K1P]      fc_output_layer
     const float* bf;     // [3][N2P]
     int NB, N1P, K1P, N2P, K2P;
+    int BN1, BN2;        // column-tile widths of the N = CH and N = F GEMMs (N1P % BN1 == 0, N2P % BN2 == 0)
     int dilation[16];
 };
 
@@ -86,6 +87,7 @@ struct TcnBuffers {
 };
 
 void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s);
+int tcn_pick_bn(int n);   // 64, 96 or 128
 
 // ---------------------------------------------------------------------------------------------
 // subband.hip : statistics of the (never materialised) sub-band input tensor

@@ -37,7 +37,7 @@ struct GemmArgs {
     float gn_eps;
 };
 
-constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int BM = 128, BK = 16;   // BN (32-column accumulator tiles per wave) is a template parameter
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -45,15 +45,19 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int PRO, int EPI>
+// One workgroup = 4 waves, wave w owns rows [32 w, 32 w + 32) of the 128-row tile and all BN columns
+// (BN / 32 accumulators of v_mfma_f32_32x32x2_f32).  BN = 96 makes the N = 257 GEMMs 3 column tiles (288, 11 %
+// padding) instead of 5 x 64 (25 %).
+template <int PRO, int EPI, int BN>
 __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
+    constexpr int NTILE = BN / 32;
+    constexpr int BLD = (BN * 4 + 255) / 256;   // float4 B loads per thread per k-tile
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * 4 + 2 * 2 * BN * 4 + 16];
     float* As = smem;                       // [kg 2][kh 2][BM][4]
     float* Bs = smem + 2 * 2 * BM * 4;      // [kg 2][kh 2][BN][4]
     double* red = reinterpret_cast<double*>(smem + 2 * 2 * BM * 4 + 2 * 2 * BN * 4);  // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int branch = blockIdx.z;
     const int tiles_per_utt = cdiv(g.Tp, BM);
     const int utt = blockIdx.y / tiles_per_utt;
@@ -76,11 +80,10 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         beta = g.beta + branch * g.gb_bs;
     }
 
-    // staging assignment: A rows ar0, ar0+64 ; k quad kq ; B column bc
+    // staging assignment: A rows ar0, ar0+64 ; k quad kq ; B columns (tid + 256 i) >> 2
     const int kq = (tid & 3) * 4;
     const int ar0 = tid >> 2;
-    const int bc = tid >> 2;
-    float4 areg[2], breg;
+    float4 areg[2], breg[BLD];
 
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq;
@@ -109,31 +112,31 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
             }
             areg[i] = v;
         }
-        breg = *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k);   // padded: always in range
+#pragma unroll
+        for (int i = 0; i < BLD; ++i) {
+            const int bc = (tid + 256 * i) >> 2;
+            breg[i] = bc < BN ? *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // a float4 of 4 consecutive k = (kh0,p) (kh1,p) (kh0,p+1) (kh1,p+1) with p = (kq>>1)&3  ->  two 8-byte LDS stores
+    auto store_frag = [&](float* base, int ld, int row, const float4& v) {
+        const int kg = kq >> 3, p = (kq >> 1) & 3;
+        *reinterpret_cast<float2*>(base + ((kg * 2 + 0) * ld + row) * 4 + p) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(base + ((kg * 2 + 1) * ld + row) * 4 + p) = make_float2(v.y, v.w);
     };
     auto store_tiles = [&]() {
-        // element k = kq+e  ->  kg = k>>3, p = (k>>1)&3, kh = k&1
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = ar0 + 64 * i;
-            const float e[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+        for (int i = 0; i < 2; ++i) store_frag(As, BM, ar0 + 64 * i, areg[i]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = kq + q;
-                As[(((k >> 3) * 2 + (k & 1)) * BM + row) * 4 + ((k >> 1) & 3)] = e[q];
-            }
-        }
-        const float e[4] = {breg.x, breg.y, breg.z, breg.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = kq + q;
-            Bs[(((k >> 3) * 2 + (k & 1)) * BN + bc) * 4 + ((k >> 1) & 3)] = e[q];
+        for (int i = 0; i < BLD; ++i) {
+            const int bc = (tid + 256 * i) >> 2;
+            if (bc < BN) store_frag(Bs, BN, bc, breg[i]);
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[NTILE];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NTILE; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -148,33 +151,33 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         const float4* Bs4 = reinterpret_cast<const float4*>(Bs);
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
-            const float4 b4 = Bs4[(kg * 2 + (lane >> 5)) * BN + wn * 32 + (lane & 31)];
+            const float4 a4 = As4[(kg * 2 + (lane >> 5)) * BM + wave * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 a4 = As4[(kg * 2 + (lane >> 5)) * BM + wm * 64 + i * 32 + (lane & 31)];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[i], 0, 0, 0);
+            for (int j = 0; j < NTILE; ++j) {
+                const float4 b4 = Bs4[(kg * 2 + (lane >> 5)) * BN + j * 32 + (lane & 31)];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
             }
         }
     }
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const int col = n0 + wn * 32 + (lane & 31);
-    const bool col_ok = col < g.N;
-    const float bias = g.bias[branch * g.bias_bs + col];
-    float* __restrict__ C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
+    float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
     double s = 0.0, q = 0.0;
     float slope = 0.f;
     if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NTILE; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool col_ok = col < g.N;
+        const float bias = g.bias[branch * g.bias_bs + col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int t = t0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (t < g.Tp && col_ok) {
-                float v = acc[i][r] + bias;
+                float v = acc[j][r] + bias;
                 if constexpr (EPI == EPI_PRELU_STATS) {
                     v = v >= 0.f ? v : slope * v;
                     s += (double)v;
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
                 C[(long)t * g.ldc + col] = v;
             }
         }
+    }
     if constexpr (EPI == EPI_PRELU_STATS) {
         s = wave_sum(s);
         q = wave_sum(q);
@@ -201,6 +205,25 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
             atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
         }
     }
+}
+
+template <int PRO, int EPI>
+static void launch_gemm(const GemmArgs& g, int bn, int npad, int row_tiles, hipStream_t s) {
+    const dim3 grid(npad / bn, row_tiles, 3);
+    if (bn == 128) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 128>), grid, dim3(256), 0, s, g);
+    else if (bn == 96) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 96>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 64>), grid, dim3(256), 0, s, g);
+}
+
+// column-tile width that wastes the fewest padded columns (ties -> the wider tile)
+int tcn_pick_bn(int n) {
+    int best = 64, best_pad = (n + 63) / 64 * 64;
+    const int cand[2] = {96, 128};
+    for (int c : cand) {
+        const int pad = (n + c - 1) / c * c;
+        if (pad <= best_pad) { best = c; best_pad = pad; }
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -287,7 +310,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gn_out = gn_slot(blk, 0);
             g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
             g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
-            hipLaunchKernelGGL((tcn_gemm_kernel<PRO_NONE, EPI_PRELU_STATS>), dim3(w.N1P / BN, row_tiles, 3), dim3(256), 0, s, g);
+            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, w.BN1, w.N1P, row_tiles, s);
         }
         {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
             DwArgs g{};
@@ -312,7 +335,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gamma = w.g2w + (long)blk * d.CH; g.beta = w.g2b + (long)blk * d.CH; g.gb_bs = (long)w.NB * d.CH;
             g.K = d.CH; g.N = d.F; g.Tp = d.Tp; g.B = d.B;
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            hipLaunchKernelGGL((tcn_gemm_kernel<PRO_GN, EPI_RESIDUAL>), dim3(w.N2P / BN, row_tiles, 3), dim3(256), 0, s, g);
+            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, w.BN2, w.N2P, row_tiles, s);
         }
         if (blk == 0 && buf.dbg_tcn0)
             (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -324,7 +347,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
         g.bias = w.bf; g.bias_bs = w.N2P;
         g.C = buf.fb; g.c_bs = x_bs; g.ldc = d.FP;
         g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
-        hipLaunchKernelGGL((tcn_gemm_kernel<PRO_RELU, EPI_ACT>), dim3(w.N2P / BN, row_tiles, 3), dim3(256), 0, s, g);
+        launch_gemm<PRO_RELU, EPI_ACT>(g, w.BN2, w.N2P, row_tiles, s);
     }
 }
 

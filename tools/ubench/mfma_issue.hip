@@ -224,7 +224,8 @@ void kern(const float* __restrict__ gin, float* __restrict__ gout, unsigned long
 #pragma unroll
             for (int n = 0; n < 12; ++n) {
                 MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); MF(acc[n], a, b); SB();
-                pk0 = __builtin_elementwise_fma(pa, pb, pk0); pk0 = __builtin_elementwise_fma(pa, pb, pk0); SB();
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pk0) : "v"(pa), "v"(pb));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pk0) : "v"(pa), "v"(pb)); SB();
             }
         } else if constexpr (P == 29) {  // A + 4 x v_mfma_f32_4x4x1_16b_f32 after each chain (4 extra rows x 64 (k,col))
 #pragma unroll
@@ -256,6 +257,26 @@ void kern(const float* __restrict__ gin, float* __restrict__ gout, unsigned long
 #pragma unroll
             for (int n = 0; n < 48; ++n) vx[n & 3] = fmaf(a, b, vx[n & 3]);
             SB();
+        } else if constexpr (P == 33) {  // 6 chains, then 12 v_pk_fma in one batch, twice per iteration (= 48 fma)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int n = 0; n < 6; ++n) { MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); }
+                SB();
+#pragma unroll
+                for (int n = 0; n < 12; ++n) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pk0) : "v"(pa), "v"(pb));
+                SB();
+            }
+        } else if constexpr (P == 34) {  // 6 chains, then 24 v_fmac in one batch, twice per iteration
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int n = 0; n < 6; ++n) { MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); MF(acc[hb * 6 + n], a, b); }
+                SB();
+#pragma unroll
+                for (int n = 0; n < 24; ++n) vx[n & 3] = fmaf(a, b, vx[n & 3]);
+                SB();
+            }
         } else if constexpr (P == 15) {  // Q: 12 accumulators x chains of 4, with 1 s_nop after each chain
 #pragma unroll
             for (int n = 0; n < 12; ++n) {
@@ -321,6 +342,8 @@ int main() {
         run<30>("P3 A + 4 x mfma_4x4x1 (4 acc) after each chain", 48, 64, din, dout, dt, blocks);
         run<31>("P4 A + 1 x mfma_4x4x1 after each chain", 48, 64, din, dout, dt, blocks);
         run<32>("P5 A + 48 v_fmac in one batch per 48 mfma", 48, 64, din, dout, dt, blocks);
+        run<33>("P6 half-group: 6 chains + 12 v_pk_fma batch (x2)", 48, 64, din, dout, dt, blocks);
+        run<34>("P7 half-group: 6 chains + 24 v_fmac batch (x2)", 48, 64, din, dout, dt, blocks);
         run<13>("N  A + global_load + 4 indep v_fmac after each chain", 48, 64, din, dout, dt, blocks);
         run<10>("K  16x16x4: 24 acc x chain4", 96, 32, din, dout, dt, blocks);
         run<11>("L  16x16x4: 2 interleaved chains", 96, 32, din, dout, dt, blocks);
