@@ -193,22 +193,22 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         sq[f] = squeeze;
     }
     __syncthreads();
-    // fc1 + ReLU: one wave per output, lanes over F
-    for (int o = wave; o < Fr; o += 4) {
-        const float* wr = g.w.fc1_w[branch] + (long)o * F;
-        float acc = 0.f;
-        for (int f = lane; f < F; f += 64) acc += wr[f] * sq[f];
-        acc = wave_sum_f(acc);
-        if (lane == 0) hid[o] = fmaxf(acc + g.w.fc1_b[branch][o], 0.f);
+    // fc1 + ReLU, fc2 + sigmoid: one thread per output over TRANSPOSED weights (coalesced, independent loads);
+    // a wave-per-output dot product is a chain of dependent L2 round trips here (measured 120 us vs a few us).
+    for (int o = tid; o < Fr; o += 256) {
+        const float* wT = g.w.fc1_wT[branch] + o;
+        float acc = g.w.fc1_b[branch][o];
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) acc += wT[(long)f * Fr] * sq[f];
+        hid[o] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    // fc2 + sigmoid
-    for (int o = wave; o < F; o += 4) {
-        const float* wr = g.w.fc2_w[branch] + (long)o * Fr;
-        float acc = 0.f;
-        for (int f = lane; f < Fr; f += 64) acc += wr[f] * hid[f];
-        acc = wave_sum_f(acc);
-        if (lane == 0) g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-(acc + g.w.fc2_b[branch][o])));
+    for (int o = tid; o < F; o += 256) {
+        const float* wT = g.w.fc2_wT[branch] + o;
+        float acc = g.w.fc2_b[branch][o];
+#pragma unroll 8
+        for (int f = 0; f < Fr; ++f) acc += wT[(long)f * F] * hid[f];
+        g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
     }
 }
 

@@ -326,12 +326,21 @@ int fsnp_commit_weights(fsnp_handle* h) {
         }
         o_cat_w[a] = put(p + ".feature_concate_fc.weight");
         o_cat_b[a] = put(p + ".feature_concate_fc.bias");
-        o_fc1w[a] = put(p + ".fc1.weight"); o_fc1b[a] = put(p + ".fc1.bias");
-        o_fc2w[a] = put(p + ".fc2.weight"); o_fc2b[a] = put(p + ".fc2.bias");
+        {   // transposed copies: fc1 [Fr][F] -> [F][Fr], fc2 [F][Fr] -> [Fr][F]
+            const auto& w1 = W(p + ".fc1.weight");
+            o_fc1w[a] = alloc((size_t)F * Fr);
+            for (int o = 0; o < Fr; ++o)
+                for (int f = 0; f < F; ++f) blob[o_fc1w[a] + (size_t)f * Fr + o] = w1[(size_t)o * F + f];
+            const auto& w2 = W(p + ".fc2.weight");
+            o_fc2w[a] = alloc((size_t)Fr * F);
+            for (int o = 0; o < F; ++o)
+                for (int f = 0; f < Fr; ++f) blob[o_fc2w[a] + (size_t)f * F + o] = w2[(size_t)o * Fr + f];
+        }
+        o_fc1b[a] = put(p + ".fc1.bias");
+        o_fc2b[a] = put(p + ".fc2.bias");
     }
     // ---- TCN: zero-padded row-major [N pad 64][K pad 16] GEMM operands, [branch][block] major
-    const int BN1 = tcn_pick_bn(CH), BN2 = tcn_pick_bn(F);
-    const int N1P = (int)align_up(CH, BN1), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, BN2), K2P = (int)align_up(CH, 16);
+    const int N1P = (int)align_up(CH, 384), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, 384), K2P = (int)align_up(CH, 16);
     const size_t o_w1 = alloc((size_t)3 * NB * N1P * K1P), o_b1 = alloc((size_t)3 * NB * N1P), o_a1 = alloc(3 * NB + 1);
     const size_t o_g1w = alloc((size_t)3 * NB * CH), o_g1b = alloc((size_t)3 * NB * CH);
     const size_t o_dw = alloc((size_t)3 * NB * 3 * CH), o_db = alloc((size_t)3 * NB * CH), o_a2 = alloc(3 * NB + 1);
@@ -396,14 +405,14 @@ int fsnp_commit_weights(fsnp_handle* h) {
     for (int a = 0; a < 3; ++a) {
         for (int c = 0; c < 3; ++c) { h->fw.conv_w[a][c] = d + o_conv_w[a][c]; h->fw.conv_b[a][c] = d + o_conv_b[a][c]; }
         h->fw.cat_w[a] = d + o_cat_w[a]; h->fw.cat_b[a] = d + o_cat_b[a];
-        h->fw.fc1_w[a] = d + o_fc1w[a]; h->fw.fc1_b[a] = d + o_fc1b[a];
-        h->fw.fc2_w[a] = d + o_fc2w[a]; h->fw.fc2_b[a] = d + o_fc2b[a];
+        h->fw.fc1_wT[a] = d + o_fc1w[a]; h->fw.fc1_b[a] = d + o_fc1b[a];
+        h->fw.fc2_wT[a] = d + o_fc2w[a]; h->fw.fc2_b[a] = d + o_fc2b[a];
     }
     for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
     h->tw.w1 = d + o_w1; h->tw.b1 = d + o_b1; h->tw.a1 = d + o_a1; h->tw.g1w = d + o_g1w; h->tw.g1b = d + o_g1b;
     h->tw.dw = d + o_dw; h->tw.db = d + o_db; h->tw.a2 = d + o_a2; h->tw.g2w = d + o_g2w; h->tw.g2b = d + o_g2b;
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
-    h->tw.BN1 = BN1; h->tw.BN2 = BN2; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
+    h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
@@ -605,6 +614,7 @@ int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves) {
 int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus) {
     if (!h || num_cus <= 0) { set_error("fsnp_debug_set_num_cus: bad argument"); return 1; }
     h->num_cus = num_cus;
+    h->tw.num_cus = num_cus;
     return 0;
 }
 

@@ -34,9 +34,9 @@ struct FrontendWeights {
     const float* conv_b[3][3];
     const float* cat_w[3];   // [3]
     const float* cat_b[3];   // [1]
-    const float* fc1_w[3];   // [F/2][F]
+    const float* fc1_wT[3];  // [F][F/2]   fc1.weight transposed (thread-per-output, coalesced)
     const float* fc1_b[3];   // [F/2]
-    const float* fc2_w[3];   // [F][F/2]
+    const float* fc2_wT[3];  // [F/2][F]   fc2.weight transposed
     const float* fc2_b[3];   // [F]
     int ksize[3];
 };
@@ -72,7 +72,7 @@ struct TcnWeights {
     const float* wf;     // [3][N2P][K1P]      fc_output_layer
     const float* bf;     // [3][N2P]
     int NB, N1P, K1P, N2P, K2P;
-    int BN1, BN2;        // column-tile widths of the N = CH and N = F GEMMs (N1P % BN1 == 0, N2P % BN2 == 0)
+    int num_cus;         // for the per-launch column-tile choice (N1P, N2P are multiples of 384: any BN fits)
     int dilation[16];
 };
 
@@ -87,7 +87,6 @@ struct TcnBuffers {
 };
 
 void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s);
-int tcn_pick_bn(int n);   // 64, 96 or 128
 
 // ---------------------------------------------------------------------------------------------
 // subband.hip : statistics of the (never materialised) sub-band input tensor

@@ -207,23 +207,28 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     }
 }
 
+// Column-tile width for one GEMM launch.  Workgroups are MFMA-bound, so the launch takes about
+// ceil(blocks / CUs) * BN; pick the BN in {64, 96, 128} that minimises it (ties -> the narrower tile: more,
+// smaller workgroups balance better).  Weights are zero-padded to a multiple of 384 rows so any choice is valid.
+static int pick_bn(int n, int row_tiles, int num_cus) {
+    int best = 64;
+    long best_cost = -1;
+    const int cand[3] = {64, 96, 128};
+    for (int c : cand) {
+        const long blocks = (long)cdiv(n, c) * row_tiles * 3;
+        const long cost = ((blocks + num_cus - 1) / num_cus) * c;
+        if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+
 template <int PRO, int EPI>
-static void launch_gemm(const GemmArgs& g, int bn, int npad, int row_tiles, hipStream_t s) {
-    const dim3 grid(npad / bn, row_tiles, 3);
+static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s) {
+    const int bn = pick_bn(n, row_tiles, num_cus);
+    const dim3 grid(cdiv(n, bn), row_tiles, 3);
     if (bn == 128) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 128>), grid, dim3(256), 0, s, g);
     else if (bn == 96) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 96>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 64>), grid, dim3(256), 0, s, g);
-}
-
-// column-tile width that wastes the fewest padded columns (ties -> the wider tile)
-int tcn_pick_bn(int n) {
-    int best = 64, best_pad = (n + 63) / 64 * 64;
-    const int cand[2] = {96, 128};
-    for (int c : cand) {
-        const int pad = (n + c - 1) / c * c;
-        if (pad <= best_pad) { best = c; best_pad = pad; }
-    }
-    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,7 +315,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gn_out = gn_slot(blk, 0);
             g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
             g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
-            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, w.BN1, w.N1P, row_tiles, s);
+            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s);
         }
         {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
             DwArgs g{};
@@ -335,7 +340,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gamma = w.g2w + (long)blk * d.CH; g.beta = w.g2b + (long)blk * d.CH; g.gb_bs = (long)w.NB * d.CH;
             g.K = d.CH; g.N = d.F; g.Tp = d.Tp; g.B = d.B;
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, w.BN2, w.N2P, row_tiles, s);
+            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s);
         }
         if (blk == 0 && buf.dbg_tcn0)
             (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -347,7 +352,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
         g.bias = w.bf; g.bias_bs = w.N2P;
         g.C = buf.fb; g.c_bs = x_bs; g.ldc = d.FP;
         g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
-        launch_gemm<PRO_RELU, EPI_ACT>(g, w.BN2, w.N2P, row_tiles, s);
+        launch_gemm<PRO_RELU, EPI_ACT>(g, d.F, row_tiles, w.num_cus, s);
     }
 }
 
