@@ -13,13 +13,14 @@ class FsnpConfig(ctypes.Structure):
         ("num_freqs", c_i32), ("look_ahead", c_i32), ("sb_num_neighbors", c_i32), ("fb_num_neighbors", c_i32),
         ("tcn_hidden", c_i32), ("num_tcn_blocks", c_i32), ("sb_hidden", c_i32), ("output_size", c_i32),
         ("norm_type", c_i32), ("fb_act", c_i32), ("sb_act", c_i32), ("kersize", c_i32 * 3),
-        ("num_groups_in_drop_band", c_i32),
+        ("num_groups_in_drop_band", c_i32), ("attention", c_i32),
     ]
 
 
 NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_gaussian_norm": 2,
               "cumulative_layer_norm": 3}
 ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
+ATTENTION = {"TSSE": 0, "SE": 1, "ECA": 2, "CBAM": 3}
 MODE_FULL, MODE_PARITY = 0, 1
 
 # every symbol include/fsnp.h declares: name -> (restype, argtypes)
@@ -33,6 +34,8 @@ SYMBOLS = {
     "fsnp_workspace_bytes": (ctypes.c_size_t, [c_vp, c_i32, c_i32, c_i32]),
     "fsnp_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64 * 3 * 3), c_vp, c_i32, c_i32, c_i32,
                              c_i32, c_i32, c_vp]),
+    "fsnp_apply_cirm": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, ctypes.POINTER(c_i64 * 3), c_i32, c_i32,
+                                c_i32, c_vp]),
     "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "fsnp_read_stage": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i64]),
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),

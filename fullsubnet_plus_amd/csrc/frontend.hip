@@ -164,15 +164,32 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kmax = max(max(g.w.ksize[0], g.w.ksize[1]), g.w.ksize[2]);
 
-    for (int i = tid; i < 2 * (kmax - 1) * F; i += 256) {
-        const int side = i / ((kmax - 1) * F), r = (i / F) % (kmax - 1), f = i % F;
-        const int t = side == 0 ? r : Tp - 1 - r;                    // r-th frame from the start / from the end
-        const NormMD m = g.md[ub * Tp + t];
-        edge[(side * MAXK + r) * FP + f] = (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d;
+    const int att = g.w.attention;
+    float* sqmax = edge;               // [FP] CBAM: max over t (edge is unused then)
+    if (att == FSNP_ATT_TSSE) {
+        for (int i = tid; i < 2 * (kmax - 1) * F; i += 256) {
+            const int side = i / ((kmax - 1) * F), r = (i / F) % (kmax - 1), f = i % F;
+            const int t = side == 0 ? r : Tp - 1 - r;                    // r-th frame from the start / from the end
+            const NormMD m = g.md[ub * Tp + t];
+            edge[(side * MAXK + r) * FP + f] = (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int f = tid; f < F; f += 256) {
         const double S = g.fsum[ub * FP + f];
+        if (att != FSNP_ATT_TSSE) {
+            // SE / ECA / CBAM squeeze = mean over time (attention_model.py:31, :349, :320)
+            sq[f] = (float)(S / (double)Tp);
+            if (att == FSNP_ATT_CBAM) {                      // + max over time (attention_model.py:321)
+                float mx = -3.4e38f;
+                for (int t = 0; t < Tp; ++t) {
+                    const NormMD m = g.md[ub * Tp + t];
+                    mx = fmaxf(mx, (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d);
+                }
+                sqmax[f] = mx;
+            }
+            continue;
+        }
         const float* first = edge + f;                       // first[r * FP] = r-th normalised frame
         const float* last = edge + (long)MAXK * FP + f;      // last[r * FP]  = r-th frame from the end
         float squeeze = g.w.cat_b[branch][0];
@@ -193,6 +210,15 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         sq[f] = squeeze;
     }
     __syncthreads();
+    if (att == FSNP_ATT_ECA) {
+        // Conv1d(1, 1, 3, padding=1, bias=False) ALONG THE CHANNEL AXIS of the pooled vector, then sigmoid
+        const float w0 = g.w.cat_w[branch][0], w1 = g.w.cat_w[branch][1], w2 = g.w.cat_w[branch][2];
+        for (int o = tid; o < F; o += 256) {
+            const float y = w0 * (o > 0 ? sq[o - 1] : 0.f) + w1 * sq[o] + w2 * (o + 1 < F ? sq[o + 1] : 0.f);
+            g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-y));
+        }
+        return;
+    }
     // fc1 + ReLU, fc2 + sigmoid: one thread per output over TRANSPOSED weights (coalesced, independent loads);
     // a wave-per-output dot product is a chain of dependent L2 round trips here (measured 120 us vs a few us).
     for (int o = tid; o < Fr; o += 256) {
@@ -200,7 +226,14 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         float acc = g.w.fc1_b[branch][o];
 #pragma unroll 8
         for (int f = 0; f < F; ++f) acc += wT[(long)f * Fr] * sq[f];
-        hid[o] = fmaxf(acc, 0.f);
+        float h = fmaxf(acc, 0.f);
+        if (att == FSNP_ATT_CBAM) {                          // relu(fc1(mean)) + relu(fc1(max))
+            float acc2 = g.w.fc1_b[branch][o];
+#pragma unroll 8
+            for (int f = 0; f < F; ++f) acc2 += wT[(long)f * Fr] * sqmax[f];
+            h += fmaxf(acc2, 0.f);
+        }
+        hid[o] = h;
     }
     __syncthreads();
     for (int o = tid; o < F; o += 256) {
@@ -227,6 +260,39 @@ __global__ __launch_bounds__(256) void fe_apply_kernel(const float* __restrict__
         }
         att[i] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decompress_cIRM (mask.py:60-63) + complex multiply (inferencer.py:152-157)
+__global__ __launch_bounds__(256) void apply_cirm_kernel(const float* __restrict__ mask, const float2* __restrict__ noisy,
+                                                         long sb, long sf, long st, float2* __restrict__ out, long ob,
+                                                         long of, long ot, int B, int F, int T) {
+    // thread per (b, t, f) with f fastest: matches torch.stft's memory order for the complex operands
+    const long total = (long)B * T * F;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int f = (int)(i % F);
+        const int t = (int)((i / F) % T);
+        const int b = (int)(i / ((long)F * T));
+        float m[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float v = mask[(((long)b * 2 + o) * F + f) * T + t];
+            const float lim = 9.9f, K = 10.0f;
+            v = v >= lim ? lim : (v <= -lim ? -lim : v);
+            m[o] = -K * logf((K - v) / (K + v));
+        }
+        const float2 x = noisy[b * sb + f * sf + t * st];
+        out[b * ob + f * of + t * ot] = make_float2(m[0] * x.x - m[1] * x.y, m[1] * x.x + m[0] * x.y);
+    }
+}
+
+void launch_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
+                       const int64_t out_strides[3], int B, int F, int T, hipStream_t s) {
+    const long total = (long)B * T * F;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(apply_cirm_kernel, dim3(blocks), dim3(256), 0, s, mask, reinterpret_cast<const float2*>(noisy),
+                       strides[0], strides[1], strides[2], reinterpret_cast<float2*>(out), out_strides[0], out_strides[1],
+                       out_strides[2], B, F, T);
 }
 
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],

@@ -85,18 +85,25 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static void build_specs(fsnp_handle* h) {
     auto add = [&](const std::string& n, int64_t numel) { h->specs.push_back({n, numel}); };
     const int F = h->F, CH = h->CH, H = h->H, Fr = h->Fr;
+    const int att = h->cfg.attention;
     for (int a = 0; a < 3; ++a) {
         const std::string p = kAtt[a];
-        for (int c = 0; c < 3; ++c) {
-            add(p + "." + kConvNames[c] + ".0.weight", (int64_t)F * h->cfg.kersize[c]);
-            add(p + "." + kConvNames[c] + ".0.bias", F);
+        if (att == FSNP_ATT_TSSE) {
+            for (int c = 0; c < 3; ++c) {
+                add(p + "." + kConvNames[c] + ".0.weight", (int64_t)F * h->cfg.kersize[c]);
+                add(p + "." + kConvNames[c] + ".0.bias", F);
+            }
+            add(p + ".feature_concate_fc.weight", 3);
+            add(p + ".feature_concate_fc.bias", 1);
         }
-        add(p + ".feature_concate_fc.weight", 3);
-        add(p + ".feature_concate_fc.bias", 1);
-        add(p + ".fc1.weight", (int64_t)Fr * F);
-        add(p + ".fc1.bias", Fr);
-        add(p + ".fc2.weight", (int64_t)F * Fr);
-        add(p + ".fc2.bias", F);
+        if (att == FSNP_ATT_ECA) {
+            add(p + ".conv.weight", 3);
+        } else {
+            add(p + ".fc1.weight", (int64_t)Fr * F);
+            add(p + ".fc1.bias", Fr);
+            add(p + ".fc2.weight", (int64_t)F * Fr);
+            add(p + ".fc2.bias", F);
+        }
     }
     for (int b = 0; b < 3; ++b) {
         for (int i = 0; i < h->NB; ++i) {
@@ -229,6 +236,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
     if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
+    if (cfg->attention < 0 || cfg->attention > 3) { set_error("unknown attention model %d", cfg->attention); return 2; }
     const int nin = 2 * cfg->sb_num_neighbors + 1 + 3;
     if (nin > 40) { set_error("sb_num_neighbors too large for the KX=40 LSTM instantiation"); return 2; }
     if (cfg->num_freqs <= cfg->sb_num_neighbors) { set_error("num_freqs must exceed sb_num_neighbors (reflect pad)"); return 2; }
@@ -317,15 +325,23 @@ int fsnp_commit_weights(fsnp_handle* h) {
     auto put = [&](const std::string& n) { const auto& v = W(n); size_t o = alloc(v.size()); std::copy(v.begin(), v.end(), blob.begin() + o); return o; };
 
     // ---- frontend (TSSE) : reference layouts are already what the kernels want
-    size_t o_conv_w[3][3], o_conv_b[3][3], o_cat_w[3], o_cat_b[3], o_fc1w[3], o_fc1b[3], o_fc2w[3], o_fc2b[3];
+    size_t o_conv_w[3][3] = {}, o_conv_b[3][3] = {}, o_cat_w[3] = {}, o_cat_b[3] = {}, o_fc1w[3] = {}, o_fc1b[3] = {},
+           o_fc2w[3] = {}, o_fc2b[3] = {};
+    const int att = h->cfg.attention;
     for (int a = 0; a < 3; ++a) {
         const std::string p = kAtt[a];
-        for (int c = 0; c < 3; ++c) {
-            o_conv_w[a][c] = put(p + "." + kConvNames[c] + ".0.weight");
-            o_conv_b[a][c] = put(p + "." + kConvNames[c] + ".0.bias");
+        if (att == FSNP_ATT_TSSE) {
+            for (int c = 0; c < 3; ++c) {
+                o_conv_w[a][c] = put(p + "." + kConvNames[c] + ".0.weight");
+                o_conv_b[a][c] = put(p + "." + kConvNames[c] + ".0.bias");
+            }
+            o_cat_w[a] = put(p + ".feature_concate_fc.weight");
+            o_cat_b[a] = put(p + ".feature_concate_fc.bias");
         }
-        o_cat_w[a] = put(p + ".feature_concate_fc.weight");
-        o_cat_b[a] = put(p + ".feature_concate_fc.bias");
+        if (att == FSNP_ATT_ECA) {
+            o_cat_w[a] = put(p + ".conv.weight");            // the 3 taps of Conv1d(1,1,3) over the channel axis
+            continue;
+        }
         {   // transposed copies: fc1 [Fr][F] -> [F][Fr], fc2 [F][Fr] -> [Fr][F]
             const auto& w1 = W(p + ".fc1.weight");
             o_fc1w[a] = alloc((size_t)F * Fr);
@@ -409,6 +425,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         h->fw.fc2_wT[a] = d + o_fc2w[a]; h->fw.fc2_b[a] = d + o_fc2b[a];
     }
     for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
+    h->fw.attention = h->cfg.attention;
     h->tw.w1 = d + o_w1; h->tw.b1 = d + o_b1; h->tw.a1 = d + o_a1; h->tw.g1w = d + o_g1w; h->tw.g1b = d + o_g1b;
     h->tw.dw = d + o_dw; h->tw.db = d + o_db; h->tw.a2 = d + o_a2; h->tw.g2w = d + o_g2w; h->tw.g2b = d + o_g2b;
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
@@ -442,7 +459,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     d.CH = h->CH; d.H = h->H; d.NSB = h->NSB; d.NIN = h->NIN;
     int kmax = 1;
     for (int c = 0; c < 3; ++c) kmax = kmax > h->cfg.kersize[c] ? kmax : h->cfg.kersize[c];
-    if (d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
+    if (h->cfg.attention == FSNP_ATT_TSSE && d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
     if ((double)3 * d.B * d.Tp * d.FP * 2 > 2.0e9) { set_error("batch too large for 32-bit gather offsets; split the batch"); return 2; }
 
     FSNP_HIP_CHECK(hipSetDevice(h->device));
@@ -503,6 +520,15 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     }
     FSNP_HIP_CHECK(hipGetLastError());
     h->last_ws = w; h->last_dims = d; h->have_last = true;
+    return 0;
+}
+
+int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
+                    const int64_t out_strides[3], int32_t batch, int32_t freqs, int32_t frames, void* hip_stream) {
+    if (!mask || !noisy || !out || !strides || !out_strides) { set_error("fsnp_apply_cirm: null argument"); return 1; }
+    if (batch <= 0 || freqs <= 0 || frames <= 0) { set_error("fsnp_apply_cirm: empty input"); return 2; }
+    launch_apply_cirm(mask, noisy, strides, out, out_strides, batch, freqs, frames, static_cast<hipStream_t>(hip_stream));
+    FSNP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

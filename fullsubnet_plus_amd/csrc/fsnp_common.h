@@ -39,6 +39,7 @@ struct FrontendWeights {
     const float* fc2_wT[3];  // [F/2][F]   fc2.weight transposed
     const float* fc2_b[3];   // [F]
     int ksize[3];
+    int attention;           // FSNP_ATT_*; for ECA cat_w holds the 3 conv taps
 };
 
 struct FrontendBuffers {
@@ -50,6 +51,8 @@ struct FrontendBuffers {
     float* att;       // [3][B][Tp][FP]
 };
 
+void launch_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
+                       const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
                      const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
 

@@ -37,6 +37,23 @@ class _TSSEParams(nn.Module):
         self.fc2 = nn.Linear(reduced, num_channels)
 
 
+class _SEParams(nn.Module):
+    """Parameter holder named like ChannelSELayer / ChannelCBAMLayer (attention_model.py:12-23, 302-313)."""
+
+    def __init__(self, num_channels, reduction_ratio=2):
+        super().__init__()
+        self.fc1 = nn.Linear(num_channels, num_channels // reduction_ratio)
+        self.fc2 = nn.Linear(num_channels // reduction_ratio, num_channels)
+
+
+class _ECAParams(nn.Module):
+    """Parameter holder named like ChannelECAlayer (attention_model.py:343-347)."""
+
+    def __init__(self, k_size=3):
+        super().__init__()
+        self.conv = nn.Conv1d(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+
+
 class _TCNBlockParams(nn.Module):
     """Parameter holder named like TCNBlock (causal_conv.py:68-94)."""
 
@@ -139,8 +156,8 @@ class FullSubNet_Plus(nn.Module):
         assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
         if sequence_model != "LSTM":
             raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM only)")
-        if channel_attention_model != "TSSE":
-            raise NotImplementedError(f"HIP path: channel attention model {channel_attention_model} is not built yet (TSSE only)")
+        if channel_attention_model not in _lib.ATTENTION:
+            raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
         if subband_num != 1:
             raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
         if fb_num_neighbors != 0:
@@ -153,9 +170,16 @@ class FullSubNet_Plus(nn.Module):
                 raise NotImplementedError(f"Not implemented activation function {act}")
 
         self.num_channels = num_freqs
-        self.channel_attention = _TSSEParams(num_freqs, kersize)
-        self.channel_attention_real = _TSSEParams(num_freqs, kersize)
-        self.channel_attention_imag = _TSSEParams(num_freqs, kersize)
+        def make_attention():
+            if channel_attention_model == "TSSE":
+                return _TSSEParams(num_freqs, kersize)
+            if channel_attention_model == "ECA":
+                return _ECAParams()
+            return _SEParams(num_freqs)                      # SE and CBAM share the parameter tree
+        self.channel_attention_model = channel_attention_model
+        self.channel_attention = make_attention()
+        self.channel_attention_real = make_attention()
+        self.channel_attention_imag = make_attention()
         # NB: the reference hard-codes the TCNBlock hidden width to 512 (causal_conv.py:68) and ignores
         # fb_model_hidden_size for the TCN full-band models (sequence_model.py:48-57).
         self.fb_model = _FullBandParams(num_freqs, 512)
@@ -201,6 +225,7 @@ class FullSubNet_Plus(nn.Module):
         for i, k in enumerate(self.kersize):
             cfg.kersize[i] = int(k)
         cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
+        cfg.attention = _lib.ATTENTION[self.channel_attention_model]
         return cfg
 
     def _weights_key(self):
@@ -283,6 +308,28 @@ class FullSubNet_Plus(nn.Module):
                                   _lib.MODE_PARITY if parity else _lib.MODE_FULL, int(batch_offset), gb,
                                   ctypes.c_void_p(stream))
         _lib.check(rc, "fsnp_forward")
+        return out
+
+    def enhance(self, noisy_complex):
+        """model forward + decompress_cIRM + complex multiply in HIP, i.e. lines 143-157 of
+        fullsubnet_plus/inferencer/inferencer.py: noisy_complex [B,F,T] complex64 (torch.stft output, any strides)
+        -> enhanced complex [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
+        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
+        mode, self.batch_mode = self.batch_mode, "full"
+        try:
+            mask = self.forward(noisy_complex.abs().unsqueeze(1), noisy_complex.real.unsqueeze(1),
+                                noisy_complex.imag.unsqueeze(1))
+        finally:
+            self.batch_mode = mode
+        B, F, T = noisy_complex.shape
+        out = torch.empty_strided((B, F, T), noisy_complex.stride(), dtype=torch.complex64, device=noisy_complex.device)
+        xr, orr = torch.view_as_real(noisy_complex), torch.view_as_real(out)
+        st = (ctypes.c_int64 * 3)(*noisy_complex.stride())
+        ost = (ctypes.c_int64 * 3)(*out.stride())
+        stream = torch.cuda.current_stream(noisy_complex.device).cuda_stream
+        with torch.cuda.device(noisy_complex.device):
+            _lib.check(_lib.load().fsnp_apply_cirm(mask.data_ptr(), xr.data_ptr(), ctypes.byref(st), orr.data_ptr(),
+                                                   ctypes.byref(ost), B, F, T, ctypes.c_void_p(stream)), "fsnp_apply_cirm")
         return out
 
     # ------------------------------------------------------------------ test / bench helpers

@@ -40,6 +40,14 @@ enum {
 /* output activation of SequenceModel (sequence_model.py:85-96); 0 == TOML `false` */
 enum { FSNP_ACT_NONE = 0, FSNP_ACT_RELU = 1, FSNP_ACT_RELU6 = 2, FSNP_ACT_TANH = 3 };
 
+/* channel_attention_model of FullSubNet_Plus.__init__ (fullsubnet_plus.py:51-70) */
+enum {
+    FSNP_ATT_TSSE = 0, /* ChannelTimeSenseSELayer  attention_model.py:43-98 (config/inference.toml) */
+    FSNP_ATT_SE = 1,   /* ChannelSELayer           attention_model.py:6-40   */
+    FSNP_ATT_ECA = 2,  /* ChannelECAlayer          attention_model.py:335-359 */
+    FSNP_ATT_CBAM = 3  /* ChannelCBAMLayer         attention_model.py:296-332 */
+};
+
 /* B > 1 semantics */
 enum {
     FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,2,F,T]          */
@@ -62,6 +70,7 @@ typedef struct fsnp_config {
     int32_t sb_act;             /* FSNP_ACT_* : sb_output_activate_function */
     int32_t kersize[3];         /* 3,5,10 : TSSE depthwise kernel sizes (attention_model.py:49) */
     int32_t num_groups_in_drop_band; /* 2 (only 2 is supported in PARITY mode) */
+    int32_t attention;          /* FSNP_ATT_* : channel_attention_model */
 } fsnp_config;
 
 /* Replaces `FullSubNet_Plus(**model.args)` (base_inferencer.py:99).  Needs a visible
@@ -100,6 +109,16 @@ size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames,
 int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
                  const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
                  int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream);
+
+/* the step right after the model in the reference inferencer
+ * (`decompress_cIRM` speech_enhance/audio_zen/acoustics/mask.py:60-63 + complex multiply
+ * speech_enhance/fullsubnet_plus/inferencer/inferencer.py:152-157) as one kernel.
+ *   mask  : DEVICE fp32 [B,2,F,T] contiguous (what fsnp_forward wrote, FULL mode)
+ *   noisy : DEVICE interleaved complex64, element (b,f,t) at noisy + 2*(b*strides[0]+f*strides[1]+t*strides[2])
+ *           (strides in complex elements - torch.stft's [B][T][F] layout is consumed in place)
+ *   out   : DEVICE interleaved complex64, same logical shape, strides out_strides (complex elements). */
+int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
+                    const int64_t out_strides[3], int32_t batch, int32_t freqs, int32_t frames, void* hip_stream);
 
 /* Stage-level entry point (unit tests, f-2 wiring): the fused two-layer LSTM + Linear
  * of SequenceModel.forward (sequence_model.py:113-123) on a dense input.

@@ -77,6 +77,43 @@ def tsse(x, p, prefix):
     return x * gate.unsqueeze(2)
 
 
+def attention(x, p, prefix, kind="TSSE"):
+    """channel attention selected by `channel_attention_model` (fullsubnet_plus.py:51-70):
+    SE attention_model.py:6-40, ECA :335-359, CBAM :296-332, TSSE :43-98."""
+    if kind == "TSSE":
+        return tsse(x, p, prefix)
+    if kind == "SE":
+        sq = x.mean(dim=2)
+        h = torch.relu(Fn.linear(sq, p[f"{prefix}.fc1.weight"], p[f"{prefix}.fc1.bias"]))
+        gate = torch.sigmoid(Fn.linear(h, p[f"{prefix}.fc2.weight"], p[f"{prefix}.fc2.bias"]))
+        return x * gate.unsqueeze(2)
+    if kind == "CBAM":
+        h = torch.relu(Fn.linear(x.mean(dim=2), p[f"{prefix}.fc1.weight"], p[f"{prefix}.fc1.bias"])) + \
+            torch.relu(Fn.linear(x.max(dim=2)[0], p[f"{prefix}.fc1.weight"], p[f"{prefix}.fc1.bias"]))
+        gate = torch.sigmoid(Fn.linear(h, p[f"{prefix}.fc2.weight"], p[f"{prefix}.fc2.bias"]))
+        return x * gate.unsqueeze(2)
+    if kind == "ECA":
+        y = x.mean(dim=2, keepdim=True)                                   # AdaptiveAvgPool1d(1): [B,C,1]
+        y = Fn.conv1d(y.transpose(-1, -2), p[f"{prefix}.conv.weight"], padding=1).transpose(-1, -2)
+        return x * torch.sigmoid(y)
+    raise NotImplementedError(kind)
+
+
+def decompress_cirm(mask, K=10.0, limit=9.9):
+    """audio_zen/acoustics/mask.py:60-63"""
+    mask = limit * (mask >= limit) - limit * (mask <= -limit) + mask * (torch.abs(mask) < limit)
+    return -K * torch.log((K - mask) / (K + mask))
+
+
+def apply_cirm(pred_crm, noisy_complex):
+    """fullsubnet_plus/inferencer/inferencer.py:152-157: pred_crm [B,2,F,T], noisy_complex [B,F,T] complex
+    -> enhanced complex [B,F,T]."""
+    m = decompress_cirm(pred_crm.permute(0, 2, 3, 1))
+    er = m[..., 0] * noisy_complex.real - m[..., 1] * noisy_complex.imag
+    ei = m[..., 1] * noisy_complex.real + m[..., 0] * noisy_complex.imag
+    return torch.complex(er, ei)
+
+
 def tcn_block(x, p, prefix, dilation):
     """causal_conv.py:96-108"""
     Hc = p[prefix + ".conv1x1.weight"].shape[0]
@@ -146,7 +183,7 @@ def drop_band(x, num_groups=2):
 def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighbors=15,
             fb_num_neighbors=0, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
             fb_output_activate_function="ReLU", sb_output_activate_function=False,
-            output_size=2, apply_drop_band=None, stages=None):
+            output_size=2, apply_drop_band=None, stages=None, channel_attention_model="TSSE"):
     """fullsubnet_plus/model/fullsubnet_plus.py:122-209; see fsnp_numpy.forward."""
     assert noisy_mag.dim() == 4
     mag, real, imag = (Fn.pad(a, [0, look_ahead]) for a in (noisy_mag, noisy_real, noisy_imag))
@@ -161,7 +198,7 @@ def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighb
     for tag, x, att, fb in (("mag", mag, "channel_attention", "fb_model"),
                             ("real", real, "channel_attention_real", "fb_model_real"),
                             ("imag", imag, "channel_attention_imag", "fb_model_imag")):
-        xin = tsse(norm(x).reshape(B, F, T), p, att)
+        xin = attention(norm(x).reshape(B, F, T), p, att, channel_attention_model)
         rec(f"att_{tag}", xin)
         if tag == "mag":
             fb_in_mag = xin

@@ -58,6 +58,12 @@ CASES = [
          inp=("spec", 1, 30, 9), stages=True),
     dict(name="b3_t18_cum_layer", wseed=10, profile="harsh", args={"norm_type": "cumulative_layer_norm"},
          inp=("spec", 3, 18, 10), stages=False),
+    dict(name="b1_t20_att_SE", wseed=12, profile="default", args={"channel_attention_model": "SE"},
+         inp=("spec", 1, 20, 12), stages=False),
+    dict(name="b1_t20_att_ECA", wseed=13, profile="harsh", args={"channel_attention_model": "ECA"},
+         inp=("spec", 1, 20, 13), stages=False),
+    dict(name="b3_t20_att_CBAM", wseed=14, profile="default", args={"channel_attention_model": "CBAM"},
+         inp=("spec", 3, 20, 14), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -77,7 +83,7 @@ def run_case(case, FullSubNet_Plus):
     args.update(case["args"])
     torch.manual_seed(0)
     model = FullSubNet_Plus(**args).eval()
-    sd = make_state_dict(case["wseed"], case["profile"])
+    sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"])
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]
@@ -148,14 +154,15 @@ def main():
         # cross-check both restatements right away (report only; tests enforce)
         kw = dict(look_ahead=args["look_ahead"], sb_num_neighbors=args["sb_num_neighbors"],
                   fb_num_neighbors=args["fb_num_neighbors"], norm_type=args["norm_type"],
-                  num_groups_in_drop_band=args["num_groups_in_drop_band"])
+                  num_groups_in_drop_band=args["num_groups_in_drop_band"],
+                  channel_attention_model=args["channel_attention_model"])
         sub = case.get("subsample_f") or 1
         ot = fsnp_torch.forward(sd, mag, real, imag, **kw).numpy()[:, :, ::sub, :]
         scale = np.abs(payload["out"]).max()
         msg = f"{case['name']:28s} out{payload['out'].shape} scale {scale:.3e} " \
               f"ref32-vs-64 {np.abs(payload['out'] - payload['out64']).max() / scale:.2e} " \
               f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e}"
-        if mag.shape[-1] <= 40:
+        if mag.shape[-1] <= 40 and args["channel_attention_model"] == "TSSE":
             sdn = {k: v.numpy() for k, v in sd.items()}
             on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kw)
             msg += f" numpy64-vs-ref64 {np.abs(on[:, :, ::sub, :] - payload['out64']).max() / scale:.2e}"

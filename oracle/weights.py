@@ -37,7 +37,7 @@ def _orthogonal(rng, rows, cols):
 
 def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb_hidden=384,
                     sb_num_neighbors=15, fb_num_neighbors=0, kersize=(3, 5, 10), output_size=2,
-                    num_tcn_blocks=8, as_torch=True):
+                    num_tcn_blocks=8, as_torch=True, attention="TSSE"):
     assert profile in ("default", "harsh")
     harsh = profile == "harsh"
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -66,11 +66,15 @@ def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb
             sd[name + ".bias"] = _uniform(rng, (cout,), b)
 
     for att in ("channel_attention", "channel_attention_real", "channel_attention_imag"):
-        for nm, k in zip(("smallConv1d", "middleConv1d", "largeConv1d"), kersize):
-            conv(f"{att}.{nm}.0", F, 1, k)
-        linear(f"{att}.feature_concate_fc", 1, 3)
-        linear(f"{att}.fc1", Fr, F)
-        linear(f"{att}.fc2", F, Fr)
+        if attention == "TSSE":
+            for nm, k in zip(("smallConv1d", "middleConv1d", "largeConv1d"), kersize):
+                conv(f"{att}.{nm}.0", F, 1, k)
+            linear(f"{att}.feature_concate_fc", 1, 3)
+        if attention in ("TSSE", "SE", "CBAM"):
+            linear(f"{att}.fc1", Fr, F)
+            linear(f"{att}.fc2", F, Fr)
+        if attention == "ECA":                      # nn.Conv1d(1, 1, 3, padding=1, bias=False)
+            sd[f"{att}.conv.weight"] = _normal(rng, (1, 1, 3)) if harsh else _uniform(rng, (1, 1, 3), 1.0 / np.sqrt(3))
 
     for fb in ("fb_model", "fb_model_real", "fb_model_imag"):
         for i in range(num_tcn_blocks):

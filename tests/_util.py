@@ -25,7 +25,8 @@ class Golden:
         self.sub = self.meta.get("subsample_f", 1)
 
     def state_dict(self):
-        return make_state_dict(self.meta["wseed"], self.meta["profile"])
+        return make_state_dict(self.meta["wseed"], self.meta["profile"],
+                               attention=self.args.get("channel_attention_model", "TSSE"))
 
     def inputs(self):
         inp = self.meta["inp"]
@@ -40,7 +41,8 @@ class Golden:
         a = self.args
         return dict(look_ahead=a["look_ahead"], sb_num_neighbors=a["sb_num_neighbors"],
                     fb_num_neighbors=a["fb_num_neighbors"], norm_type=a["norm_type"],
-                    num_groups_in_drop_band=a["num_groups_in_drop_band"])
+                    num_groups_in_drop_band=a["num_groups_in_drop_band"],
+                    channel_attention_model=a.get("channel_attention_model", "TSSE"))
 
 
 def rel_err(a, b):

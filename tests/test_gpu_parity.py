@@ -157,6 +157,22 @@ def test_forward_vs_reference_golden(name):
         assert errf < TOL, errf
 
 
+def test_enhance_epilogue_vs_oracle():
+    """forward + decompress_cIRM + complex multiply (inferencer.py:143-157) in HIP."""
+    sd = make_state_dict(21, "harsh")                       # harsh weights -> masks beyond +-9.9 exercise the clamp
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    mag, real, imag = make_spec(2, 40, 5)
+    X = torch.complex(real[:, 0], imag[:, 0])               # [B,F,T] with torch.stft strides
+    Xg = torch.empty_strided(X.shape, X.stride(), dtype=X.dtype, device="cuda")
+    Xg.copy_(X)
+    got = m.enhance(Xg).cpu()
+    mask = fsnp_torch.forward_full(sd, mag, real, imag)
+    want = fsnp_torch.apply_cirm(mask, X)
+    err = float((got - want).abs().max() / want.abs().max())
+    _record("enhance_epilogue", rel=err, mask_absmax=float(mask.abs().max()))
+    assert got.shape == want.shape and err < TOL, err
+
+
 def test_batch2_raises_like_reference():
     g = Golden("b4_t16_default")
     m = _model(g.args, g.state_dict(), "parity")

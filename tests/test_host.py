@@ -55,6 +55,16 @@ def test_module_has_reference_parameter_tree_and_strict_load():
     assert m2._hip is not m._hip
 
 
+@pytest.mark.parametrize("att", ["SE", "ECA", "CBAM"])
+def test_attention_variants_have_reference_parameter_tree(att):
+    m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": att})
+    sd = make_state_dict(0, attention=att)
+    assert set(m.state_dict()) == set(sd)
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd, strict=True)
+
+
 def test_error_behaviour_matches_reference():
     m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
     x = torch.zeros(1, 1, 257, 12)
@@ -68,8 +78,10 @@ def test_error_behaviour_matches_reference():
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": "forgetting_norm"})
     with pytest.raises(AssertionError):           # fullsubnet_plus.py:45
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "RNN"})
+    with pytest.raises(NotImplementedError):      # fullsubnet_plus.py:70
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": "XYZ"})
     with pytest.raises(NotImplementedError):
-        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": "SE"})
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"})
 
 
 def test_weight_init_true_reinitialises():
