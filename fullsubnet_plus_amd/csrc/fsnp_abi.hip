@@ -32,7 +32,7 @@ struct WeightSpec {
 
 struct Workspace {
     // offsets in bytes from the workspace base
-    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, zero_begin, fsum, gn, sb_acc, zero_end,
+    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, zero_begin, fsum, gn, sb_acc, coop_hx, coop_bar, zero_end,
         dbg_tcn0, total;
 };
 
@@ -65,6 +65,9 @@ struct fsnp_handle {
     bool have_last = false;
     bool debug = false;
     int num_cus = 256;
+    int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
+    int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
+    unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in the cooperative LSTM kernel
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
     bool timing = false;
@@ -169,6 +172,12 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
     rows[slot] = r;
 }
 
+// The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
+// would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
+static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) {
+    return h->lstm_coop != 0 && lp.ex == 0 && lp.num_tiles * (h->H / 32) <= h->num_cus_real;
+}
+
 static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
 
 static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
@@ -197,6 +206,9 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.fsum = take((size_t)3 * B * h->FP * 8);
     w.gn = take((size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
+    const bool coop = use_coop(h, lp);
+    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles) : 0);
+    w.coop_bar = take(coop ? (size_t)lp.num_tiles * 4 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
     w.total = o;
@@ -259,6 +271,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->cfg = *cfg;
     h->device = dev;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->num_cus_real = h->num_cus;
     h->F = cfg->num_freqs;
     h->FP = (int)align_up(cfg->num_freqs, 4);
     h->CH = cfg->tcn_hidden;
@@ -269,6 +282,13 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->NB = cfg->num_tcn_blocks;
     h->Fr = cfg->num_freqs / 2;
     build_specs(h);
+    const char* cp = getenv("FSNP_LSTM_COOP");
+    if (cp && cp[0] == '0') h->lstm_coop = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_err), 256) != hipSuccess || hipMemset(h->d_err, 0, 256) != hipSuccess) {
+        set_error("hipMalloc of the error word failed");
+        delete h;
+        return 4;
+    }
     const char* nw = getenv("FSNP_LSTM_WAVES");
     if (nw && atoi(nw) == 4) h->lstm_waves = 4;
     if (nw && atoi(nw) == 12) h->lstm_waves = 12;
@@ -283,6 +303,7 @@ void fsnp_destroy(fsnp_handle* h) {
     (void)hipDeviceSynchronize();
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_weights) (void)hipFree(h->d_weights);
+    if (h->d_err) (void)hipFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
     delete h;
@@ -400,6 +421,9 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
     lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                       W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
+    const size_t o_wpack_coop = alloc(lstm_coop_pack_floats(H, h->KX, 1));
+    lstm_coop_pack_weights(H, h->NIN, h->KX, 1, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                           W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop);
     const size_t o_lbias = alloc((size_t)2 * 4 * H);
     for (int l = 0; l < 2; ++l) {
         const auto& bi = W(s + "bias_ih_l" + std::to_string(l));
@@ -431,7 +455,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
     h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
-    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
+    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.wpack_coop = d + o_wpack_coop; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
     h->d_refl_w = d + o_refl;
     h->committed = true;
@@ -513,7 +537,12 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
     a.num_rows = num_rows; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.act = h->cfg.sb_act;
-    launch_lstm(h->lw, a, s);
+    if (use_coop(h, lp)) {
+        a.coop_hx = fptr(w.coop_hx); a.coop_bar = reinterpret_cast<unsigned*>(base + w.coop_bar); a.coop_err = h->d_err;
+        launch_lstm_coop(h->lw, a, s);
+    } else {
+        launch_lstm(h->lw, a, s);
+    }
     if (h->timing) {
         FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
         h->timing_recs.push_back(rec);
@@ -541,15 +570,27 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
     const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
-    if (ensure_workspace(h, (size_t)num_slots * sizeof(RowDesc))) return 4;
+    const bool coop = use_coop(h, lp);
+    const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
+    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles), 256) : 0;
+    const size_t coop_bytes = coop ? coop_hx_bytes + align_up((size_t)lp.num_tiles * 4, 256) : 0;
+    if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
+    if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_seq, lp.num_tiles,
                        lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
-    launch_lstm(h->lw, a, s);
+    if (coop) {
+        a.coop_hx = reinterpret_cast<float*>(h->ws + coop_off);
+        a.coop_bar = reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes);
+        a.coop_err = h->d_err;
+        launch_lstm_coop(h->lw, a, s);
+    } else {
+        launch_lstm(h->lw, a, s);
+    }
     FSNP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -627,6 +668,27 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     launch_lstm(h->lw, a, 0);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     FSNP_HIP_CHECK(hipMemcpy(host_stamps, dprof, (size_t)num_stamps * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fsnp_check_errors(fsnp_handle* h) {
+    if (!h) { set_error("null handle"); return 1; }
+    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
+    unsigned e = 0;
+    FSNP_HIP_CHECK(hipMemcpy(&e, h->d_err, 4, hipMemcpyDeviceToHost));
+    if (e != 0) {
+        (void)hipMemset(h->d_err, 0, 4);
+        set_error("cooperative LSTM kernel: an inter-workgroup wait timed out (a workgroup was not resident); the "
+                  "results of that forward are invalid - set FSNP_LSTM_COOP=0");
+        return 5;
+    }
+    return 0;
+}
+
+int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off) or 1 (auto)"); return 1; }
+    h->lstm_coop = mode;
     return 0;
 }
 

@@ -112,6 +112,7 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
+    const float* wpack_coop; // column-split kernel: [column split][k-group][tile][lane][4] (lstm_coop.hip)
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
@@ -137,11 +138,21 @@ struct LstmArgs {
     int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
     int act;               // FSNP_ACT_* on the Linear output
     unsigned long long* prof;  // optional [Tp][8] s_memtime stamps of workgroup 0 (debug)
+    // column-split (cooperative) kernel only
+    float* coop_hx;            // per row tile: h0/h1 exchange images (double buffered) + Linear partials, zeroed per launch
+    unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
+    unsigned* coop_err;        // set to 1 if a barrier wait timed out
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+// lstm_coop.hip: column-split kernel for small batches (row_tiles * H/32 workgroups, all co-resident)
+void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t lstm_coop_pack_floats(int H, int KX, int TW);
+void lstm_coop_pack_weights(int H, int NIN, int KX, int TW, const float* wih0, const float* whh0, const float* wih1,
+                            const float* whh1, float* wpack);
+size_t lstm_coop_exchange_bytes(int H, int TW, int row_tiles);
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
 void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,

@@ -370,6 +370,18 @@ class FullSubNet_Plus(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_lstm_waves(self._handle, int(waves)), "fsnp_debug_set_lstm_waves")
 
+    def debug_set_lstm_coop(self, mode, device="cuda"):
+        """Tuning hook: 1 = use the cooperative column-split LSTM kernel for small batches (default), 0 = never."""
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        lib = self._ensure_handle(dev)
+        _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
+
+    def check_errors(self):
+        """Synchronise and raise if an earlier call failed on the device (see fsnp_check_errors)."""
+        _lib.check(_lib.load().fsnp_check_errors(self._handle), "fsnp_check_errors")
+
     def set_timing(self, enable=True):
         _lib.check(_lib.load().fsnp_set_timing(self._handle, int(bool(enable))), "fsnp_set_timing")
 

@@ -151,6 +151,15 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
+/* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
+ * inter-workgroup wait in the cooperative small-batch LSTM kernel).  0 = none. */
+int fsnp_check_errors(fsnp_handle* h);
+
+/* Tuning hook: 1 (default) = use the column-split cooperative LSTM kernel (csrc/lstm_coop.hip) whenever
+ * row_tiles * H/32 workgroups fit the chip (small batches, e.g. the reference CLI's batch of one); 0 = never
+ * (also FSNP_LSTM_COOP=0 at fsnp_create time). */
+int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
+
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
  * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the
  * environment variable FSNP_LSTM_WAVES at fsnp_create time. */
