@@ -174,9 +174,11 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
 
 // The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
 // would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
-static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) {
-    return h->lstm_coop != 0 && lp.ex == 0 && lp.num_tiles * (h->H / 32) <= h->num_cus_real;
+static int coop_tw(const fsnp_handle* h, const LstmPlan& lp) {      // 0 = use the row-tile kernel
+    if (h->lstm_coop == 0 || lp.ex != 0) return 0;
+    return lstm_coop_pick_tw(h->H, lp.num_tiles, h->num_cus_real);
 }
+static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return coop_tw(h, lp) != 0; }
 
 static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
 
@@ -207,7 +209,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gn = take((size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     const bool coop = use_coop(h, lp);
-    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles) : 0);
+    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles) : 0);   // TW = 1 is the largest image
     w.coop_bar = take(coop ? (size_t)lp.num_tiles * 4 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
@@ -421,9 +423,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
     lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                       W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
-    const size_t o_wpack_coop = alloc(lstm_coop_pack_floats(H, h->KX, 1));
-    lstm_coop_pack_weights(H, h->NIN, h->KX, 1, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                           W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop);
+    size_t o_wpack_coop[3];
+    for (int tw = 1; tw <= 3; ++tw) {
+        o_wpack_coop[tw - 1] = alloc(lstm_coop_pack_floats(H, h->KX, tw));
+        lstm_coop_pack_weights(H, h->NIN, h->KX, tw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                               W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[tw - 1]);
+    }
     const size_t o_lbias = alloc((size_t)2 * 4 * H);
     for (int l = 0; l < 2; ++l) {
         const auto& bi = W(s + "bias_ih_l" + std::to_string(l));
@@ -455,7 +460,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
     h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
-    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; h->lw.wpack_coop = d + o_wpack_coop; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
+    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int tw = 0; tw < 3; ++tw) h->lw.wpack_coop[tw] = d + o_wpack_coop[tw]; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
     h->d_refl_w = d + o_refl;
     h->committed = true;
@@ -539,6 +544,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     a.act = h->cfg.sb_act;
     if (use_coop(h, lp)) {
         a.coop_hx = fptr(w.coop_hx); a.coop_bar = reinterpret_cast<unsigned*>(base + w.coop_bar); a.coop_err = h->d_err;
+        a.coop_tw = coop_tw(h, lp);
         launch_lstm_coop(h->lw, a, s);
     } else {
         launch_lstm(h->lw, a, s);
@@ -587,6 +593,7 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
         a.coop_hx = reinterpret_cast<float*>(h->ws + coop_off);
         a.coop_bar = reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes);
         a.coop_err = h->d_err;
+        a.coop_tw = coop_tw(h, lp);
         launch_lstm_coop(h->lw, a, s);
     } else {
         launch_lstm(h->lw, a, s);

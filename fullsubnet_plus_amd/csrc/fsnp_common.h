@@ -112,7 +112,7 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
-    const float* wpack_coop; // column-split kernel: [column split][k-group][tile][lane][4] (lstm_coop.hip)
+    const float* wpack_coop[3]; // column-split kernel, 32*(i+1) units per workgroup: [split][k-group][tile][lane][4]
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
@@ -142,6 +142,7 @@ struct LstmArgs {
     float* coop_hx;            // per row tile: h0/h1 exchange images (double buffered) + Linear partials, zeroed per launch
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
     unsigned* coop_err;        // set to 1 if a barrier wait timed out
+    int coop_tw;               // 32-unit blocks per workgroup: 1, 2 or 3
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
@@ -153,6 +154,7 @@ size_t lstm_coop_pack_floats(int H, int KX, int TW);
 void lstm_coop_pack_weights(int H, int NIN, int KX, int TW, const float* wih0, const float* whh0, const float* wih1,
                             const float* whh1, float* wpack);
 size_t lstm_coop_exchange_bytes(int H, int TW, int row_tiles);
+int lstm_coop_pick_tw(int H, int row_tiles, int num_cus);   // 0 = not applicable
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
 void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,

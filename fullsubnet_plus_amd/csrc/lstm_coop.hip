@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* Xs = reinterpret_cast<float4*>(smem_raw);                     // [KGX][64] A image of x_t
-    float* red = reinterpret_cast<float*>(Xs + KGX * 64);                 // [4 waves][NT][16][64]
-    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 16 * 64); // [32]
+    float* red = reinterpret_cast<float*>(Xs + KGX * 64);                 // [4 waves][NT][12][64]
+    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 12 * 64); // [32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,18 +174,34 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
     // sum the 4 waves' partial tiles through LDS; returns, for the 4 rows this wave owns, gate pre-activations
     auto reduce_tiles = [&](f32x16 (&acc)[NT], float (&g)[NT][4]) {
         __syncthreads();                       // previous use of `red` finished
+        // wave v parks the 12 registers it does NOT own (slot j = r, or r - 4 past its own group) ...
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * NT + n) * 16 + r) * 64 + lane] = acc[n][r];
+            for (int r = 0; r < 16; ++r) {
+                const int grp = r >> 2;
+                if (grp != wave) red[((wave * NT + n) * 12 + (grp < wave ? r : r - 4)) * 64 + lane] = acc[n][r];
+            }
         __syncthreads();
+        // ... and sums, for its own 4 registers, its value with the three other waves' partials (fixed order 0..3)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = wave * 4 + q;
-                g[n][q] = red[((0 * NT + n) * 16 + r) * 64 + lane] + red[((1 * NT + n) * 16 + r) * 64 + lane] +
-                          red[((2 * NT + n) * 16 + r) * 64 + lane] + red[((3 * NT + n) * 16 + r) * 64 + lane];
+                float sum = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {          // static register index: select this wave's own value
+                        if (w2 == wave) {
+                            part = (v == wave) ? acc[n][w2 * 4 + q]
+                                               : red[((v * NT + n) * 12 + ((w2 < v) ? w2 * 4 + q : w2 * 4 + q - 4)) * 64 + lane];
+                        }
+                    }
+                    sum += part;
+                }
+                g[n][q] = sum;
             }
     };
     // rows owned by this lane for register q of the wave's group: C layout row = (r&3) + 8 (r>>2) + 4 (lane>>5), r = 4w+q
@@ -372,10 +388,11 @@ size_t lstm_coop_exchange_bytes(int H, int TW, int row_tiles) {
     return (size_t)row_tiles * (4 * (size_t)(H / 8) * 64 + 2 * (size_t)S * 16) * 16;
 }
 
-void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, KX = 40, OUT = 2, TW = 1;
+template <int TW>
+static void launch_lstm_coop_tw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int S = HID / (32 * TW), NT = 4 * TW;
-    const size_t smem = (size_t)(KX / 8) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
+    const size_t smem = (size_t)(KX / 8) * 64 * 16 + (size_t)4 * NT * 12 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_fc_coop_kernel<HID, KX, OUT, TW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -383,8 +400,22 @@ void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     LstmWeights wv = w;
-    wv.wpack = w.wpack_coop;
+    wv.wpack = w.wpack_coop[TW - 1];
     hipLaunchKernelGGL(kern, dim3(a.num_tiles * S), dim3(256), smem, s, wv, a);
+}
+
+// Largest column split (fewest units per workgroup: 32 TW, TW in {1,2,3}) whose row_tiles * H/(32 TW) workgroups
+// are all resident at once; 0 = use the row-tile kernel.
+int lstm_coop_pick_tw(int H, int row_tiles, int num_cus) {
+    for (int tw = 1; tw <= 3; ++tw)
+        if (H % (32 * tw) == 0 && row_tiles * (H / (32 * tw)) <= num_cus) return tw;
+    return 0;
+}
+
+void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (a.coop_tw == 1) launch_lstm_coop_tw<1>(w, a, s);
+    else if (a.coop_tw == 2) launch_lstm_coop_tw<2>(w, a, s);
+    else launch_lstm_coop_tw<3>(w, a, s);
 }
 
 }  // namespace fsnp
