@@ -423,8 +423,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
     lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                       W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
-    size_t o_wpack_coop[3];
-    for (int tw = 1; tw <= 3; ++tw) {
+    size_t o_wpack_coop[3] = {0, 0, 0};
+    for (int tw = 1; tw <= 2; ++tw) {
         o_wpack_coop[tw - 1] = alloc(lstm_coop_pack_floats(H, h->KX, tw));
         lstm_coop_pack_weights(H, h->NIN, h->KX, tw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                                W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[tw - 1]);

@@ -37,10 +37,12 @@ __device__ __forceinline__ float4 coop_wload(const CoopStream& ws, int group, in
 }
 
 // One layer's share of this wave: k-groups [lo, hi) of the layer, weights at stream group (wbase + g).
-// A operand of group g comes from `src(g)` (LDS or the global exchange image).  Depth-4 register pipeline.
+// A operand of group g comes from `src(g)` (LDS or the global exchange image).  Register pipeline D groups deep:
+// a k-group lasts NT * 256 cycles, so D = 4 (one tile quad per wave) or 2 (two / three) keeps >= 4096 cycles of loads
+// in flight without spilling.
 template <int NT, typename ASrc>
 __device__ __forceinline__ void coop_layer(f32x16 (&acc)[NT], const CoopStream& ws, int wbase, int lo, int hi, ASrc src) {
-    constexpr int D = 4;
+    constexpr int D = NT <= 4 ? 4 : 2;
     float4 a[D];
     float4 b[D][NT];
 #pragma unroll
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* Xs = reinterpret_cast<float4*>(smem_raw);                     // [KGX][64] A image of x_t
-    float* red = reinterpret_cast<float*>(Xs + KGX * 64);                 // [4 waves][NT][12][64]
-    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 12 * 64); // [32]
+    float* red = reinterpret_cast<float*>(Xs + KGX * 64);                 // [4 waves][NT][16][64]
+    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 16 * 64); // [32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,13 +160,9 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
     for (int s = 0; s < TW; ++s)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { c0[s][q] = 0.f; c1[s][q] = 0.f; }
-    float bias0[NT], bias1[NT], wfc0[TW], wfc1[TW];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int gr = (n / TW) * HID + cs * 32 * TW + (n % TW) * 32 + (lane & 31);
-        bias0[n] = w.bias[gr];
-        bias1[n] = w.bias[4 * HID + gr];
-    }
+    float wfc0[TW], wfc1[TW];
+    const float* __restrict__ bias_l0 = w.bias + cs * 32 * TW + (lane & 31);             // + gate * HID + s * 32
+    const float* __restrict__ bias_l1 = w.bias + 4 * HID + cs * 32 * TW + (lane & 31);
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
         wfc0[s] = w.wfc[cs * 32 * TW + s * 32 + (lane & 31)];
@@ -174,34 +172,18 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
     // sum the 4 waves' partial tiles through LDS; returns, for the 4 rows this wave owns, gate pre-activations
     auto reduce_tiles = [&](f32x16 (&acc)[NT], float (&g)[NT][4]) {
         __syncthreads();                       // previous use of `red` finished
-        // wave v parks the 12 registers it does NOT own (slot j = r, or r - 4 past its own group) ...
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int grp = r >> 2;
-                if (grp != wave) red[((wave * NT + n) * 12 + (grp < wave ? r : r - 4)) * 64 + lane] = acc[n][r];
-            }
+            for (int r = 0; r < 16; ++r) red[((wave * NT + n) * 16 + r) * 64 + lane] = acc[n][r];
         __syncthreads();
-        // ... and sums, for its own 4 registers, its value with the three other waves' partials (fixed order 0..3)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float sum = 0.f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float part = 0.f;
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {          // static register index: select this wave's own value
-                        if (w2 == wave) {
-                            part = (v == wave) ? acc[n][w2 * 4 + q]
-                                               : red[((v * NT + n) * 12 + ((w2 < v) ? w2 * 4 + q : w2 * 4 + q - 4)) * 64 + lane];
-                        }
-                    }
-                    sum += part;
-                }
-                g[n][q] = sum;
+                const int r = wave * 4 + q;
+                g[n][q] = red[((0 * NT + n) * 16 + r) * 64 + lane] + red[((1 * NT + n) * 16 + r) * 64 + lane] +
+                          red[((2 * NT + n) * 16 + r) * 64 + lane] + red[((3 * NT + n) * 16 + r) * 64 + lane];
             }
     };
     // rows owned by this lane for register q of the wave's group: C layout row = (r&3) + 8 (r>>2) + 4 (lane>>5), r = 4w+q
@@ -261,12 +243,13 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
 #pragma unroll
             for (int s = 0; s < TW; ++s) {
                 const int k = cs * 32 * TW + s * 32 + (lane & 31);
+                const float bi = bias_l0[s * 32], bf = bias_l0[HID + s * 32], bg = bias_l0[2 * HID + s * 32], bo = bias_l0[3 * HID + s * 32];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float ig = fast_sigmoid(g[s][q] + bias0[s]);
-                    const float fg = fast_sigmoid(g[TW + s][q] + bias0[TW + s]);
-                    const float gg = fast_tanh(g[2 * TW + s][q] + bias0[2 * TW + s]);
-                    const float og = fast_sigmoid(g[3 * TW + s][q] + bias0[3 * TW + s]);
+                    const float ig = fast_sigmoid(g[s][q] + bi);
+                    const float fg = fast_sigmoid(g[TW + s][q] + bf);
+                    const float gg = fast_tanh(g[2 * TW + s][q] + bg);
+                    const float og = fast_sigmoid(g[3 * TW + s][q] + bo);
                     const float cn = fg * c0[s][q] + ig * gg;
                     c0[s][q] = cn;
                     img[a_frag_index(own_row(q), k)] = og * fast_tanh(cn);
@@ -309,12 +292,13 @@ __global__ __launch_bounds__(256) void lstm2_fc_coop_kernel(LstmWeights w, LstmA
 #pragma unroll
             for (int s = 0; s < TW; ++s) {
                 const int k = cs * 32 * TW + s * 32 + (lane & 31);
+                const float bi = bias_l1[s * 32], bf = bias_l1[HID + s * 32], bg = bias_l1[2 * HID + s * 32], bo = bias_l1[3 * HID + s * 32];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float ig = fast_sigmoid(g[s][q] + bias1[s]);
-                    const float fg = fast_sigmoid(g[TW + s][q] + bias1[TW + s]);
-                    const float gg = fast_tanh(g[2 * TW + s][q] + bias1[2 * TW + s]);
-                    const float og = fast_sigmoid(g[3 * TW + s][q] + bias1[3 * TW + s]);
+                    const float ig = fast_sigmoid(g[s][q] + bi);
+                    const float fg = fast_sigmoid(g[TW + s][q] + bf);
+                    const float gg = fast_tanh(g[2 * TW + s][q] + bg);
+                    const float og = fast_sigmoid(g[3 * TW + s][q] + bo);
                     const float cn = fg * c1[s][q] + ig * gg;
                     c1[s][q] = cn;
                     const float h = og * fast_tanh(cn);
@@ -392,7 +376,7 @@ template <int TW>
 static void launch_lstm_coop_tw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int S = HID / (32 * TW), NT = 4 * TW;
-    const size_t smem = (size_t)(KX / 8) * 64 * 16 + (size_t)4 * NT * 12 * 64 * 4 + 32 * sizeof(RowDesc);
+    const size_t smem = (size_t)(KX / 8) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_fc_coop_kernel<HID, KX, OUT, TW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -404,18 +388,17 @@ static void launch_lstm_coop_tw(const LstmWeights& w, const LstmArgs& a, hipStre
     hipLaunchKernelGGL(kern, dim3(a.num_tiles * S), dim3(256), smem, s, wv, a);
 }
 
-// Largest column split (fewest units per workgroup: 32 TW, TW in {1,2,3}) whose row_tiles * H/(32 TW) workgroups
-// are all resident at once; 0 = use the row-tile kernel.
+// Largest column split (fewest units per workgroup: 32 TW, TW in {1,2}) whose row_tiles * H/(32 TW) workgroups
+// are all resident at once; 0 = use the row-tile kernel.  (TW = 3 would need 192 KB of LDS for the partial tiles.)
 int lstm_coop_pick_tw(int H, int row_tiles, int num_cus) {
-    for (int tw = 1; tw <= 3; ++tw)
+    for (int tw = 1; tw <= 2; ++tw)
         if (H % (32 * tw) == 0 && row_tiles * (H / (32 * tw)) <= num_cus) return tw;
     return 0;
 }
 
 void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (a.coop_tw == 1) launch_lstm_coop_tw<1>(w, a, s);
-    else if (a.coop_tw == 2) launch_lstm_coop_tw<2>(w, a, s);
-    else launch_lstm_coop_tw<3>(w, a, s);
+    else launch_lstm_coop_tw<2>(w, a, s);
 }
 
 }  // namespace fsnp
