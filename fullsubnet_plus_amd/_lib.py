@@ -43,6 +43,7 @@ SYMBOLS = {
     "fsnp_forward_flops": (ctypes.c_double, [c_vp, c_i32, c_i32, c_i32]),
     "fsnp_lstm_flops": (ctypes.c_double, [c_vp, c_i64, c_i32]),
     "fsnp_debug_lstm_profile": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64]),
+    "fsnp_set_precision": (c_i32, [c_vp, c_i32]),
     "fsnp_check_errors": (c_i32, [c_vp]),
     "fsnp_debug_set_lstm_coop": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_lstm_waves": (c_i32, [c_vp, c_i32]),

@@ -66,6 +66,7 @@ struct fsnp_handle {
     bool debug = false;
     int num_cus = 256;
     int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
+    int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in the cooperative LSTM kernel
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
@@ -175,7 +176,7 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
 // The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
 // would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
 static int coop_tw(const fsnp_handle* h, const LstmPlan& lp) {      // 0 = use the row-tile kernel
-    if (h->lstm_coop == 0 || lp.ex != 0) return 0;
+    if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return 0;   // the cooperative kernel is fp32 only
     return lstm_coop_pick_tw(h->H, lp.num_tiles, h->num_cus_real);
 }
 static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return coop_tw(h, lp) != 0; }
@@ -423,6 +424,13 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
     lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                       W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
+    size_t o_wpack_bf[2];
+    for (int i = 0; i < 2; ++i) {
+        const int nw = i == 0 ? 4 : 12;
+        o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
+        lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                                 W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_bf[i]);
+    }
     size_t o_wpack_coop[3] = {0, 0, 0};
     for (int tw = 1; tw <= 2; ++tw) {
         o_wpack_coop[tw - 1] = alloc(lstm_coop_pack_floats(H, h->KX, tw));
@@ -460,7 +468,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
     h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
-    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int tw = 0; tw < 3; ++tw) h->lw.wpack_coop[tw] = d + o_wpack_coop[tw]; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
+    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int tw = 0; tw < 3; ++tw) h->lw.wpack_coop[tw] = d + o_wpack_coop[tw];
+    h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
     h->d_refl_w = d + o_refl;
     h->committed = true;
@@ -675,6 +684,13 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     launch_lstm(h->lw, a, 0);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     FSNP_HIP_CHECK(hipMemcpy(host_stamps, dprof, (size_t)num_stamps * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
+    if (!h || (ih_bf16 != 0 && ih_bf16 != 1)) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM)"); return 1; }
+    h->ih_bf16 = ih_bf16;
+    h->lw.ih_bf16 = ih_bf16;
     return 0;
 }
 

@@ -112,6 +112,8 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
+    const float* wpack_bf[2];   // bf16-ih streams (4-wave, 12-wave): layer-1 W_ih as bf16 k-steps (configs[4])
+    int ih_bf16;                // 1 = use them
     const float* wpack_coop[3]; // column-split kernel, 32*(i+1) units per workgroup: [split][k-group][tile][lane][4]
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
@@ -157,6 +159,9 @@ size_t lstm_coop_exchange_bytes(int H, int TW, int row_tiles);
 int lstm_coop_pick_tw(int H, int row_tiles, int num_cus);   // 0 = not applicable
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
+size_t lstm_pack_floats_bf16ih(int H, int KX, int NW);
+void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
+                              const float* whh1, float* wpack);
 void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
                        const float* whh1, float* wpack);
 

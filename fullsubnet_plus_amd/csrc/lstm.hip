@@ -32,6 +32,8 @@
 //                 are almost free; they exist to kill the tail: B=32 gives 8224 = 257 x 32 sequences,
 //                 i.e. one tile more than the chip has CUs - 33-row tiles finish in ONE round instead of two.
 // fp32 throughout: v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain.
+#include <cstring>
+
 #include "fsnp_common.h"
 #include "lstm_common.h"
 
@@ -124,9 +126,20 @@ __device__ __forceinline__ void mfma_groups(f32x16 (&acc)[NT], float (&accx)[EX 
     }
 }
 
+// bf16 (round-to-nearest-even) bits of an fp32 value
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+// index (in 2-byte elements) of element (row, k) inside the bf16 A image of v_mfma_f32_32x32x16_bf16:
+// [k-step of 16][k half of 8][row][8]  - lane l of a step reads the 16 bytes of (half l>>5, row l&31)
+__host__ __device__ __forceinline__ int a_frag_index_bf16(int row, int k) {
+    return (((k >> 4) * 64) + (((k >> 3) & 1) * 32) + row) * 8 + (k & 7);
+}
+
 template <int ST, int UW>
 __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST], float* __restrict__ Hs, int wave,
-                                          int lane) {
+                                          int lane, unsigned short* __restrict__ Hb = nullptr) {
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
         const int k = wave * UW + s * 32 + (lane & 31);
@@ -140,8 +153,57 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST]
             const float cn = fg * c[s][r] + ig * gg;
             c[s][r] = cn;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            Hs[kbase + row * 4] = og * fast_tanh(cn);
+            const float h = og * fast_tanh(cn);
+            Hs[kbase + row * 4] = h;
+            if (Hb) Hb[a_frag_index_bf16(row, k)] = bf16_bits(h);
         }
+    }
+}
+
+// bf16 ih-GEMM segment (BASELINE.json configs[4]): `nsteps` k-steps of 16, ONE v_mfma_f32_32x32x16_bf16 per tile and
+// step (fp32 accumulate into the same tiles), operands = bf16 A image of h0_t in LDS and bf16 weight fragments that
+// travel through the same 16-byte-per-lane register pipeline as the fp32 groups.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+template <int NT, int EX>
+__device__ __forceinline__ void mfma_groups_bf16(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
+                                                 const float4* __restrict__ A, const float4* __restrict__ AE, int nsteps,
+                                                 const WStream& ws, int& gnext, int groups_total, int lane) {
+    float4 a = A[0];
+    for (int g = 0; g < nsteps; ++g) {
+        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64];
+        // VALU rows: this lane's 8 weights of tile n are k = 16 g + 8 (lane>>5) + j, i.e. fp32 k-group 2g + (lane>>5)
+        // of the E image (kh = 0: j even, kh = 1: j odd)
+        float4 he[EX > 0 ? EX : 1][2];
+        if constexpr (EX > 0) {
+            const int kg = 2 * g + (lane >> 5);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) { he[e][0] = AE[(kg * 2 + 0) * EX + e]; he[e][1] = AE[(kg * 2 + 1) * EX + e]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if constexpr (EX > 0) {
+                const unsigned w0 = __float_as_uint(b[n].x), w1 = __float_as_uint(b[n].y), w2 = __float_as_uint(b[n].z),
+                               w3 = __float_as_uint(b[n].w);
+#pragma unroll
+                for (int e = 0; e < EX; ++e) {
+                    float v = accx[e][n];
+                    v = fmaf(he[e][0].x, __uint_as_float(w0 << 16), v);
+                    v = fmaf(he[e][1].x, __uint_as_float(w0 & 0xFFFF0000u), v);
+                    v = fmaf(he[e][0].y, __uint_as_float(w1 << 16), v);
+                    v = fmaf(he[e][1].y, __uint_as_float(w1 & 0xFFFF0000u), v);
+                    v = fmaf(he[e][0].z, __uint_as_float(w2 << 16), v);
+                    v = fmaf(he[e][1].z, __uint_as_float(w2 & 0xFFFF0000u), v);
+                    v = fmaf(he[e][0].w, __uint_as_float(w3 << 16), v);
+                    accx[e][n] = fmaf(he[e][1].w, __uint_as_float(w3 & 0xFFFF0000u), v);
+                }
+            }
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[n]),
+                                                             acc[n], 0, 0, 0);
+            b[n] = wload<NT>(ws, gnext, n);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
+        a = an;
     }
 }
 
@@ -167,7 +229,7 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
         }
 }
 
-template <int HID, int KX, int OUT, int EX, bool PROF, int NW>
+template <int HID, int KX, int OUT, int EX, bool PROF, int NW, bool BF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
@@ -176,8 +238,11 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     constexpr int NTHR = 64 * NW;
     constexpr int UW = HID / NW, ST = UW / 32, NT = 4 * ST;   // hidden units, 32-unit blocks, tiles per wave
     static_assert(UW % 32 == 0 && UW * NW == HID, "hidden/NW must be a multiple of 32");
-    constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH, KG1 = 2 * KGH, KGT = KG0 + KG1;
+    constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH;
+    constexpr int KSB = HID / 16;                                   // bf16 k-steps of the layer-1 ih segment (BF only)
+    constexpr int KG1 = BF ? KGH + KSB : 2 * KGH, KGT = KG0 + KG1;   // weight-stream groups per step
     static_assert(KGH % 4 == 0, "FC k-split");
+    static_assert(!BF || HID % 16 == 0, "bf16 k-steps");
     constexpr int RT = 32 + EX;                 // row slots per tile
     constexpr int EXA = EX > 0 ? EX : 1;
 
@@ -191,6 +256,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     float4* Wfc4 = HE1s + KGH * 2 * EX;                  // [OUT][KGH][2]
     RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [RT]
     float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [2][NW][NT][32]
+    float4* H0b = reinterpret_cast<float4*>(Bs + 2 * NW * NT * 32);      // BF: [KSB][64] bf16 A image of h0_t
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -386,7 +452,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         FSNP_STAMP(1);
         __syncthreads();
         FSNP_STAMP(2);
-        lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
+        lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
         if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
         if (have_next) {
 #pragma unroll
@@ -407,7 +473,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
         run_groups(acc, accx, H1s + lane, AEh1, KGH);
-        run_groups(acc, accx, H0s + lane, AEh0, KGH);
+        if constexpr (BF) mfma_groups_bf16<NT, EX>(acc, accx, breg, H0b + lane, HE0s, KSB, ws, gnext, KGT, lane);
+        else run_groups(acc, accx, H0s + lane, AEh0, KGH);
         FSNP_STAMP(5);
         __syncthreads();
         FSNP_STAMP(6);
@@ -454,22 +521,68 @@ void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const 
                     }
 }
 
-template <int EX, int NW>
+// bf16-ih variant of the stream: layer 0 and the h1 part of layer 1 as above (fp32), then HID/16 bf16 k-steps of
+// W_ih1: lane l of step ks / tile n holds the 8 weights k = 16 ks + 8 (l>>5) + j of its column, 2 bytes each.
+size_t lstm_pack_floats_bf16ih(int H, int KX, int NW) {
+    const int NT = 4 * (H / NW / 32);
+    const int KGT = KX / 8 + H / 8 + H / 8 + H / 16;
+    return (size_t)NW * KGT * NT * 64 * 4;
+}
+
+static unsigned short host_bf16(float v) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
+                              const float* whh1, float* wpack) {
+    const int UW = H / NW, ST = UW / 32, NT = 4 * ST;
+    const int KGX = KX / 8, KGH = H / 8, KG0 = KGX + KGH, KSB = H / 16, KGT = KG0 + KGH + KSB;
+    for (int wv = 0; wv < NW; ++wv)
+        for (int g = 0; g < KGT; ++g)
+            for (int n = 0; n < NT; ++n)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int gate = n / ST, s = n % ST;
+                    const int wrow = gate * H + wv * UW + s * 32 + (lane & 31);
+                    float* dst = wpack + ((((size_t)wv * KGT + g) * NT + n) * 64 + lane) * 4;
+                    if (g < KG0 + KGH) {
+                        for (int p = 0; p < 4; ++p) {
+                            float v = 0.0f;
+                            if (g < KG0) {
+                                const int k = 8 * g + 2 * p + (lane >> 5);
+                                if (k < KX) { if (k < NIN) v = wih0[(size_t)wrow * NIN + k]; }
+                                else v = whh0[(size_t)wrow * H + (k - KX)];
+                            } else {
+                                const int k = 8 * (g - KG0) + 2 * p + (lane >> 5);
+                                v = whh1[(size_t)wrow * H + k];
+                            }
+                            dst[p] = v;
+                        }
+                    } else {
+                        const int ks = g - KG0 - KGH;
+                        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+                        for (int j = 0; j < 8; ++j) d16[j] = host_bf16(wih1[(size_t)wrow * H + 16 * ks + 8 * (lane >> 5) + j]);
+                    }
+                }
+}
+
+template <int EX, int NW, bool BF>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
-                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4;
+                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4 + (BF ? (size_t)(HID / 16) * 64 * 16 : 0);
     LstmWeights wv = w;
-    wv.wpack = NW == 12 ? w.wpack12 : w.wpack;
+    wv.wpack = BF ? (NW == 12 ? w.wpack_bf[1] : w.wpack_bf[0]) : (NW == 12 ? w.wpack12 : w.wpack);
     if (a.prof != nullptr) {
-        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW>;
+        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW, BF>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
         return;
     }
     static bool attr_set = false;
-    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW>;
+    auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW, BF>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -477,13 +590,13 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
     hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
 }
 
-template <int NW>
+template <int NW, bool BF>
 static void launch_lstm_nw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     switch (a.ex) {
-        case 0: launch_lstm_ex<0, NW>(w, a, s); break;
-        case 1: launch_lstm_ex<1, NW>(w, a, s); break;
-        case 2: launch_lstm_ex<2, NW>(w, a, s); break;
-        default: launch_lstm_ex<4, NW>(w, a, s); break;
+        case 0: launch_lstm_ex<0, NW, BF>(w, a, s); break;
+        case 1: launch_lstm_ex<1, NW, BF>(w, a, s); break;
+        case 2: launch_lstm_ex<2, NW, BF>(w, a, s); break;
+        default: launch_lstm_ex<4, NW, BF>(w, a, s); break;
     }
 }
 
@@ -492,8 +605,13 @@ void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     // measured (profiles/r01_lstm_phase_ab.md): with VALU rows the 12-wave shape is 10 % faster, without them
     // both shapes tie and the 4-wave one needs no spills
     const int waves = w.waves != 0 ? w.waves : (a.ex > 0 ? 12 : 4);
-    if (waves == 12) launch_lstm_nw<12>(w, a, s);
-    else launch_lstm_nw<4>(w, a, s);
+    if (w.ih_bf16) {
+        if (waves == 12) launch_lstm_nw<12, true>(w, a, s);
+        else launch_lstm_nw<4, true>(w, a, s);
+    } else {
+        if (waves == 12) launch_lstm_nw<12, false>(w, a, s);
+        else launch_lstm_nw<4, false>(w, a, s);
+    }
 }
 
 // Tile plan: a tile = 32 MFMA rows + up to ex VALU rows.  All tiles cost the same time whatever their

@@ -378,6 +378,15 @@ class FullSubNet_Plus(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
+    def set_precision(self, mode, device="cuda"):
+        """"fp32" (default) or "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16)."""
+        assert mode in ("fp32", "bf16_ih")
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        lib = self._ensure_handle(dev)
+        _lib.check(lib.fsnp_set_precision(self._handle, int(mode == "bf16_ih")), "fsnp_set_precision")
+
     def check_errors(self):
         """Synchronise and raise if an earlier call failed on the device (see fsnp_check_errors)."""
         _lib.check(_lib.load().fsnp_check_errors(self._handle), "fsnp_check_errors")

@@ -151,6 +151,12 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                             uint64_t* host_stamps, int64_t num_stamps);
 
+/* BASELINE.json configs[4]: 0 = fp32 everywhere (default, the headline path); 1 = the layer-1 input-to-hidden GEMM of
+ * the sub-band LSTM (W_ih_l1 x h0_t, 32 % of the LSTM FLOPs) runs on v_mfma_f32_32x32x16_bf16 with bf16 operands
+ * and fp32 accumulation; the recurrent GEMMs, layer 0, the cell and everything else stay fp32.  Tolerance of this
+ * mode vs the fp32 reference: 2e-2 rel (tests/test_gpu_parity.py::test_bf16_ih_variant). */
+int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
+
 /* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
  * inter-workgroup wait in the cooperative small-batch LSTM kernel).  0 = none. */
 int fsnp_check_errors(fsnp_handle* h);

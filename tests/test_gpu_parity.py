@@ -213,6 +213,42 @@ def test_enhance_epilogue_vs_oracle():
     assert got.shape == want.shape and err < TOL, err
 
 
+@pytest.mark.parametrize("n,cus", [(700, 256), (257, 8), (8192 + 32, 256)])
+def test_bf16_ih_variant(n, cus):
+    """BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM on bf16 MFMA (fp32 accumulate), everything else
+    fp32.  Tolerance re-stated against the fp32 oracle: 2e-2 rel (bf16 has 8 mantissa bits: h0 and W_ih_l1 are each
+    rounded to ~4e-3 relative); the fp32 path on the same inputs must stay at 2e-5."""
+    sd = make_state_dict(10, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    m.debug_set_num_cus(cus)
+    m.debug_set_lstm_coop(0)
+    steps = 24
+    rng = np.random.Generator(np.random.PCG64(55 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    m.set_precision("bf16_ih")
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    err = rel_err(got, want)
+    m.set_precision("fp32")
+    got32 = m.lstm2_fc(x.cuda()).cpu().numpy()
+    _record(f"bf16_ih_{n}_cus{cus}", rel_bf16=err, rel_fp32=rel_err(got32, want))
+    assert rel_err(got32, want) < 2e-5
+    assert 1e-6 < err < 2e-2, err            # must differ from fp32 (the mode is really on) and stay inside the stated bound
+
+
+def test_bf16_ih_forward_b32():
+    sd = make_state_dict(0, "default")
+    mag, real, imag = make_inputs(32, 2.0, 100)
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    ins = _cuda((mag, real, imag))
+    ref = m(*ins).cpu().numpy()
+    m.set_precision("bf16_ih")
+    got = m(*ins).cpu().numpy()
+    err = rel_err(got, ref)
+    _record("bf16_ih_forward_b32_vs_fp32_hip", rel=err)
+    assert 1e-6 < err < 2e-2, err
+
+
 def test_batch2_raises_like_reference():
     g = Golden("b4_t16_default")
     m = _model(g.args, g.state_dict(), "parity")

@@ -172,11 +172,15 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.analyse()
-    assert len(res) >= 8
+    assert len(res) >= 16
     for key, loops in res.items():
-        assert len(loops) == 3, (key, loops)                      # layer 0, layer 1 (h1 part), layer 1 (h0 part)
-        for l in loops:
+        # layer 0, layer 1 (h1 part), layer 1 (h0 part: fp32 groups, or bf16 k-steps which hipcc may fully unroll)
+        assert len(loops) == 3 or (key.endswith("_BF1") and len(loops) == 2), (key, loops)
+        for i, l in enumerate(loops):
             assert l["scratch"] == 0, (key, l)
+            if key.endswith("_BF1") and i == 2:       # bf16 segment: one MFMA and one refill per tile and k-step
+                assert l["gload"] == l["mfma"], (key, l)
+                continue
             assert l["mfma"] % 16 == 0 and l["gload"] * 4 == l["mfma"], (key, l)
-            if "_NW4" in key and ("_EX0_" in key or "_EX1_" in key):   # the production kernels
+            if "_NW4_" in key and ("_EX0_" in key or "_EX1_" in key):   # the production fp32 kernels
                 assert l["drain"] == 0, (key, l)

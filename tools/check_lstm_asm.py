@@ -23,8 +23,8 @@ def analyse(flags=("-fno-slp-vectorize",)):
     res = {}
     for m in re.finditer(r"^(_ZN4fsnp15lstm2_fc_kernelI\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
-        tag = re.search(r"Li384ELi(\d+)ELi2ELi(\d)ELb(\d)ELi(\d+)E", name)
-        key = f"KX{tag.group(1)}_EX{tag.group(2)}_PROF{tag.group(3)}_NW{tag.group(4)}"
+        tag = re.search(r"Li384ELi(\d+)ELi2ELi(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
+        key = f"KX{tag.group(1)}_EX{tag.group(2)}_PROF{tag.group(3)}_NW{tag.group(4)}_BF{tag.group(5)}"
         loops = []
         for i, l in enumerate(body):
             if "Inner Loop Header: Depth=2" not in l:
