@@ -319,4 +319,18 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
                        d.F, d.FP);
 }
 
+// speech_enhance/fullsubnet/model/fullsubnet.py:82-89: pad the look-ahead, norm(noisy_mag) - one branch, no attention.
+void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3],
+                         const FrontendBuffers& buf, hipStream_t s) {
+    StridedIn si;
+    for (int i = 0; i < 3; ++i) {
+        si.p[i] = mag;
+        si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2];
+    }
+    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw,
+                       d.B, d.T, d.Tp, d.F, d.FP);
+    hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 1), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
+    hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 1), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
+}
+
 }  // namespace fsnp

@@ -32,8 +32,8 @@ struct WeightSpec {
 
 struct Workspace {
     // offsets in bytes from the workspace base
-    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, frame, zero_begin, fsum, gn, sb_acc, coop_hx, coop_bar, zero_end,
-        dbg_tcn0, total;
+    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, zero_begin, fsum, gn, sb_acc, coop_hx, coop_bar,
+        fb_hx, fb_bar, zero_end, dbg_tcn0, total;
 };
 
 struct TimingRec {
@@ -56,6 +56,13 @@ struct fsnp_handle {
     FrontendWeights fw{};
     TcnWeights tw{};
     LstmWeights lw{};
+    // original FullSubNet only: full-band 2-layer LSTM(F -> CH) (cooperative kernel) + Linear(CH, F) (GEMM)
+    int model = FSNP_MODEL_FULLSUBNET_PLUS;
+    int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
+    LstmWeights fbw{};
+    const float* fsn_wf = nullptr;   // [F pad 384][CH pad 16]
+    const float* fsn_bf = nullptr;   // [F pad 384]
+    int fsn_kp = 0;
     const float* d_refl_w = nullptr;
 
     unsigned char* ws = nullptr;
@@ -90,7 +97,21 @@ static void build_specs(fsnp_handle* h) {
     auto add = [&](const std::string& n, int64_t numel) { h->specs.push_back({n, numel}); };
     const int F = h->F, CH = h->CH, H = h->H, Fr = h->Fr;
     const int att = h->cfg.attention;
-    for (int a = 0; a < 3; ++a) {
+    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
+    if (fsn) {   // fullsubnet.py:39-47: SequenceModel(257 -> 512 x 2 -> 257), same key layout as nn.LSTM
+        const std::string f = "fb_model.sequence_model.";
+        add(f + "weight_ih_l0", (int64_t)4 * CH * F);
+        add(f + "weight_hh_l0", (int64_t)4 * CH * CH);
+        add(f + "bias_ih_l0", 4 * CH);
+        add(f + "bias_hh_l0", 4 * CH);
+        add(f + "weight_ih_l1", (int64_t)4 * CH * CH);
+        add(f + "weight_hh_l1", (int64_t)4 * CH * CH);
+        add(f + "bias_ih_l1", 4 * CH);
+        add(f + "bias_hh_l1", 4 * CH);
+        add("fb_model.fc_output_layer.weight", (int64_t)F * CH);
+        add("fb_model.fc_output_layer.bias", F);
+    }
+    for (int a = 0; a < 3 && !fsn; ++a) {
         const std::string p = kAtt[a];
         if (att == FSNP_ATT_TSSE) {
             for (int c = 0; c < 3; ++c) {
@@ -109,7 +130,7 @@ static void build_specs(fsnp_handle* h) {
             add(p + ".fc2.bias", F);
         }
     }
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 3 && !fsn; ++b) {
         for (int i = 0; i < h->NB; ++i) {
             const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
             add(p + ".conv1x1.weight", (int64_t)CH * F);
@@ -175,43 +196,54 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
 
 // The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
 // would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
-static int coop_tw(const fsnp_handle* h, const LstmPlan& lp) {      // 0 = use the row-tile kernel
+static int coop_units(const fsnp_handle* h, const LstmPlan& lp) {   // hidden units per workgroup; 0 = use the row-tile kernel
     if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return 0;   // the cooperative kernel is fp32 only
-    return lstm_coop_pick_tw(h->H, lp.num_tiles, h->num_cus_real);
+    return lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
 }
-static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return coop_tw(h, lp) != 0; }
+static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return coop_units(h, lp) != 0; }
+// full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
+static int fb_row_tiles(int B) { return cdiv(B, 32); }
+static int fb_coop_units(const fsnp_handle* h, int B) {
+    const int u = lstm_coop_pick_units(h->CH, fb_row_tiles(B), h->num_cus_real, 8);
+    return u > 32 ? 0 : u;
+}
 
 static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
 
 static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     Workspace w{};
     const size_t Tp = (size_t)T + h->cfg.look_ahead;
-    const size_t xb = (size_t)3 * B * Tp * h->FP * 4;
-    const size_t yb = (size_t)3 * B * Tp * h->CH * 4;
+    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
+    const size_t nbr = fsn ? 1 : 3;
+    const size_t xb = nbr * B * Tp * h->FP * 4;
+    const size_t yb = nbr * B * Tp * h->CH * 4;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    w.att = take(xb);
+    w.att = take(xb);                     // FullSubNet: the padded raw magnitude lives here (no attention stage)
     w.fb = take(xb);
-    w.raw = take(xb);
-    w.x = take(xb);
-    w.y1 = take(yb);
-    w.y2 = take(yb);
-    w.gate = take((size_t)3 * B * h->FP * 4);
-    w.md = take((size_t)3 * B * Tp * sizeof(NormMD));
+    w.raw = take(fsn ? 0 : xb);
+    w.x = take(fsn ? 0 : xb);
+    w.y1 = take(yb);                      // FullSubNet: h1 sequence of the full-band LSTM [B][Tp][CH]
+    w.y2 = take(fsn ? 0 : yb);
+    w.gate = take(fsn ? 0 : (size_t)3 * B * h->FP * 4);
+    w.md = take(nbr * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
     const LstmPlan lp = plan_lstm_tiles(B * rows_per_utt(h, mode), h->num_cus);
     const size_t nrows_pad = (size_t)lp.num_tiles * lp.rows_per_slot_tile;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
     w.rows = take(nrows_pad * sizeof(RowDesc));
-    w.frame = take((size_t)3 * B * Tp * 2 * 8);
+    w.fb_rows = take(fsn ? (size_t)fb_row_tiles(B) * 32 * sizeof(RowDesc) : 0);
+    w.frame = take(nbr * B * Tp * 2 * 8);
     w.zero_begin = o;
-    w.fsum = take((size_t)3 * B * h->FP * 8);
-    w.gn = take((size_t)h->NB * 2 * 3 * B * 2 * 8);
+    w.fsum = take(fsn ? 0 : (size_t)3 * B * h->FP * 8);
+    w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     const bool coop = use_coop(h, lp);
-    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles) : 0);   // TW = 1 is the largest image
+    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, lp.num_tiles) : 0);
     w.coop_bar = take(coop ? (size_t)lp.num_tiles * 4 : 0);
+    w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
+    w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
     w.total = o;
@@ -234,6 +266,10 @@ static double tcn_flops_per_frame(const fsnp_handle* h) {
     const double F = h->F, CH = h->CH;
     return h->NB * (2.0 * F * CH + 2.0 * CH * 3 + 2.0 * CH * F) + 2.0 * F * F;
 }
+static double fb_lstm_flops_per_frame(const fsnp_handle* h) {   // original FullSubNet: LSTM(F, CH) x 2 + Linear(CH, F)
+    const double F = h->F, CH = h->CH;
+    return 2.0 * 4 * CH * (F + CH) + 2.0 * 4 * CH * (2 * CH) + 2.0 * CH * F;
+}
 
 }  // namespace fsnp
 
@@ -252,7 +288,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
     if (cfg->attention < 0 || cfg->attention > 3) { set_error("unknown attention model %d", cfg->attention); return 2; }
-    const int nin = 2 * cfg->sb_num_neighbors + 1 + 3;
+    if (cfg->model != FSNP_MODEL_FULLSUBNET_PLUS && cfg->model != FSNP_MODEL_FULLSUBNET) { set_error("unknown model %d", cfg->model); return 2; }
+    const bool fsn = cfg->model == FSNP_MODEL_FULLSUBNET;
+    if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
+    if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
+    const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3);
     if (nin > 40) { set_error("sb_num_neighbors too large for the KX=40 LSTM instantiation"); return 2; }
     if (cfg->num_freqs <= cfg->sb_num_neighbors) { set_error("num_freqs must exceed sb_num_neighbors (reflect pad)"); return 2; }
     for (int c = 0; c < 3; ++c)
@@ -275,6 +315,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->device = dev;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->num_cus_real = h->num_cus;
+    h->model = cfg->model;
+    h->NFB = fsn ? 1 : 3;
     h->F = cfg->num_freqs;
     h->FP = (int)align_up(cfg->num_freqs, 4);
     h->CH = cfg->tcn_hidden;
@@ -282,7 +324,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->NSB = 2 * cfg->sb_num_neighbors + 1;
     h->NIN = nin;
     h->KX = 40;
-    h->NB = cfg->num_tcn_blocks;
+    h->NB = fsn ? 0 : cfg->num_tcn_blocks;
     h->Fr = cfg->num_freqs / 2;
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
@@ -352,7 +394,9 @@ int fsnp_commit_weights(fsnp_handle* h) {
     size_t o_conv_w[3][3] = {}, o_conv_b[3][3] = {}, o_cat_w[3] = {}, o_cat_b[3] = {}, o_fc1w[3] = {}, o_fc1b[3] = {},
            o_fc2w[3] = {}, o_fc2b[3] = {};
     const int att = h->cfg.attention;
-    for (int a = 0; a < 3; ++a) {
+    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
+    const int nbr_w = fsn ? 0 : 3;          // the original FullSubNet has neither attention nor TCN branches
+    for (int a = 0; a < nbr_w; ++a) {
         const std::string p = kAtt[a];
         if (att == FSNP_ATT_TSSE) {
             for (int c = 0; c < 3; ++c) {
@@ -387,7 +431,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_g2w = alloc((size_t)3 * NB * CH), o_g2b = alloc((size_t)3 * NB * CH);
     const size_t o_w2 = alloc((size_t)3 * NB * N2P * K2P), o_b2 = alloc((size_t)3 * NB * N2P);
     const size_t o_wf = alloc((size_t)3 * N2P * K1P), o_bf = alloc((size_t)3 * N2P);
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < nbr_w; ++b) {
         for (int i = 0; i < NB; ++i) {
             const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
             const size_t bi = (size_t)b * NB + i;
@@ -431,11 +475,38 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                                  W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_bf[i]);
     }
-    size_t o_wpack_coop[3] = {0, 0, 0};
-    for (int tw = 1; tw <= 2; ++tw) {
-        o_wpack_coop[tw - 1] = alloc(lstm_coop_pack_floats(H, h->KX, tw));
-        lstm_coop_pack_weights(H, h->NIN, h->KX, tw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                               W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[tw - 1]);
+    size_t o_wpack_coop[4] = {0, 0, 0, 0};
+    for (int ui = 0; ui < 4; ++ui) {
+        const int units = 8 << ui;
+        o_wpack_coop[ui] = alloc(lstm_coop_pack_floats(H, h->KX, units));
+        lstm_coop_pack_weights(H, h->NIN, h->KX, units, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                               W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[ui]);
+    }
+    // ---- original FullSubNet: full-band LSTM (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
+    constexpr int KXF = 264;
+    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
+    const int fsn_kp = (int)align_up(CH, 16), fsn_np = (int)align_up(F, 384);
+    if (fsn) {
+        const std::string f = "fb_model.sequence_model.";
+        for (int ui = 0; ui < 3; ++ui) {
+            const int units = 8 << ui;
+            o_fbpack[ui] = alloc(lstm_coop_pack_floats(CH, KXF, units));
+            lstm_coop_pack_weights(CH, F, KXF, units, W(f + "weight_ih_l0").data(), W(f + "weight_hh_l0").data(),
+                                   W(f + "weight_ih_l1").data(), W(f + "weight_hh_l1").data(), blob.data() + o_fbpack[ui]);
+        }
+        o_fbbias = alloc((size_t)2 * 4 * CH);
+        for (int l = 0; l < 2; ++l) {
+            const auto& bi = W(f + "bias_ih_l" + std::to_string(l));
+            const auto& bh = W(f + "bias_hh_l" + std::to_string(l));
+            for (int i = 0; i < 4 * CH; ++i) blob[o_fbbias + (size_t)l * 4 * CH + i] = bi[i] + bh[i];
+        }
+        o_fsn_wf = alloc((size_t)fsn_np * fsn_kp);
+        const auto& wf = W("fb_model.fc_output_layer.weight");          // [F][CH]
+        for (int n = 0; n < F; ++n)
+            for (int k = 0; k < CH; ++k) blob[o_fsn_wf + (size_t)n * fsn_kp + k] = wf[(size_t)n * CH + k];
+        o_fsn_bf = alloc(fsn_np);
+        const auto& bf = W("fb_model.fc_output_layer.bias");
+        std::copy(bf.begin(), bf.end(), blob.begin() + o_fsn_bf);
     }
     const size_t o_lbias = alloc((size_t)2 * 4 * H);
     for (int l = 0; l < 2; ++l) {
@@ -468,9 +539,16 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
     h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
-    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int tw = 0; tw < 3; ++tw) h->lw.wpack_coop[tw] = d + o_wpack_coop[tw];
+    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
+    if (fsn) {
+        h->fbw = LstmWeights{};
+        for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
+        h->fbw.bias = d + o_fbbias;
+        h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0;
+        h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
+    }
     h->d_refl_w = d + o_refl;
     h->committed = true;
     (void)Fr;
@@ -485,7 +563,9 @@ size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames,
 int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
                  const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
                  int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
-    if (!h || !mag || !real || !imag || !out || !strides) { set_error("fsnp_forward: null argument"); return 1; }
+    if (!h || !mag || !out || !strides) { set_error("fsnp_forward: null argument"); return 1; }
+    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
+    if (!fsn && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
     if (!h->committed) { set_error("fsnp_forward: weights not committed (call fsnp_commit_weights)"); return 2; }
     if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
@@ -497,8 +577,10 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     d.CH = h->CH; d.H = h->H; d.NSB = h->NSB; d.NIN = h->NIN;
     int kmax = 1;
     for (int c = 0; c < 3; ++c) kmax = kmax > h->cfg.kersize[c] ? kmax : h->cfg.kersize[c];
-    if (h->cfg.attention == FSNP_ATT_TSSE && d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
+    if (!fsn && h->cfg.attention == FSNP_ATT_TSSE && d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
     if ((double)3 * d.B * d.Tp * d.FP * 2 > 2.0e9) { set_error("batch too large for 32-bit gather offsets; split the batch"); return 2; }
+    const int fb_units = fsn ? fb_coop_units(h, batch) : 0;
+    if (fsn && fb_units == 0) { set_error("FullSubNet: at most %d utterances per call (full-band LSTM residency); split the batch", 32 * (h->num_cus_real / 16)); return 2; }
 
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     const Workspace w = plan_workspace(h, batch, frames, mode);
@@ -520,18 +602,39 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_rows, lp.num_tiles,
                        lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
 
-    FrontendBuffers fbuf;
-    fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
-    fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
-    fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
-    const float* in[3] = {mag, real, imag};
-    launch_frontend(d, h->cfg.norm_type, in, strides, h->fw, fbuf, s);
+    if (!fsn) {
+        FrontendBuffers fbuf;
+        fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
+        fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
+        fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
+        const float* in[3] = {mag, real, imag};
+        launch_frontend(d, h->cfg.norm_type, in, strides, h->fw, fbuf, s);
 
-    TcnBuffers tbuf;
-    tbuf.att = fptr(w.att); tbuf.x = fptr(w.x); tbuf.y1 = fptr(w.y1); tbuf.y2 = fptr(w.y2);
-    tbuf.gn = reinterpret_cast<double*>(base + w.gn); tbuf.fb = fptr(w.fb);
-    tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
-    launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+        TcnBuffers tbuf;
+        tbuf.att = fptr(w.att); tbuf.x = fptr(w.x); tbuf.y1 = fptr(w.y1); tbuf.y2 = fptr(w.y2);
+        tbuf.gn = reinterpret_cast<double*>(base + w.gn); tbuf.fb = fptr(w.fb);
+        tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
+        launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+    } else {
+        // fullsubnet.py:82-90: pad, norm(noisy_mag), 2-layer LSTM(F -> CH), Linear(CH, F) + fb_act
+        FrontendBuffers fbuf{};
+        fbuf.raw = fptr(w.att); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
+        fbuf.md = reinterpret_cast<NormMD*>(base + w.md);
+        launch_frontend_mag(d, h->cfg.norm_type, mag, strides[0], fbuf, s);
+        const int fb_tiles = fb_row_tiles(batch);
+        RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
+        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * 32, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, 32,
+                           1, frames, 0, 0, 1, 1);
+        LstmArgs fa{};
+        fa.rows = fb_rows; fa.dense = fptr(w.att); fa.dense_stride = d.FP; fa.md_seq = fbuf.md;
+        fa.seq_out = fptr(w.y1);
+        fa.num_rows = batch; fa.num_tiles = fb_tiles; fa.Tp = d.Tp; fa.LA = 0; fa.FP = d.FP; fa.F = d.F;
+        fa.coop_hx = fptr(w.fb_hx); fa.coop_bar = reinterpret_cast<unsigned*>(base + w.fb_bar); fa.coop_err = h->d_err;
+        fa.coop_units = fb_units;
+        launch_lstm_coop_seq(h->fbw, fa, s);
+        launch_linear_act(fptr(w.y1), d.CH, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
+                          h->cfg.fb_act, h->num_cus, s);
+    }
 
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     SubbandBuffers sbuf;
@@ -553,7 +656,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     a.act = h->cfg.sb_act;
     if (use_coop(h, lp)) {
         a.coop_hx = fptr(w.coop_hx); a.coop_bar = reinterpret_cast<unsigned*>(base + w.coop_bar); a.coop_err = h->d_err;
-        a.coop_tw = coop_tw(h, lp);
+        a.coop_units = coop_units(h, lp);
         launch_lstm_coop(h->lw, a, s);
     } else {
         launch_lstm(h->lw, a, s);
@@ -587,7 +690,7 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const bool coop = use_coop(h, lp);
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, 1, lp.num_tiles), 256) : 0;
+    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, lp.num_tiles), 256) : 0;
     const size_t coop_bytes = coop ? coop_hx_bytes + align_up((size_t)lp.num_tiles * 4, 256) : 0;
     if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
@@ -596,13 +699,13 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_seq, lp.num_tiles,
                        lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
     LstmArgs a{};
-    a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
+    a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
     if (coop) {
         a.coop_hx = reinterpret_cast<float*>(h->ws + coop_off);
         a.coop_bar = reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes);
         a.coop_err = h->d_err;
-        a.coop_tw = coop_tw(h, lp);
+        a.coop_units = coop_units(h, lp);
         launch_lstm_coop(h->lw, a, s);
     } else {
         launch_lstm(h->lw, a, s);
@@ -621,10 +724,10 @@ int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t n
     const float* src = nullptr;
     bool is_gate = false;
     static const char* tags[3] = {"mag", "real", "imag"};
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < h->NFB; ++b) {
         if (n == std::string("att_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.att) + b * plane;
         if (n == std::string("fb_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.fb) + b * plane;
-        if (n == std::string("gate_") + tags[b]) { src = reinterpret_cast<float*>(h->ws + w.gate) + (size_t)b * d.B * d.FP; is_gate = true; }
+        if (h->NFB == 3 && n == std::string("gate_") + tags[b]) { src = reinterpret_cast<float*>(h->ws + w.gate) + (size_t)b * d.B * d.FP; is_gate = true; }
     }
     if (n == "tcn0_mag") {
         if (!h->debug) { set_error("tcn0_mag needs FSNP_DEBUG_STAGES=1 at fsnp_create time"); return 2; }
@@ -741,6 +844,21 @@ int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t
     return 0;
 }
 
+int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t units, const float* wih0, const float* whh0,
+                              const float* wih1, const float* whh1, float* out, int64_t out_floats) {
+    if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_coop_pack: null argument"); return 1; }
+    if ((units != 8 && units != 16 && units != 32 && units != 64) || hidden % 64 != 0 || kx % 8 != 0 || input_size > kx) {
+        set_error("fsnp_debug_lstm_coop_pack: bad sizes");
+        return 2;
+    }
+    if ((int64_t)lstm_coop_pack_floats(hidden, kx, units) != out_floats) {
+        set_error("fsnp_debug_lstm_coop_pack: need %lld floats", (long long)lstm_coop_pack_floats(hidden, kx, units));
+        return 2;
+    }
+    lstm_coop_pack_weights(hidden, input_size, kx, units, wih0, whh0, wih1, whh1, out);
+    return 0;
+}
+
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps) {
     if (!h) return 0;
     return (double)num_seq * steps * lstm_flops_per_step(h);
@@ -749,7 +867,8 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps) {
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode) {
     if (!h) return 0;
     const double Tp = frames + h->cfg.look_ahead;
-    return batch * Tp * (rows_per_utt(h, mode) * lstm_flops_per_step(h) + 3.0 * tcn_flops_per_frame(h));
+    const double full_band = h->model == FSNP_MODEL_FULLSUBNET ? fb_lstm_flops_per_frame(h) : 3.0 * tcn_flops_per_frame(h);
+    return batch * Tp * (rows_per_utt(h, mode) * lstm_flops_per_step(h) + full_band);
 }
 
 }  // extern "C"

@@ -55,6 +55,9 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
                        const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
                      const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
+// original FullSubNet: magnitude only - repack into buf.raw [B][Tp][FP] and the norm's (m_t, d_t) table into buf.md
+void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3],
+                         const FrontendBuffers& buf, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // tcn.hip : 8 x TCNBlock + ReLU + Linear + activation for the three full-band branches at once
@@ -90,12 +93,14 @@ struct TcnBuffers {
 };
 
 void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s);
+void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,
+                       int N, int B, int Tp, int act, int num_cus, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // subband.hip : statistics of the (never materialised) sub-band input tensor
 struct SubbandBuffers {
     const float* att_mag;  // [B][Tp][FP]
-    const float* fb;       // [3][B][Tp][FP]
+    const float* fb;       // [NFB][B][Tp][FP]  NFB = NIN - NSB full-band branches (3: FullSubNet+, 1: FullSubNet)
     const float* refl_w;   // [F] multiplicity of each frequency row inside the unfold
     double* acc;           // [B][2]  (sum, sumsq) over the whole [F,NIN,Tp] tensor, zeroed per forward
     NormMD* md_utt;        // [B]
@@ -114,7 +119,7 @@ struct LstmWeights {
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
     const float* wpack_bf[2];   // bf16-ih streams (4-wave, 12-wave): layer-1 W_ih as bf16 k-steps (configs[4])
     int ih_bf16;                // 1 = use them
-    const float* wpack_coop[3]; // column-split kernel, 32*(i+1) units per workgroup: [split][k-group][tile][lane][4]
+    const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
@@ -130,8 +135,11 @@ struct LstmArgs {
     const RowDesc* rows;   // [num_tiles*32]
     const NormMD* md_utt;  // [B]   (offline norms)
     const NormMD* md_row;  // [rows][Tp] or nullptr
-    // dense mode: x[row][t][NIN]
+    // dense mode: x[row.b][t][dense_stride] (first NIN entries of each row)
     const float* dense;
+    int dense_stride;          // cooperative kernel only (the row-tile kernel assumes NIN)
+    const NormMD* md_seq;      // cooperative kernel only: optional [sequence = row.b][Tp] table, overrides md_utt / md_row
+    float* seq_out;            // cooperative SEQ kernel: h1 of the second layer, [row.b][t][H]
     float* out;            // out[row.out_off + o*out_stride_o + (t-LA)]
     long out_stride_o;
     int num_rows;          // valid rows
@@ -144,19 +152,20 @@ struct LstmArgs {
     float* coop_hx;            // per row tile: h0/h1 exchange images (double buffered) + Linear partials, zeroed per launch
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
     unsigned* coop_err;        // set to 1 if a barrier wait timed out
-    int coop_tw;               // 32-unit blocks per workgroup: 1, 2 or 3
+    int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 // lstm_coop.hip: column-split kernel for small batches (row_tiles * H/32 workgroups, all co-resident)
-void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
-size_t lstm_coop_pack_floats(int H, int KX, int TW);
-void lstm_coop_pack_weights(int H, int NIN, int KX, int TW, const float* wih0, const float* whh0, const float* wih1,
+void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s);       // H = 384, KX = 40, Linear(H, 2) fused
+void launch_lstm_coop_seq(const LstmWeights& w, const LstmArgs& a, hipStream_t s);   // H = 512, KX = 264, h1 sequence out
+size_t lstm_coop_pack_floats(int H, int KX, int units);
+void lstm_coop_pack_weights(int H, int NIN, int KX, int units, const float* wih0, const float* whh0, const float* wih1,
                             const float* whh1, float* wpack);
-size_t lstm_coop_exchange_bytes(int H, int TW, int row_tiles);
-int lstm_coop_pick_tw(int H, int row_tiles, int num_cus);   // 0 = not applicable
+size_t lstm_coop_exchange_bytes(int H, int row_tiles);
+int lstm_coop_pick_units(int H, int row_tiles, int num_cus, int min_units);   // 0 = not applicable
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
 size_t lstm_pack_floats_bf16ih(int H, int KX, int NW);

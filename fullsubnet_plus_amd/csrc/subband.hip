@@ -3,7 +3,8 @@
 // The reference builds sb_input[b, f, j, t] = cat(unfold(att_mag, 15), fb_mag, fb_real, fb_imag)
 // (speech_enhance/fullsubnet_plus/model/fullsubnet_plus.py:167-188; BaseModel.unfold
 // speech_enhance/audio_zen/model/base_model.py:15-47) - a [B,257,34,T'] tensor, 143 MB at B=32 - and then
-// applies self.norm to it (fullsubnet_plus.py:189).  Here:
+// applies self.norm to it (fullsubnet_plus.py:189).  The original FullSubNet builds cat(unfold(noisy_mag, 15),
+// fb_output) with ONE full-band branch (speech_enhance/fullsubnet/model/fullsubnet.py:92-105).  Here:
 //   offline norms   : sum / sumsq over the tensor == sum_r w_r * rowstat(att_mag[:, r]) + rowstats(fb*),
 //                     where w_r = number of (f, j) pairs whose reflect-padded neighbour index is r;
 //   cumulative norms: the reshape to [B*257, 34, T'] (base_model.py:237-238, 288-289) makes the running
@@ -33,7 +34,7 @@ __device__ __forceinline__ NormMD sb_norm_md(int norm_type, double sum, double s
 
 constexpr int SB_ROWS = 16;
 __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
-                                                               const float* __restrict__ fb, long fb_bs,
+                                                               const float* __restrict__ fb, long fb_bs, int nfb,
                                                                const float* __restrict__ refl_w,
                                                                double* __restrict__ acc, int Tp, int F, int FP) {
     __shared__ double red[8];
@@ -46,8 +47,7 @@ __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __re
             const double a = att_mag[i];
             s += wr * a;
             q += wr * a * a;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < nfb; ++k) {
                 const double v = fb[k * fb_bs + i];
                 s += v;
                 q += v * v;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restri
             const double v = att_mag[base + reflect_index(rd.f - nsbn + j, F)];
             s += v; q += v * v;
         }
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < nin - nsb; ++k) {
             const double v = fb[k * fb_bs + base + rd.f];
             s += v; q += v * v;
         }
@@ -104,7 +104,7 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
     const long fb_bs = (long)d.B * d.Tp * d.FP;
     if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
         hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, SB_ROWS), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
-                           fb_bs, buf.refl_w, buf.acc, d.Tp, d.F, d.FP);
+                           fb_bs, d.NIN - d.NSB, buf.refl_w, buf.acc, d.Tp, d.F, d.FP);
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);
     } else {

@@ -210,12 +210,12 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
 // Column-tile width for one GEMM launch.  Workgroups are MFMA-bound, so the launch takes about
 // ceil(blocks / CUs) * BN; pick the BN in {64, 96, 128} that minimises it (ties -> the narrower tile: more,
 // smaller workgroups balance better).  Weights are zero-padded to a multiple of 384 rows so any choice is valid.
-static int pick_bn(int n, int row_tiles, int num_cus) {
+static int pick_bn(int n, int row_tiles, int num_cus, int branches) {
     int best = 64;
     long best_cost = -1;
     const int cand[3] = {64, 96, 128};
     for (int c : cand) {
-        const long blocks = (long)cdiv(n, c) * row_tiles * 3;
+        const long blocks = (long)cdiv(n, c) * row_tiles * branches;
         const long cost = ((blocks + num_cus - 1) / num_cus) * c;
         if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
     }
@@ -223,9 +223,9 @@ static int pick_bn(int n, int row_tiles, int num_cus) {
 }
 
 template <int PRO, int EPI>
-static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s) {
-    const int bn = pick_bn(n, row_tiles, num_cus);
-    const dim3 grid(cdiv(n, bn), row_tiles, 3);
+static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches = 3) {
+    const int bn = pick_bn(n, row_tiles, num_cus, branches);
+    const dim3 grid(cdiv(n, bn), row_tiles, branches);
     if (bn == 128) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 128>), grid, dim3(256), 0, s, g);
     else if (bn == 96) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 96>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 64>), grid, dim3(256), 0, s, g);
@@ -354,6 +354,16 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
         g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
         launch_gemm<PRO_RELU, EPI_ACT>(g, d.F, row_tiles, w.num_cus, s);
     }
+}
+
+// C[utt][t][0..N) = act(A[utt][t][0..K) * W^T + bias): the Linear(512, 257) + ReLU after the full-band LSTM of the
+// original FullSubNet (SequenceModel.forward, sequence_model.py:119-122).  W is [N pad 384][ldw], zero padded.
+void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,
+                       int N, int B, int Tp, int act, int num_cus, hipStream_t s) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.K = K; g.N = N; g.Tp = Tp; g.B = B; g.act = act;
+    launch_gemm<PRO_NONE, EPI_ACT>(g, N, cdiv(Tp, BM) * B, num_cus, s, 1);
 }
 
 }  // namespace fsnp

@@ -133,100 +133,16 @@ def _reference_style_init(m):
             (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p)
 
 
-class FullSubNet_Plus(nn.Module):
-    def __init__(self,
-                 num_freqs,
-                 look_ahead,
-                 sequence_model,
-                 fb_num_neighbors,
-                 sb_num_neighbors,
-                 fb_output_activate_function,
-                 sb_output_activate_function,
-                 fb_model_hidden_size,
-                 sb_model_hidden_size,
-                 channel_attention_model="SE",
-                 norm_type="offline_laplace_norm",
-                 num_groups_in_drop_band=2,
-                 output_size=2,
-                 subband_num=1,
-                 kersize=[3, 5, 10],
-                 weight_init=True,
-                 ):
-        super().__init__()
-        assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
-        if sequence_model != "LSTM":
-            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM only)")
-        if channel_attention_model not in _lib.ATTENTION:
-            raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
-        if subband_num != 1:
-            raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
-        if fb_num_neighbors != 0:
-            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
-        if norm_type not in _lib.NORM_TYPES:
-            raise NotImplementedError("You must set up a type of Norm. "
-                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
-        for act in (fb_output_activate_function, sb_output_activate_function):
-            if act and act not in _lib.ACTIVATIONS:
-                raise NotImplementedError(f"Not implemented activation function {act}")
+class _HipModel(nn.Module):
+    """Everything the two reference models share on the HIP side: the fsnp_handle, lazy strict weight packing,
+    the fsnp_forward call and the test / bench hooks.  Subclasses hold the reference's parameter tree and
+    provide ``_config()``."""
 
-        self.num_channels = num_freqs
-        def make_attention():
-            if channel_attention_model == "TSSE":
-                return _TSSEParams(num_freqs, kersize)
-            if channel_attention_model == "ECA":
-                return _ECAParams()
-            return _SEParams(num_freqs)                      # SE and CBAM share the parameter tree
-        self.channel_attention_model = channel_attention_model
-        self.channel_attention = make_attention()
-        self.channel_attention_real = make_attention()
-        self.channel_attention_imag = make_attention()
-        # NB: the reference hard-codes the TCNBlock hidden width to 512 (causal_conv.py:68) and ignores
-        # fb_model_hidden_size for the TCN full-band models (sequence_model.py:48-57).
-        self.fb_model = _FullBandParams(num_freqs, 512)
-        self.fb_model_real = _FullBandParams(num_freqs, 512)
-        self.fb_model_imag = _FullBandParams(num_freqs, 512)
-        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1),
-                                       sb_model_hidden_size, output_size)
-
-        self.subband_num = subband_num
-        self.sb_num_neighbors = sb_num_neighbors
-        self.fb_num_neighbors = fb_num_neighbors
-        self.look_ahead = look_ahead
-        self.norm_type = norm_type
-        self.num_groups_in_drop_band = num_groups_in_drop_band
-        self.output_size = output_size
-        self.num_freqs = num_freqs
-        self.kersize = list(kersize)
-        self.fb_output_activate_function = fb_output_activate_function
-        self.sb_output_activate_function = sb_output_activate_function
-        self.sb_model_hidden_size = sb_model_hidden_size
-        # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196);
-        # "full": every utterance keeps all bins (== the reference run per utterance), the inference workload.
+    def _init_hip(self):
+        # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196,
+        # fullsubnet.py:107-110); "full": every utterance keeps all bins (== the reference run per utterance).
         self.batch_mode = "parity"
-
         self._hip = _HipState()
-        if weight_init:
-            self.apply(_reference_style_init)
-
-    # ------------------------------------------------------------------ handle / weights
-    def _config(self):
-        cfg = _lib.FsnpConfig()
-        cfg.num_freqs = self.num_freqs
-        cfg.look_ahead = self.look_ahead
-        cfg.sb_num_neighbors = self.sb_num_neighbors
-        cfg.fb_num_neighbors = self.fb_num_neighbors
-        cfg.tcn_hidden = 512
-        cfg.num_tcn_blocks = len(_TCN_DILATIONS)
-        cfg.sb_hidden = self.sb_model_hidden_size
-        cfg.output_size = self.output_size
-        cfg.norm_type = _lib.NORM_TYPES[self.norm_type]
-        cfg.fb_act = _lib.ACTIVATIONS[self.fb_output_activate_function or None]
-        cfg.sb_act = _lib.ACTIVATIONS[self.sb_output_activate_function or None]
-        for i, k in enumerate(self.kersize):
-            cfg.kersize[i] = int(k)
-        cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
-        cfg.attention = _lib.ATTENTION[self.channel_attention_model]
-        return cfg
 
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -259,19 +175,14 @@ class FullSubNet_Plus(nn.Module):
             raise RuntimeError("no HIP handle yet: run a forward on a CUDA tensor first")
         return self._hip.handle
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, noisy_mag, noisy_real, noisy_imag, batch_offset=0, global_batch=None):
-        """
-        Shapes:
-            noisy_mag / noisy_real / noisy_imag: [B, 1, F, T] fp32 CUDA tensors (any strides)
-            return: [B, 2, F, T]   (B == 1 or batch_mode == "full")
-                    [B, 2, F//2, T] with the reference's drop_band row order (B > 1, batch_mode == "parity")
-        batch_offset / global_batch: only for sharded batches (fullsubnet_plus_amd.dist).
-        """
+    def _forward_impl(self, ins, batch_offset, global_batch):
+        """ins: 1 (FullSubNet) or 3 (FullSubNet+) tensors [B, 1, F, T]; returns the cIRM tensor."""
+        noisy_mag = ins[0]
         assert noisy_mag.dim() == 4
         batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
         assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
-        assert noisy_real.shape == noisy_mag.shape and noisy_imag.shape == noisy_mag.shape
+        for t in ins[1:]:
+            assert t.shape == noisy_mag.shape
         assert num_freqs == self.num_freqs, f"expected {self.num_freqs} frequency bins, got {num_freqs}"
         if not noisy_mag.is_cuda:
             raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; move the model and inputs to 'cuda'. "
@@ -285,12 +196,9 @@ class FullSubNet_Plus(nn.Module):
                 f"The batch size should larger than the num_groups."
             if self.num_groups_in_drop_band != 2:
                 raise NotImplementedError("HIP path: drop_band with num_groups != 2 is not built yet")
-        ins = []
-        for t in (noisy_mag, noisy_real, noisy_imag):
-            if t.dtype != torch.float32:
-                t = t.float()
+        ins = [t if t.dtype == torch.float32 else t.float() for t in ins]
+        for t in ins:
             assert t.device == device
-            ins.append(t)
         lib = self._ensure_handle(device)
         out_f = num_freqs // 2 if parity else num_freqs
         standalone = global_batch is None
@@ -301,26 +209,17 @@ class FullSubNet_Plus(nn.Module):
         for i, t in enumerate(ins):
             sb, _, sf, st = t.stride()
             strides[i][0], strides[i][1], strides[i][2] = sb, sf, st
+        ptrs = [t.data_ptr() for t in ins] + [None] * (3 - len(ins))
         stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
-            rc = lib.fsnp_forward(self._handle, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(),
+            rc = lib.fsnp_forward(self._handle, ptrs[0], ptrs[1], ptrs[2],
                                   ctypes.byref(strides), out.data_ptr(), batch_size, num_frames,
                                   _lib.MODE_PARITY if parity else _lib.MODE_FULL, int(batch_offset), gb,
                                   ctypes.c_void_p(stream))
         _lib.check(rc, "fsnp_forward")
         return out
 
-    def enhance(self, noisy_complex):
-        """SURVEY.md 8(f-1): model forward + decompress_cIRM + complex multiply in HIP, i.e. lines 143-157 of
-        fullsubnet_plus/inferencer/inferencer.py: noisy_complex [B,F,T] complex64 (torch.stft output, any strides)
-        -> enhanced complex [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
-        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
-        mode, self.batch_mode = self.batch_mode, "full"
-        try:
-            mask = self.forward(noisy_complex.abs().unsqueeze(1), noisy_complex.real.unsqueeze(1),
-                                noisy_complex.imag.unsqueeze(1))
-        finally:
-            self.batch_mode = mode
+    def _apply_cirm(self, mask, noisy_complex):
         B, F, T = noisy_complex.shape
         out = torch.empty_strided((B, F, T), noisy_complex.stride(), dtype=torch.complex64, device=noisy_complex.device)
         xr, orr = torch.view_as_real(noisy_complex), torch.view_as_real(out)
@@ -404,6 +303,218 @@ class FullSubNet_Plus(nn.Module):
 
     def forward_flops(self, batch, frames, parity=False):
         return float(_lib.load().fsnp_forward_flops(self._handle, batch, frames, int(parity)))
+
+
+class FullSubNet_Plus(_HipModel):
+    def __init__(self,
+                 num_freqs,
+                 look_ahead,
+                 sequence_model,
+                 fb_num_neighbors,
+                 sb_num_neighbors,
+                 fb_output_activate_function,
+                 sb_output_activate_function,
+                 fb_model_hidden_size,
+                 sb_model_hidden_size,
+                 channel_attention_model="SE",
+                 norm_type="offline_laplace_norm",
+                 num_groups_in_drop_band=2,
+                 output_size=2,
+                 subband_num=1,
+                 kersize=[3, 5, 10],
+                 weight_init=True,
+                 ):
+        super().__init__()
+        assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
+        if sequence_model != "LSTM":
+            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM only)")
+        if channel_attention_model not in _lib.ATTENTION:
+            raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
+        if subband_num != 1:
+            raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
+        if fb_num_neighbors != 0:
+            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
+        if norm_type not in _lib.NORM_TYPES:
+            raise NotImplementedError("You must set up a type of Norm. "
+                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
+        for act in (fb_output_activate_function, sb_output_activate_function):
+            if act and act not in _lib.ACTIVATIONS:
+                raise NotImplementedError(f"Not implemented activation function {act}")
+
+        self.num_channels = num_freqs
+        def make_attention():
+            if channel_attention_model == "TSSE":
+                return _TSSEParams(num_freqs, kersize)
+            if channel_attention_model == "ECA":
+                return _ECAParams()
+            return _SEParams(num_freqs)                      # SE and CBAM share the parameter tree
+        self.channel_attention_model = channel_attention_model
+        self.channel_attention = make_attention()
+        self.channel_attention_real = make_attention()
+        self.channel_attention_imag = make_attention()
+        # NB: the reference hard-codes the TCNBlock hidden width to 512 (causal_conv.py:68) and ignores
+        # fb_model_hidden_size for the TCN full-band models (sequence_model.py:48-57).
+        self.fb_model = _FullBandParams(num_freqs, 512)
+        self.fb_model_real = _FullBandParams(num_freqs, 512)
+        self.fb_model_imag = _FullBandParams(num_freqs, 512)
+        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1),
+                                       sb_model_hidden_size, output_size)
+
+        self.subband_num = subband_num
+        self.sb_num_neighbors = sb_num_neighbors
+        self.fb_num_neighbors = fb_num_neighbors
+        self.look_ahead = look_ahead
+        self.norm_type = norm_type
+        self.num_groups_in_drop_band = num_groups_in_drop_band
+        self.output_size = output_size
+        self.num_freqs = num_freqs
+        self.kersize = list(kersize)
+        self.fb_output_activate_function = fb_output_activate_function
+        self.sb_output_activate_function = sb_output_activate_function
+        self.sb_model_hidden_size = sb_model_hidden_size
+        self._init_hip()
+        if weight_init:
+            self.apply(_reference_style_init)
+
+    # ------------------------------------------------------------------ handle / weights
+    def _config(self):
+        cfg = _lib.FsnpConfig()
+        cfg.num_freqs = self.num_freqs
+        cfg.look_ahead = self.look_ahead
+        cfg.sb_num_neighbors = self.sb_num_neighbors
+        cfg.fb_num_neighbors = self.fb_num_neighbors
+        cfg.tcn_hidden = 512
+        cfg.num_tcn_blocks = len(_TCN_DILATIONS)
+        cfg.sb_hidden = self.sb_model_hidden_size
+        cfg.output_size = self.output_size
+        cfg.norm_type = _lib.NORM_TYPES[self.norm_type]
+        cfg.fb_act = _lib.ACTIVATIONS[self.fb_output_activate_function or None]
+        cfg.sb_act = _lib.ACTIVATIONS[self.sb_output_activate_function or None]
+        for i, k in enumerate(self.kersize):
+            cfg.kersize[i] = int(k)
+        cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
+        cfg.attention = _lib.ATTENTION[self.channel_attention_model]
+        return cfg
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, noisy_mag, noisy_real, noisy_imag, batch_offset=0, global_batch=None):
+        """
+        Shapes:
+            noisy_mag / noisy_real / noisy_imag: [B, 1, F, T] fp32 CUDA tensors (any strides)
+            return: [B, 2, F, T]   (B == 1 or batch_mode == "full")
+                    [B, 2, F//2, T] with the reference's drop_band row order (B > 1, batch_mode == "parity")
+        batch_offset / global_batch: only for sharded batches (fullsubnet_plus_amd.dist).
+        """
+        return self._forward_impl([noisy_mag, noisy_real, noisy_imag], batch_offset, global_batch)
+
+    def enhance(self, noisy_complex):
+        """SURVEY.md 8(f-1): model forward + decompress_cIRM + complex multiply in HIP, i.e. lines 143-157 of
+        fullsubnet_plus/inferencer/inferencer.py: noisy_complex [B,F,T] complex64 (torch.stft output, any strides)
+        -> enhanced complex [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
+        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
+        mode, self.batch_mode = self.batch_mode, "full"
+        try:
+            mask = self.forward(noisy_complex.abs().unsqueeze(1), noisy_complex.real.unsqueeze(1),
+                                noisy_complex.imag.unsqueeze(1))
+        finally:
+            self.batch_mode = mode
+        return self._apply_cirm(mask, noisy_complex)
+
+
+class _FullBandLSTMParams(nn.Module):
+    """Parameter holder named like SequenceModel(sequence_model="LSTM") of the original FullSubNet's full-band model
+    (fullsubnet/model/fullsubnet.py:39-47; sequence_model.py:31-38,78-79)."""
+
+    def __init__(self, num_freqs, hidden):
+        super().__init__()
+        self.sequence_model = nn.LSTM(num_freqs, hidden, num_layers=2, batch_first=True)
+        self.fc_output_layer = nn.Linear(hidden, num_freqs)
+
+
+class FullSubNet(_HipModel):
+    """the original FullSubNet ``Model`` (speech_enhance/fullsubnet/model/fullsubnet.py:12-118, the
+    commented alternative of config/inference.toml:11,28) on the same HIP kernels: constructor kwargs
+    fullsubnet.py:13-26, ``forward(noisy_mag) -> [B, 2, F, T]`` fullsubnet.py:68-118, strict state_dict."""
+
+    def __init__(self,
+                 num_freqs,
+                 look_ahead,
+                 sequence_model,
+                 fb_num_neighbors,
+                 sb_num_neighbors,
+                 fb_output_activate_function,
+                 sb_output_activate_function,
+                 fb_model_hidden_size,
+                 sb_model_hidden_size,
+                 norm_type="offline_laplace_norm",
+                 num_groups_in_drop_band=2,
+                 weight_init=True,
+                 ):
+        super().__init__()
+        assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
+        if sequence_model != "LSTM":
+            raise NotImplementedError(f"HIP path: sequence_model {sequence_model} is not built yet (LSTM only)")
+        if fb_num_neighbors != 0:
+            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
+        if norm_type not in _lib.NORM_TYPES:
+            raise NotImplementedError("You must set up a type of Norm. "
+                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
+        for act in (fb_output_activate_function, sb_output_activate_function):
+            if act and act not in _lib.ACTIVATIONS:
+                raise NotImplementedError(f"Not implemented activation function {act}")
+        self.fb_model = _FullBandLSTMParams(num_freqs, fb_model_hidden_size)
+        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), sb_model_hidden_size, 2)
+
+        self.sb_num_neighbors = sb_num_neighbors
+        self.fb_num_neighbors = fb_num_neighbors
+        self.look_ahead = look_ahead
+        self.norm_type = norm_type
+        self.num_groups_in_drop_band = num_groups_in_drop_band
+        self.num_freqs = num_freqs
+        self.output_size = 2
+        self.fb_output_activate_function = fb_output_activate_function
+        self.sb_output_activate_function = sb_output_activate_function
+        self.fb_model_hidden_size = fb_model_hidden_size
+        self.sb_model_hidden_size = sb_model_hidden_size
+        self._init_hip()
+        if weight_init:
+            self.apply(_reference_style_init)
+
+    def _config(self):
+        cfg = _lib.FsnpConfig()
+        cfg.model = _lib.MODEL_FULLSUBNET
+        cfg.num_freqs = self.num_freqs
+        cfg.look_ahead = self.look_ahead
+        cfg.sb_num_neighbors = self.sb_num_neighbors
+        cfg.fb_num_neighbors = self.fb_num_neighbors
+        cfg.tcn_hidden = self.fb_model_hidden_size       # fb_model_hidden_size (fsnp.h: FSNP_MODEL_FULLSUBNET)
+        cfg.num_tcn_blocks = 0
+        cfg.sb_hidden = self.sb_model_hidden_size
+        cfg.output_size = 2
+        cfg.norm_type = _lib.NORM_TYPES[self.norm_type]
+        cfg.fb_act = _lib.ACTIVATIONS[self.fb_output_activate_function or None]
+        cfg.sb_act = _lib.ACTIVATIONS[self.sb_output_activate_function or None]
+        for i in range(3):
+            cfg.kersize[i] = 1
+        cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
+        cfg.attention = 0
+        return cfg
+
+    def forward(self, noisy_mag, batch_offset=0, global_batch=None):
+        """noisy_mag [B, 1, F, T] fp32 CUDA tensor (any strides) -> cIRM [B, 2, F, T] (see FullSubNet_Plus.forward
+        for batch_mode and the sharding arguments)."""
+        return self._forward_impl([noisy_mag], batch_offset, global_batch)
+
+    def enhance(self, noisy_complex):
+        """fullsubnet/inferencer/inferencer.py `full_band_crm_mask`: forward on |X| + decompress_cIRM + complex
+        multiply -> enhanced complex [B,F,T] ready for torch.istft (all bins kept)."""
+        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
+        mode, self.batch_mode = self.batch_mode, "full"
+        try:
+            mask = self.forward(noisy_complex.abs().unsqueeze(1))
+        finally:
+            self.batch_mode = mode
+        return self._apply_cirm(mask, noisy_complex)
 
 
 Model = FullSubNet_Plus  # the name BASELINE.json's north_star uses

@@ -48,6 +48,14 @@ enum {
     FSNP_ATT_CBAM = 3  /* ChannelCBAMLayer         attention_model.py:296-332 */
 };
 
+/* Which reference model the handle implements.
+ * FSNP_MODEL_FULLSUBNET is the original FullSubNet (speech_enhance/fullsubnet/model/fullsubnet.py:12-118, the
+ * commented alternative of config/inference.toml:11,28): ONE magnitude input, full-band model = 2-layer
+ * LSTM(num_freqs -> tcn_hidden) + Linear(tcn_hidden, num_freqs) + fb_act, sub-band input = 31 neighbours of the RAW
+ * magnitude + 1 full-band feature.  For it tcn_hidden means fb_model_hidden_size (must be 512), num_tcn_blocks /
+ * kersize / attention are ignored, and fsnp_forward takes real = imag = NULL. */
+enum { FSNP_MODEL_FULLSUBNET_PLUS = 0, FSNP_MODEL_FULLSUBNET = 1 };
+
 /* B > 1 semantics */
 enum {
     FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,2,F,T]          */
@@ -71,6 +79,7 @@ typedef struct fsnp_config {
     int32_t kersize[3];         /* 3,5,10 : TSSE depthwise kernel sizes (attention_model.py:49) */
     int32_t num_groups_in_drop_band; /* 2 (only 2 is supported in PARITY mode) */
     int32_t attention;          /* FSNP_ATT_* : channel_attention_model */
+    int32_t model;              /* FSNP_MODEL_* (0 = FullSubNet+) */
 } fsnp_config;
 
 /* Replaces `FullSubNet_Plus(**model.args)` (base_inferencer.py:99).  Needs a visible
@@ -181,6 +190,10 @@ int fsnp_debug_set_num_cus(fsnp_handle* h, int32_t num_cus);
  * [wave][k-group][tile][lane][k-pair] for a `waves`-wave workgroup (layout documented in csrc/lstm.hip). */
 int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t waves, const float* wih0, const float* whh0,
                          const float* wih1, const float* whh1, float* out, int64_t out_floats);
+/* Same for the column-split cooperative kernel (csrc/lstm_coop.hip): `units` hidden units per workgroup (8, 16,
+ * 32 or 64); layout [split][wave][local k-group][tile][lane][4]. */
+int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t units, const float* wih0,
+                              const float* whh0, const float* wih1, const float* whh1, float* out, int64_t out_floats);
 
 const char* fsnp_last_error(void);
 const char* fsnp_version(void);

@@ -226,3 +226,41 @@ def forward_full(p, mag, real, imag, **kw):
     """"full" mode: every utterance keeps all bins == the reference run per utterance at
     B=1 and stacked."""
     return forward(p, mag, real, imag, apply_drop_band=False, **kw)
+
+
+@torch.no_grad()
+def forward_fullsubnet(p, noisy_mag, *, look_ahead=2, sb_num_neighbors=15, fb_num_neighbors=0,
+                       norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
+                       fb_output_activate_function="ReLU", sb_output_activate_function=False,
+                       apply_drop_band=None, stages=None):
+    """the original FullSubNet forward, speech_enhance/fullsubnet/model/fullsubnet.py:68-118."""
+    assert noisy_mag.dim() == 4
+    mag = Fn.pad(noisy_mag, [0, look_ahead])                                      # :82
+    B, C, F, T = mag.shape
+    assert C == 1
+    if norm_type not in NORMS:
+        raise NotImplementedError("You must set up a type of Norm.")
+    norm = NORMS[norm_type]
+    rec = (lambda k, v: stages.__setitem__(k, v)) if stages is not None else (lambda k, v: None)
+    fb_input = norm(mag).reshape(B, F, T)                                          # :87
+    fb_output = lstm2_fc(fb_input, p, "fb_model", fb_output_activate_function)     # :88, sequence_model.py:113-123
+    rec("fb_mag", fb_output)
+    nfb, nsb = 2 * fb_num_neighbors + 1, 2 * sb_num_neighbors + 1
+    fb_unf = unfold(fb_output.reshape(B, 1, F, T), fb_num_neighbors).reshape(B, F, nfb, T)   # :91-92
+    mag_unf = unfold(mag, sb_num_neighbors).reshape(B, F, nsb, T)                  # :95-96
+    sb_input = norm(torch.cat([mag_unf, fb_unf], dim=2))                           # :99-100
+    rec("sb_input", sb_input)
+    drop = (B > 1) if apply_drop_band is None else apply_drop_band
+    Fo = F
+    if drop:                                                                       # :103-106
+        sb_input = drop_band(sb_input.permute(0, 2, 1, 3), num_groups_in_drop_band)
+        Fo = sb_input.shape[2]
+        sb_input = sb_input.permute(0, 2, 1, 3)
+    sb_input = sb_input.reshape(B * Fo, nsb + nfb, T)
+    sb_mask = lstm2_fc(sb_input, p, "sb_model", sb_output_activate_function)       # :115
+    sb_mask = sb_mask.reshape(B, Fo, 2, T).permute(0, 2, 1, 3).contiguous()
+    return sb_mask[:, :, :, look_ahead:]                                           # :118
+
+
+def forward_fullsubnet_full(p, mag, **kw):
+    return forward_fullsubnet(p, mag, apply_drop_band=False, **kw)

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ref_loader
-from .weights import make_inputs, make_state_dict
+from .weights import make_inputs, make_state_dict, make_state_dict_fullsubnet
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -68,6 +68,21 @@ CASES = [
          subsample_f=4),
 ]
 
+
+# the original FullSubNet ``Model`` (fullsubnet/model/fullsubnet.py), fixtures named fsn_*
+FSN_CASES = [
+    dict(name="fsn_b1_t24_default_stages", wseed=1, profile="default", args={}, inp=("spec", 1, 24, 21), stages=True),
+    dict(name="fsn_b1_t24_harsh_stages", wseed=2, profile="harsh", args={}, inp=("spec", 1, 24, 22), stages=True),
+    dict(name="fsn_b3_t20_harsh", wseed=3, profile="harsh", args={}, inp=("spec", 3, 20, 23), stages=False),
+    dict(name="fsn_b5_t16_default", wseed=4, profile="default", args={}, inp=("spec", 5, 16, 24), stages=False),
+    dict(name="fsn_b1_t30_cum_layer", wseed=5, profile="default", args={"norm_type": "cumulative_layer_norm"},
+         inp=("spec", 1, 30, 25), stages=True),
+    dict(name="fsn_b3_t18_cum_laplace", wseed=6, profile="harsh", args={"norm_type": "cumulative_laplace_norm"},
+         inp=("spec", 3, 18, 26), stages=False),
+    dict(name="fsn_b1_t20_gaussian", wseed=7, profile="default", args={"norm_type": "offline_gaussian_norm"},
+         inp=("spec", 1, 20, 27), stages=True),
+    dict(name="fsn_b1_2s_default", wseed=8, profile="default", args={}, inp=("stft", 1, 2.0, 28), stages=False),
+]
 
 SB_ROWS = [0, 1, 14, 15, 16, 128, 240, 241, 242, 255, 256]   # sub-bands kept from stage sb_input (B=1)
 
@@ -139,12 +154,75 @@ def run_case(case, FullSubNet_Plus):
     return payload, (sd, args, mag, real, imag)
 
 
+def run_case_fsn(case, Model):
+    """Same as run_case for the original FullSubNet (one magnitude input)."""
+    args = dict(ref_loader.FULLSUBNET_MODEL_ARGS)
+    args.update(case["args"])
+    torch.manual_seed(0)
+    model = Model(**args).eval()
+    sd = make_state_dict_fullsubnet(case["wseed"], case["profile"])
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    kind, B, t, iseed = case["inp"]
+    mag, _, _ = build_inputs(kind, B, t, iseed)
+    stages = {}
+    hooks = []
+    if case["stages"]:
+        hooks.append(model.fb_model.register_forward_hook(
+            lambda _m, _i, o: stages.__setitem__("fb_mag", o.detach().numpy().copy())))
+        hooks.append(model.sb_model.register_forward_pre_hook(
+            lambda _m, i: stages.__setitem__("sb_input", i[0].detach().numpy()[SB_ROWS].copy())))
+    with torch.no_grad():
+        out = model(mag).numpy()
+        for h in hooks:
+            h.remove()
+        m64 = copy.deepcopy(model).double()
+        payload = dict(out=out, out64=m64(mag.double()).numpy().astype(np.float32))
+        if B > 1:
+            payload["full"] = torch.cat([model(mag[b:b + 1]) for b in range(B)], 0).numpy()
+            payload["full64"] = torch.cat([m64(mag[b:b + 1].double()) for b in range(B)], 0).numpy().astype(np.float32)
+    if kind == "stft":
+        payload["mag"] = mag.numpy()
+    for k, v in stages.items():
+        payload["stage_" + k] = v.astype(np.float32)
+    meta = dict(name=case["name"], model="fullsubnet", wseed=case["wseed"], profile=case["profile"], args=args,
+                inp=dict(kind=kind, B=B, t=t, seed=iseed), subsample_f=1,
+                torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
+                in_checksum=[float(mag.double().sum())])
+    payload["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return payload, (sd, args, mag)
+
+
+def main_fsn(only):
+    from . import fsnp_torch
+    Model = ref_loader.load_reference_fullsubnet()
+    for case in FSN_CASES:
+        if only and case["name"] not in only:
+            continue
+        payload, (sd, args, mag) = run_case_fsn(case, Model)
+        path = os.path.join(GOLDEN_DIR, case["name"] + ".npz")
+        np.savez_compressed(path, **payload)
+        kw = {k: args[k] for k in ("look_ahead", "sb_num_neighbors", "fb_num_neighbors", "norm_type",
+                                   "num_groups_in_drop_band", "fb_output_activate_function",
+                                   "sb_output_activate_function")}
+        ot = fsnp_torch.forward_fullsubnet(sd, mag, **kw).numpy()
+        scale = np.abs(payload["out"]).max()
+        print(f"{case['name']:28s} out{payload['out'].shape} scale {scale:.3e} "
+              f"ref32-vs-64 {np.abs(payload['out'] - payload['out64']).max() / scale:.2e} "
+              f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e} [{os.path.getsize(path) / 1024:.0f} KB]",
+              flush=True)
+
+
 def main():
+    only = set(sys.argv[1:])
+    if not only or any(n.startswith("fsn_") for n in only):
+        main_fsn(only)
+        if only and all(n.startswith("fsn_") for n in only):
+            return
     FullSubNet_Plus = ref_loader.load_reference()
     assert ref_loader.reference_model_args() == ref_loader.DEFAULT_MODEL_ARGS, "inference.toml drifted"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     from . import fsnp_numpy, fsnp_torch
-    only = set(sys.argv[1:])
     for case in CASES:
         if only and case["name"] not in only:
             continue

@@ -76,3 +76,21 @@ DEFAULT_MODEL_ARGS = dict(
     kersize=[3, 5, 10],
     subband_num=1,
 )
+
+
+# [model.args] of the original FullSubNet as the reference ships them (commented alternative of
+# config/inference.toml:11,28 -> recipes' fullsubnet config): same values as above minus the FullSubNet+-only keys.
+FULLSUBNET_MODEL_ARGS = dict(
+    sb_num_neighbors=15,
+    fb_num_neighbors=0,
+    num_freqs=257,
+    look_ahead=2,
+    sequence_model="LSTM",
+    fb_output_activate_function="ReLU",
+    sb_output_activate_function=False,
+    fb_model_hidden_size=512,
+    sb_model_hidden_size=384,
+    weight_init=False,
+    norm_type="offline_laplace_norm",
+    num_groups_in_drop_band=2,
+)

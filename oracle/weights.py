@@ -113,6 +113,49 @@ def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb
     return sd
 
 
+def make_state_dict_fullsubnet(seed=0, profile="default", num_freqs=257, fb_hidden=512, sb_hidden=384,
+                                sb_num_neighbors=15, fb_num_neighbors=0, as_torch=True):
+    """Original FullSubNet (speech_enhance/fullsubnet/model/fullsubnet.py:39-57): two SequenceModel(LSTM) stacks,
+    keys ``fb_model.*`` (257 -> 512 x 2 -> 257) then ``sb_model.*`` (32 -> 384 x 2 -> 2)."""
+    assert profile in ("default", "harsh")
+    harsh = profile == "harsh"
+    rng = np.random.Generator(np.random.PCG64(50_000 + seed))
+    sd = {}
+
+    def lstm(prefix, cin, H):
+        for layer, c in ((0, cin), (1, H)):
+            p = prefix + ".sequence_model."
+            if harsh:
+                sd[p + f"weight_ih_l{layer}"] = _orthogonal(rng, 4 * H, c)
+                sd[p + f"weight_hh_l{layer}"] = _orthogonal(rng, 4 * H, H)
+                sd[p + f"bias_ih_l{layer}"] = _normal(rng, (4 * H,))
+                sd[p + f"bias_hh_l{layer}"] = _normal(rng, (4 * H,))
+            else:
+                b = 1.0 / np.sqrt(H)
+                sd[p + f"weight_ih_l{layer}"] = _uniform(rng, (4 * H, c), b)
+                sd[p + f"weight_hh_l{layer}"] = _uniform(rng, (4 * H, H), b)
+                sd[p + f"bias_ih_l{layer}"] = _uniform(rng, (4 * H,), b)
+                sd[p + f"bias_hh_l{layer}"] = _uniform(rng, (4 * H,), b)
+
+    def linear(name, cout, cin):
+        if harsh:
+            sd[name + ".weight"] = _normal(rng, (cout, cin), np.sqrt(2.0 / (cin + cout)))
+            sd[name + ".bias"] = _normal(rng, (cout,))
+        else:
+            b = 1.0 / np.sqrt(cin)
+            sd[name + ".weight"] = _uniform(rng, (cout, cin), b)
+            sd[name + ".bias"] = _uniform(rng, (cout,), b)
+
+    lstm("fb_model", num_freqs, fb_hidden)
+    linear("fb_model.fc_output_layer", num_freqs, fb_hidden)
+    lstm("sb_model", (2 * sb_num_neighbors + 1) + (2 * fb_num_neighbors + 1), sb_hidden)
+    linear("sb_model.fc_output_layer", 2, sb_hidden)
+    if as_torch:
+        import torch
+        return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    return sd
+
+
 def make_wave(batch, seconds, seed, sr=16000, scale=0.1):
     """Seeded synthetic waveform, numpy PCG64 (SURVEY.md 8d uses torch.randn*0.1; we
     avoid the torch RNG so fixtures do not depend on the torch version)."""

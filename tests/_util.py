@@ -6,13 +6,15 @@ import numpy as np
 import torch
 
 from oracle.make_golden import make_spec
-from oracle.weights import make_inputs, make_state_dict
+from oracle.weights import make_inputs, make_state_dict, make_state_dict_fullsubnet
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+def golden_names(model="plus"):
+    """Fixtures of FullSubNet+ ("plus") or of the original FullSubNet ("fullsubnet", files fsn_*)."""
+    names = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return [n for n in names if n.startswith("fsn_") == (model == "fullsubnet")]
 
 
 class Golden:
@@ -24,12 +26,21 @@ class Golden:
         self.args = self.meta["args"]
         self.sub = self.meta.get("subsample_f", 1)
 
+    @property
+    def is_fullsubnet(self):
+        return self.meta.get("model") == "fullsubnet"
+
     def state_dict(self):
+        if self.is_fullsubnet:
+            return make_state_dict_fullsubnet(self.meta["wseed"], self.meta["profile"])
         return make_state_dict(self.meta["wseed"], self.meta["profile"],
                                attention=self.args.get("channel_attention_model", "TSSE"))
 
     def inputs(self):
         inp = self.meta["inp"]
+        if "mag" in self.arrays:             # fsn_* stft fixtures keep the magnitude itself, [B,1,F,T]
+            m = torch.from_numpy(self.arrays["mag"][:, 0].transpose(0, 2, 1).copy()).permute(0, 2, 1).unsqueeze(1)
+            return m, None, None
         if "X" in self.arrays:
             X = torch.from_numpy(self.arrays["X"].transpose(0, 2, 1).copy()).permute(0, 2, 1)  # stft strides
             return X.abs().unsqueeze(1), X.real.unsqueeze(1), X.imag.unsqueeze(1)
@@ -39,6 +50,10 @@ class Golden:
 
     def fwd_kwargs(self):
         a = self.args
+        if self.is_fullsubnet:
+            return {k: a[k] for k in ("look_ahead", "sb_num_neighbors", "fb_num_neighbors", "norm_type",
+                                      "num_groups_in_drop_band", "fb_output_activate_function",
+                                      "sb_output_activate_function")}
         return dict(look_ahead=a["look_ahead"], sb_num_neighbors=a["sb_num_neighbors"],
                     fb_num_neighbors=a["fb_num_neighbors"], norm_type=a["norm_type"],
                     num_groups_in_drop_band=a["num_groups_in_drop_band"],

@@ -1,0 +1,126 @@
+"""GPU parity tests of SURVEY.md 8(f-2): the original FullSubNet ``Model``
+(speech_enhance/fullsubnet/model/fullsubnet.py:12-118) on the HIP kernels, through the C ABI, against the golden
+vectors the REAL reference produced (tests/golden/fsn_*.npz, oracle/make_golden.py) and the torch-CPU oracle
+(oracle/fsnp_torch.forward_fullsubnet) at the benchmark size.  Tolerance: 1e-3 rel (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fullsubnet_plus_amd import FullSubNet
+from oracle import fsnp_torch
+from oracle.ref_loader import FULLSUBNET_MODEL_ARGS
+from oracle.weights import make_inputs, make_state_dict_fullsubnet
+from tests._util import Golden, golden_names, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+def _record(name, **kw):
+    REPORT[name] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in kw.items()}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report_fullsubnet.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _model(args, sd, mode="parity"):
+    m = FullSubNet(**args)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    m.batch_mode = mode
+    return m
+
+
+def _cuda(t):
+    g = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device="cuda")
+    g.copy_(t)
+    return g
+
+
+@pytest.mark.parametrize("name", golden_names("fullsubnet"))
+def test_fullsubnet_forward_vs_reference_golden(name):
+    g = Golden(name)
+    m = _model(g.args, g.state_dict(), "parity")
+    mag = g.inputs()[0]
+    B, T = mag.shape[0], mag.shape[-1]
+    out = m(_cuda(mag)).cpu().numpy()
+    m.check_errors()
+    want = g.arrays["out"]
+    assert out.shape == want.shape
+    err, err64 = rel_err(out, want), rel_err(out, g.arrays["out64"])
+    rec = dict(rel_vs_ref32=err, rel_vs_ref64=err64, ref32_vs_ref64=rel_err(want, g.arrays["out64"]))
+    if "stage_fb_mag" in g.arrays:            # full-band LSTM + Linear + ReLU output, [B,F,T'] (forward hook on fb_model)
+        fb = m.read_stage("fb_mag", B, T).permute(0, 2, 1).numpy()
+        rec["fb_stage"] = rel_err(fb, g.arrays["stage_fb_mag"])
+    _record(f"forward_{name}", **rec)
+    assert err < TOL, rec
+    if "fb_stage" in rec:
+        assert rec["fb_stage"] < 2e-4, rec
+    if "full" in g.arrays:
+        m.batch_mode = "full"
+        full = m(_cuda(mag)).cpu().numpy()
+        errf = rel_err(full, g.arrays["full"])
+        _record(f"forward_full_{name}", rel_vs_ref32=errf)
+        assert errf < TOL, errf
+
+
+@pytest.mark.parametrize("batch", [32, 40])
+def test_fullsubnet_batch_vs_oracle(batch):
+    """Benchmark-sized call (one / two full-band row tiles, all bins) vs the oracle, + bitwise repeatability."""
+    sd = make_state_dict_fullsubnet(11, "harsh")
+    mag = make_inputs(batch, 1.0 if batch > 32 else 2.0, 31)[0]
+    m = _model(dict(FULLSUBNET_MODEL_ARGS), sd, "full")
+    x = _cuda(mag)
+    out = m(x)
+    out2 = m(x)
+    m.check_errors()
+    assert torch.equal(out, out2)
+    kw = {k: FULLSUBNET_MODEL_ARGS[k] for k in ("look_ahead", "sb_num_neighbors", "fb_num_neighbors", "norm_type",
+                                                "num_groups_in_drop_band", "fb_output_activate_function",
+                                                "sb_output_activate_function")}
+    pick = [0, batch // 2, batch - 1]          # the oracle is slow: check three utterances of the batch
+    want = fsnp_torch.forward_fullsubnet_full(sd, mag[pick], **kw).numpy()
+    err = rel_err(out[pick].cpu().numpy(), want)
+    _record(f"fullsubnet_b{batch}_full_vs_oracle", rel=err)
+    assert err < TOL, err
+    # parity mode rows are a sub-selection of the full rows (drop_band, feature.py:254-285)
+    m.batch_mode = "parity"
+    par = m(x).cpu().numpy()
+    full = out.cpu().numpy()
+    n0 = (batch + 1) // 2
+    for r in (0, 1, n0 - 1, n0, batch - 1):
+        s, p = (2 * r, 0) if r < n0 else (2 * (r - n0) + 1, 1)
+        assert np.abs(par[r] - full[s][:, p:256:2, :]).max() <= 1e-6 * np.abs(full).max()
+
+
+def test_fullsubnet_enhance_epilogue():
+    sd = make_state_dict_fullsubnet(12, "default")
+    mag, real, imag = make_inputs(2, 1.0, 32)
+    X = torch.complex(real[:, 0], imag[:, 0])
+    m = _model(dict(FULLSUBNET_MODEL_ARGS), sd, "parity")
+    Xg = torch.empty_strided(X.shape, X.stride(), dtype=X.dtype, device="cuda")
+    Xg.copy_(X)
+    got = m.enhance(Xg).cpu()
+    kw = {k: FULLSUBNET_MODEL_ARGS[k] for k in ("look_ahead", "sb_num_neighbors", "fb_num_neighbors", "norm_type",
+                                                "num_groups_in_drop_band", "fb_output_activate_function",
+                                                "sb_output_activate_function")}
+    mask = fsnp_torch.forward_fullsubnet_full(sd, X.abs().unsqueeze(1), **kw)
+    want = fsnp_torch.apply_cirm(mask, X)
+    err = float((got - want).abs().max() / want.abs().max())
+    _record("fullsubnet_enhance", rel=err)
+    assert err < TOL
+
+
+def test_fullsubnet_rejects_oversized_batch():
+    m = _model(dict(FULLSUBNET_MODEL_ARGS), make_state_dict_fullsubnet(0), "full")
+    x = torch.rand(513, 1, 257, 9, device="cuda")
+    with pytest.raises(RuntimeError, match="split the batch"):
+        m(x)

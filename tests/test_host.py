@@ -10,9 +10,9 @@ import numpy as np
 import pytest
 import torch
 
-from fullsubnet_plus_amd import FullSubNet_Plus, Model, _lib
-from oracle.ref_loader import DEFAULT_MODEL_ARGS
-from oracle.weights import make_state_dict
+from fullsubnet_plus_amd import FullSubNet, FullSubNet_Plus, Model, _lib
+from oracle.ref_loader import DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS
+from oracle.weights import make_state_dict, make_state_dict_fullsubnet
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -184,3 +184,91 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
             assert l["mfma"] % 16 == 0 and l["gload"] * 4 == l["mfma"], (key, l)
             if "_NW4_" in key and ("_EX0_" in key or "_EX1_" in key):   # the production fp32 kernels
                 assert l["drain"] == 0, (key, l)
+
+
+# ---------------------------------------------------------------- cooperative kernel weight stream (csrc/lstm_coop.hip)
+@pytest.mark.parametrize("H,NIN,KX,units", [(384, 34, 40, 8), (384, 34, 40, 16), (384, 32, 40, 32), (384, 34, 40, 64),
+                                            (512, 257, 264, 8), (512, 257, 264, 32)])
+def test_lstm_coop_pack_matches_mfma_fragment_emulation(H, NIN, KX, units):
+    """Emulates what lstm2_coop_kernel does with the packed stream: workgroup cs, wave w walks its local k-groups
+    (global k-group 4 i + w), multiplies the A fragments of [x | h0] / [h1 | h0] with the packed B fragments, the four
+    waves' partial tiles are summed, column j = gate * units + unit."""
+    lib = _lib.load()
+    rng = np.random.default_rng(units + H)
+    wih0 = rng.standard_normal((4 * H, NIN)).astype(np.float32)
+    whh0 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    wih1 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    whh1 = rng.standard_normal((4 * H, H)).astype(np.float32)
+    S, NT = H // units, units // 8
+    KGXP, KGH = (KX // 8 + 3) // 4 * 4, H // 8
+    G0W, G1W = (KGXP + KGH) // 4, KGH // 2
+    GW = G0W + G1W
+    n = S * 4 * GW * NT * 64 * 4
+    pack = np.zeros(n, dtype=np.float32)
+    rc = lib.fsnp_debug_lstm_coop_pack(H, NIN, KX, units, wih0.ctypes.data, whh0.ctypes.data, wih1.ctypes.data,
+                                       whh1.ctypes.data, pack.ctypes.data, n)
+    assert rc == 0, lib.fsnp_last_error()
+    pack = pack.reshape(S, 4, GW, NT, 64, 4).astype(np.float64)
+
+    def a_img(mat, groups):  # [32][K] -> [groups][64 lanes][4], lane = row + 32 (k & 1), component (k >> 1) & 3
+        img = np.zeros((groups, 64, 4))
+        for k in range(mat.shape[1]):
+            img[k >> 3, (k & 1) * 32 + np.arange(32), (k >> 1) & 3] = mat[:, k]
+        return img
+
+    x = rng.standard_normal((32, NIN)); h0 = rng.standard_normal((32, H)); h1 = rng.standard_normal((32, H))
+    ximg, h0img, h1img = a_img(x, KGXP), a_img(h0, KGH), a_img(h1, KGH)
+    got = np.zeros((2, 32, 4 * H))
+    for cs in range(S):
+        for layer, (G, base, first, nfirst, second) in enumerate(((G0W, 0, ximg, KGXP, h0img), (G1W, G0W, h1img, KGH, h0img))):
+            acc = np.zeros((NT, 32, 32))
+            for wave in range(4):
+                for i in range(G):
+                    g = 4 * i + wave
+                    A = first[g] if g < nfirst else second[g - nfirst]          # [64][4]
+                    Bf = pack[cs, wave, base + i]                               # [NT][64][4]
+                    for p in range(4):
+                        Am = np.stack([A[:32, p], A[32:, p]], axis=1)            # [row][k half]
+                        for t in range(NT):
+                            Bm = np.stack([Bf[t, :32, p], Bf[t, 32:, p]], axis=0)  # [k half][col]
+                            acc[t] += Am @ Bm
+            for t in range(NT):
+                for col in range(32):
+                    j = t * 32 + col
+                    got[layer, :, (j // units) * H + cs * units + j % units] = acc[t, :, col]
+    want0 = x @ wih0.T.astype(np.float64) + h0 @ whh0.T.astype(np.float64)
+    want1 = h1 @ whh1.T.astype(np.float64) + h0 @ wih1.T.astype(np.float64)
+    assert np.abs(got[0] - want0).max() < 1e-9
+    assert np.abs(got[1] - want1).max() < 1e-9
+
+
+# ---------------------------------------------------------------- SURVEY.md 8(f-2): the original FullSubNet
+def test_fullsubnet_module_has_reference_parameter_tree_and_strict_load():
+    m = FullSubNet(**FULLSUBNET_MODEL_ARGS)
+    sd = make_state_dict_fullsubnet(0)
+    own = m.state_dict()
+    assert list(own.keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(own[k].shape) == tuple(sd[k].shape), k
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    bad = dict(sd); bad.pop("fb_model.fc_output_layer.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    from fullsubnet_plus_amd.fullsubnet import Model as FsnModel
+    assert FsnModel is FullSubNet
+    for attr in ("num_groups_in_drop_band", "look_ahead", "sb_num_neighbors", "fb_num_neighbors"):
+        assert getattr(m, attr) == FULLSUBNET_MODEL_ARGS[attr]
+
+
+def test_fullsubnet_error_behaviour_matches_reference():
+    args = dict(FULLSUBNET_MODEL_ARGS)
+    with pytest.raises(AssertionError):                       # fullsubnet.py:37
+        FullSubNet(**{**args, "sequence_model": "TCN"})
+    with pytest.raises(NotImplementedError):                  # base_model.py:328
+        FullSubNet(**{**args, "norm_type": "nope"})
+    m = FullSubNet(**args)
+    with pytest.raises(AssertionError):                       # fullsubnet.py:81
+        m(torch.zeros(1, 257, 10))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 257, 10))

@@ -76,3 +76,31 @@ def test_state_dict_matches_reference_parameter_tree():
     for k in sd:
         assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), k
     assert sum(v.numel() for v in sd.values()) == 8_675_102
+
+
+# ---------------------------------------------------------------- the original FullSubNet
+@pytest.mark.parametrize("name", golden_names("fullsubnet"))
+def test_fullsubnet_torch_port_matches_reference(name):
+    g = Golden(name)
+    mag = g.inputs()[0]
+    stages = {}
+    out = fsnp_torch.forward_fullsubnet(g.state_dict(), mag, stages=stages, **g.fwd_kwargs()).numpy()
+    assert out.shape == g.arrays["out"].shape
+    assert rel_err(out, g.arrays["out"]) < 2e-5
+    if "full" in g.arrays:
+        full = fsnp_torch.forward_fullsubnet_full(g.state_dict(), mag, **g.fwd_kwargs()).numpy()
+        assert rel_err(full, g.arrays["full"]) < 2e-5
+    if "stage_fb_mag" in g.arrays:
+        assert rel_err(stages["fb_mag"].numpy(), g.arrays["stage_fb_mag"]) < 2e-5
+
+
+def test_fullsubnet_state_dict_matches_reference_parameter_tree():
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted")
+    from oracle.weights import make_state_dict_fullsubnet
+    ref = ref_loader.load_reference_fullsubnet()(**ref_loader.FULLSUBNET_MODEL_ARGS)
+    sd = make_state_dict_fullsubnet(0)
+    rsd = ref.state_dict()
+    assert list(sd.keys()) == list(rsd.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(rsd[k].shape), k
