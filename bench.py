@@ -44,12 +44,14 @@ def parse():
     ap.add_argument("--norm", default="offline_laplace_norm")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_ih"],
                     help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
+    ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
+                    help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
 
 
-def cpu_baseline(sd, inputs, budget_s, norm):
+def cpu_baseline(sd, inputs, budget_s, norm, fullsubnet=False):
     """Time the torch-CPU port of the reference forward on host cores, one utterance per call
     (== "full" semantics), until the time budget is used.  torch's CPU LSTM
     collapses when oversubscribed (256 threads on the GPU box: 118 s per utterance), so the thread count
@@ -57,13 +59,19 @@ def cpu_baseline(sd, inputs, budget_s, norm):
     from oracle import fsnp_torch
     mag, real, imag = inputs
     T = mag.shape[-1]
+    if fullsubnet:
+        def fwd(m, r, i, norm_type):
+            return fsnp_torch.forward_fullsubnet_full(sd, m, norm_type=norm_type)
+    else:
+        def fwd(m, r, i, norm_type):
+            return fsnp_torch.forward_full(sd, m, r, i, norm_type=norm_type)
     ncpu = os.cpu_count() or 1
     best_threads, best_dt = 1, float("inf")
     for th in [c for c in (8, 16, 32) if c <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
-        fsnp_torch.forward_full(sd, mag[:1], real[:1], imag[:1], norm_type=norm)  # warm-up
+        fwd(mag[:1], real[:1], imag[:1], norm)  # warm-up
         t0 = time.perf_counter()
-        fsnp_torch.forward_full(sd, mag[:1], real[:1], imag[:1], norm_type=norm)
+        fwd(mag[:1], real[:1], imag[:1], norm)
         dt = time.perf_counter() - t0
         if dt < best_dt:
             best_threads, best_dt = th, dt
@@ -71,7 +79,7 @@ def cpu_baseline(sd, inputs, budget_s, norm):
     done, t0 = 0, time.perf_counter()
     out0 = None
     while done < mag.shape[0]:
-        o = fsnp_torch.forward_full(sd, mag[done:done + 1], real[done:done + 1], imag[done:done + 1], norm_type=norm)
+        o = fwd(mag[done:done + 1], real[done:done + 1], imag[done:done + 1], norm)
         if out0 is None:
             out0 = o
         done += 1
@@ -99,13 +107,18 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from fullsubnet_plus_amd import FullSubNet_Plus
-    from oracle.ref_loader import DEFAULT_MODEL_ARGS
-    from oracle.weights import make_inputs, make_state_dict
+    from fullsubnet_plus_amd import FullSubNet, FullSubNet_Plus
+    from oracle.ref_loader import DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS
+    from oracle.weights import make_inputs, make_state_dict, make_state_dict_fullsubnet
 
-    model_args = {**DEFAULT_MODEL_ARGS, "norm_type": args.norm}
-    sd = make_state_dict(0, "default")
-    model = FullSubNet_Plus(**model_args)
+    fsn = args.model == "fullsubnet"
+    if fsn:
+        assert args.precision == "fp32", "the bf16 ih-GEMM variant is defined for FullSubNet+ only"
+        sd = make_state_dict_fullsubnet(0, "default")
+        model = FullSubNet(**{**FULLSUBNET_MODEL_ARGS, "norm_type": args.norm})
+    else:
+        sd = make_state_dict(0, "default")
+        model = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": args.norm})
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.batch_mode = args.mode
@@ -118,6 +131,8 @@ def main():
         g.copy_(t)
         gpu_in.append(g)
     T = cpu_in[0].shape[-1]
+    if fsn:
+        gpu_in = gpu_in[:1]                                      # the original FullSubNet takes the magnitude only
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -173,7 +188,7 @@ def main():
             traffic = json.load(f).get("traffic_bytes_per_launch")
 
     result = {
-        "metric": "STFT frames/sec (257-bin, 2 s clips), FullSubNet+ forward",
+        "metric": "STFT frames/sec (257-bin, 2 s clips), " + ("FullSubNet forward" if fsn else "FullSubNet+ forward"),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 + bf16 ih-GEMM (configs[4])",
@@ -190,7 +205,7 @@ def main():
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ref0 = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm)
+        base, ref0 = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
         result["cpu_baseline"] = base
         if args.mode == "full":
             got = out[:1].cpu()
