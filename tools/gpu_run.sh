@@ -22,7 +22,7 @@ fi
 if [[ "$WHAT" == "all" || "$WHAT" == *prof* ]]; then
   echo "== rocprofv3 kernel trace" | tee -a gpurun_out/run.log
   rm -rf gpurun_out/prof
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
   tail -2 gpurun_out/prof_bench.log
   find gpurun_out/prof -name "*stats*" | head
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
