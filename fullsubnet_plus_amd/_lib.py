@@ -35,6 +35,7 @@ SYMBOLS = {
     "fsnp_workspace_bytes": (ctypes.c_size_t, [c_vp, c_i32, c_i32, c_i32]),
     "fsnp_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64 * 3 * 3), c_vp, c_i32, c_i32, c_i32,
                              c_i32, c_i32, c_vp]),
+    "fsnp_forward_complex": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_apply_cirm": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, ctypes.POINTER(c_i64 * 3), c_i32, c_i32,
                                 c_i32, c_vp]),
     "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

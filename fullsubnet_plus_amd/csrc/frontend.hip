@@ -52,6 +52,45 @@ __global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __r
     }
 }
 
+// the same repack straight from the interleaved complex64 STFT buffer (torch.stft's output; strides
+// in complex elements): real and imag are the two halves of each element, mag = |X| is derived here instead of by a
+// torch op (audio_zen/acoustics/feature.py:24-31 `mag_phase`, inferencer.py:143-147).  nbr = 3: [mag, real, imag]
+// planes; nbr = 1: magnitude only (original FullSubNet).
+__global__ __launch_bounds__(256) void fe_repack_complex_kernel(const float2* __restrict__ x, long sb, long sf, long st,
+                                                                float* __restrict__ raw, int nbr, int B, int T, int Tp,
+                                                                int F, int FP) {
+    __shared__ float2 tile[32][33];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float2* __restrict__ src = x + (long)b * sb;
+    const bool f_fast = sf <= st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        if (f_fast) {
+            const int f = f0 + tx, t = t0 + r;
+            tile[r][tx] = (f < F && t < T) ? src[f * sf + t * st] : make_float2(0.f, 0.f);
+        } else {
+            const int t = t0 + tx, f = f0 + r;
+            tile[tx][r] = (f < F && t < T) ? src[f * sf + t * st] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const long plane = (long)B * Tp * FP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 8 * i;
+        const int t = t0 + r, f = f0 + tx;
+        if (t < Tp && f < FP) {
+            const float2 v = tile[r][tx];
+            const long o = ((long)b * Tp + t) * FP + f;
+            raw[o] = hypotf(v.x, v.y);
+            if (nbr == 3) { raw[plane + o] = v.x; raw[2 * plane + o] = v.y; }
+        }
+    }
+}
+
 // one wave per (branch, utt, t)
 __global__ __launch_bounds__(64) void fe_frame_kernel(const float* __restrict__ raw, double* __restrict__ frame, int B,
                                                       int Tp, int F, int FP) {
@@ -295,15 +334,21 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
                        out_strides[2], B, F, T);
 }
 
-void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
+void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
                      const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s) {
-    StridedIn si;
-    for (int i = 0; i < 3; ++i) {
-        si.p[i] = in[i];
-        si.sb[i] = strides[i][0]; si.sf[i] = strides[i][1]; si.st[i] = strides[i][2];
+    if (is_complex) {
+        hipLaunchKernelGGL(fe_repack_complex_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s,
+                           reinterpret_cast<const float2*>(in[0]), (long)strides[0][0], (long)strides[0][1],
+                           (long)strides[0][2], buf.raw, 3, d.B, d.T, d.Tp, d.F, d.FP);
+    } else {
+        StridedIn si;
+        for (int i = 0; i < 3; ++i) {
+            si.p[i] = in[i];
+            si.sb[i] = strides[i][0]; si.sf[i] = strides[i][1]; si.st[i] = strides[i][2];
+        }
+        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw,
+                           d.B, d.T, d.Tp, d.F, d.FP);
     }
-    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw,
-                       d.B, d.T, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
     hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, FSUM_ROWS), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,
@@ -320,15 +365,21 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
 }
 
 // speech_enhance/fullsubnet/model/fullsubnet.py:82-89: pad the look-ahead, norm(noisy_mag) - one branch, no attention.
-void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3],
+void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3], bool is_complex,
                          const FrontendBuffers& buf, hipStream_t s) {
-    StridedIn si;
-    for (int i = 0; i < 3; ++i) {
-        si.p[i] = mag;
-        si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2];
+    if (is_complex) {
+        hipLaunchKernelGGL(fe_repack_complex_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s,
+                           reinterpret_cast<const float2*>(mag), (long)strides[0], (long)strides[1], (long)strides[2],
+                           buf.raw, 1, d.B, d.T, d.Tp, d.F, d.FP);
+    } else {
+        StridedIn si;
+        for (int i = 0; i < 3; ++i) {
+            si.p[i] = mag;
+            si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2];
+        }
+        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw,
+                           d.B, d.T, d.Tp, d.F, d.FP);
     }
-    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw,
-                       d.B, d.T, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 1), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 1), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
 }

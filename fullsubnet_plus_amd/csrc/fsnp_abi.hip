@@ -560,12 +560,12 @@ size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames,
     return plan_workspace(h, batch, frames, mode).total;
 }
 
-int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
-                 const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
-                 int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
+static int forward_impl(fsnp_handle* h, const float* mag, const float* real, const float* imag, bool is_complex,
+                        const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
+                        int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
     if (!h || !mag || !out || !strides) { set_error("fsnp_forward: null argument"); return 1; }
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
-    if (!fsn && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
+    if (!fsn && !is_complex && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
     if (!h->committed) { set_error("fsnp_forward: weights not committed (call fsnp_commit_weights)"); return 2; }
     if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
@@ -608,7 +608,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
         fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
         fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
         const float* in[3] = {mag, real, imag};
-        launch_frontend(d, h->cfg.norm_type, in, strides, h->fw, fbuf, s);
+        launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s);
 
         TcnBuffers tbuf;
         tbuf.att = fptr(w.att); tbuf.x = fptr(w.x); tbuf.y1 = fptr(w.y1); tbuf.y2 = fptr(w.y2);
@@ -620,7 +620,7 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
         FrontendBuffers fbuf{};
         fbuf.raw = fptr(w.att); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
         fbuf.md = reinterpret_cast<NormMD*>(base + w.md);
-        launch_frontend_mag(d, h->cfg.norm_type, mag, strides[0], fbuf, s);
+        launch_frontend_mag(d, h->cfg.norm_type, mag, strides[0], is_complex, fbuf, s);
         const int fb_tiles = fb_row_tiles(batch);
         RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * 32, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, 32,
@@ -668,6 +668,21 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
     FSNP_HIP_CHECK(hipGetLastError());
     h->last_ws = w; h->last_dims = d; h->have_last = true;
     return 0;
+}
+
+int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
+                 const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
+                 int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
+    return forward_impl(h, mag, real, imag, false, strides, out, batch, frames, mode, batch_offset, global_batch, hip_stream);
+}
+
+int fsnp_forward_complex(fsnp_handle* h, const float* noisy, const int64_t strides[3], float* out, int32_t batch,
+                         int32_t frames, int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
+    if (!strides) { set_error("fsnp_forward_complex: null argument"); return 1; }
+    int64_t st[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) st[i][j] = strides[j];
+    return forward_impl(h, noisy, nullptr, nullptr, true, st, out, batch, frames, mode, batch_offset, global_batch, hip_stream);
 }
 
 int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,

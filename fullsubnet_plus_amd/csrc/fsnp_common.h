@@ -53,10 +53,12 @@ struct FrontendBuffers {
 
 void launch_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
                        const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
-void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3],
+// is_complex: in[0] is the interleaved complex64 STFT buffer (strides[0] in complex elements); mag / real / imag are
+// derived inside the repack kernel
+void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
                      const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
 // original FullSubNet: magnitude only - repack into buf.raw [B][Tp][FP] and the norm's (m_t, d_t) table into buf.md
-void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3],
+void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3], bool is_complex,
                          const FrontendBuffers& buf, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

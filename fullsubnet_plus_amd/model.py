@@ -175,12 +175,17 @@ class _HipModel(nn.Module):
             raise RuntimeError("no HIP handle yet: run a forward on a CUDA tensor first")
         return self._hip.handle
 
-    def _forward_impl(self, ins, batch_offset, global_batch):
-        """ins: 1 (FullSubNet) or 3 (FullSubNet+) tensors [B, 1, F, T]; returns the cIRM tensor."""
+    def _forward_impl(self, ins, batch_offset, global_batch, complex_in=False):
+        """ins: 1 (FullSubNet) or 3 (FullSubNet+) tensors [B, 1, F, T], or - complex_in - ONE complex64 [B, F, T]
+        tensor (the STFT itself, fsnp_forward_complex); returns the cIRM tensor."""
         noisy_mag = ins[0]
-        assert noisy_mag.dim() == 4
-        batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
-        assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
+        if complex_in:
+            assert noisy_mag.dim() == 3 and noisy_mag.dtype == torch.complex64
+            batch_size, num_freqs, num_frames = noisy_mag.size()
+        else:
+            assert noisy_mag.dim() == 4
+            batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
+            assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
         for t in ins[1:]:
             assert t.shape == noisy_mag.shape
         assert num_freqs == self.num_freqs, f"expected {self.num_freqs} frequency bins, got {num_freqs}"
@@ -196,7 +201,8 @@ class _HipModel(nn.Module):
                 f"The batch size should larger than the num_groups."
             if self.num_groups_in_drop_band != 2:
                 raise NotImplementedError("HIP path: drop_band with num_groups != 2 is not built yet")
-        ins = [t if t.dtype == torch.float32 else t.float() for t in ins]
+        if not complex_in:
+            ins = [t if t.dtype == torch.float32 else t.float() for t in ins]
         for t in ins:
             assert t.device == device
         lib = self._ensure_handle(device)
@@ -205,19 +211,46 @@ class _HipModel(nn.Module):
         out = torch.empty((gb if parity else batch_size, 2, out_f, num_frames), dtype=torch.float32, device=device)
         if parity and not standalone:
             out.zero_()     # a shard writes only its own rows of the global tensor
+        stream = torch.cuda.current_stream(device).cuda_stream
+        mode = _lib.MODE_PARITY if parity else _lib.MODE_FULL
+        if complex_in:
+            cst = (ctypes.c_int64 * 3)(*noisy_mag.stride())
+            with torch.cuda.device(device):
+                rc = lib.fsnp_forward_complex(self._handle, torch.view_as_real(noisy_mag).data_ptr(), ctypes.byref(cst),
+                                              out.data_ptr(), batch_size, num_frames, mode, int(batch_offset), gb,
+                                              ctypes.c_void_p(stream))
+            _lib.check(rc, "fsnp_forward_complex")
+            return out
         strides = (ctypes.c_int64 * 3 * 3)()
         for i, t in enumerate(ins):
             sb, _, sf, st = t.stride()
             strides[i][0], strides[i][1], strides[i][2] = sb, sf, st
         ptrs = [t.data_ptr() for t in ins] + [None] * (3 - len(ins))
-        stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
             rc = lib.fsnp_forward(self._handle, ptrs[0], ptrs[1], ptrs[2],
                                   ctypes.byref(strides), out.data_ptr(), batch_size, num_frames,
-                                  _lib.MODE_PARITY if parity else _lib.MODE_FULL, int(batch_offset), gb,
-                                  ctypes.c_void_p(stream))
+                                  mode, int(batch_offset), gb, ctypes.c_void_p(stream))
         _lib.check(rc, "fsnp_forward")
         return out
+
+    def forward_complex(self, noisy_complex, batch_offset=0, global_batch=None):
+        """the forward fed with the complex64 STFT itself ([B, F, T], any strides - torch.stft's
+        output is consumed in place); mag / real / imag are derived inside the HIP repack kernel instead of by the
+        three torch ops of inferencer.py:143-147.  Same result as forward(|X|, X.real, X.imag)."""
+        return self._forward_impl([noisy_complex], batch_offset, global_batch, complex_in=True)
+
+    def enhance(self, noisy_complex):
+        """SURVEY.md 8(f-1) + (f-3): model forward + decompress_cIRM + complex multiply, all in HIP - lines 143-157 of
+        fullsubnet_plus/inferencer/inferencer.py (`full_band_crm_mask` of fullsubnet/inferencer/inferencer.py for the
+        original FullSubNet): noisy_complex [B,F,T] complex64 (torch.stft output, any strides) -> enhanced complex
+        [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
+        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
+        mode, self.batch_mode = self.batch_mode, "full"
+        try:
+            mask = self.forward_complex(noisy_complex)
+        finally:
+            self.batch_mode = mode
+        return self._apply_cirm(mask, noisy_complex)
 
     def _apply_cirm(self, mask, noisy_complex):
         B, F, T = noisy_complex.shape
@@ -407,19 +440,6 @@ class FullSubNet_Plus(_HipModel):
         """
         return self._forward_impl([noisy_mag, noisy_real, noisy_imag], batch_offset, global_batch)
 
-    def enhance(self, noisy_complex):
-        """model forward + decompress_cIRM + complex multiply in HIP, i.e. lines 143-157 of
-        fullsubnet_plus/inferencer/inferencer.py: noisy_complex [B,F,T] complex64 (torch.stft output, any strides)
-        -> enhanced complex [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
-        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
-        mode, self.batch_mode = self.batch_mode, "full"
-        try:
-            mask = self.forward(noisy_complex.abs().unsqueeze(1), noisy_complex.real.unsqueeze(1),
-                                noisy_complex.imag.unsqueeze(1))
-        finally:
-            self.batch_mode = mode
-        return self._apply_cirm(mask, noisy_complex)
-
 
 class _FullBandLSTMParams(nn.Module):
     """Parameter holder named like SequenceModel(sequence_model="LSTM") of the original FullSubNet's full-band model
@@ -504,17 +524,6 @@ class FullSubNet(_HipModel):
         """noisy_mag [B, 1, F, T] fp32 CUDA tensor (any strides) -> cIRM [B, 2, F, T] (see FullSubNet_Plus.forward
         for batch_mode and the sharding arguments)."""
         return self._forward_impl([noisy_mag], batch_offset, global_batch)
-
-    def enhance(self, noisy_complex):
-        """fullsubnet/inferencer/inferencer.py `full_band_crm_mask`: forward on |X| + decompress_cIRM + complex
-        multiply -> enhanced complex [B,F,T] ready for torch.istft (all bins kept)."""
-        assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
-        mode, self.batch_mode = self.batch_mode, "full"
-        try:
-            mask = self.forward(noisy_complex.abs().unsqueeze(1))
-        finally:
-            self.batch_mode = mode
-        return self._apply_cirm(mask, noisy_complex)
 
 
 Model = FullSubNet_Plus  # the name BASELINE.json's north_star uses

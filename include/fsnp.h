@@ -119,6 +119,13 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
                  const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
                  int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream);
 
+/* the same forward fed with the interleaved complex64 STFT buffer itself (what torch.stft returns;
+ * inferencer.py:142-147 derives mag / real / imag from it with three torch ops): element (b,f,t) is the float pair at
+ * noisy + 2*(b*strides[0] + f*strides[1] + t*strides[2]) (strides in complex elements).  mag = |X| is computed by the
+ * repack kernel; for FSNP_MODEL_FULLSUBNET only the magnitude is derived.  Other arguments as fsnp_forward. */
+int fsnp_forward_complex(fsnp_handle* h, const float* noisy, const int64_t strides[3], float* out, int32_t batch,
+                         int32_t frames, int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream);
+
 /* the step right after the model in the reference inferencer
  * (`decompress_cIRM` speech_enhance/audio_zen/acoustics/mask.py:60-63 + complex multiply
  * speech_enhance/fullsubnet_plus/inferencer/inferencer.py:152-157) as one kernel.

@@ -340,3 +340,21 @@ def test_long_clip_cumulative_norms_vs_oracle():
         assert err < max(TOL, 2 * ref_err), (name, err, ref_err)
         if name != "cumulative_laplace_norm":
             assert err < TOL and ref_err < TOL, (name, err, ref_err)
+
+
+def test_forward_complex_equals_three_plane_forward():
+    """fsnp_forward_complex derives mag / real / imag from the complex64 STFT buffer in the repack
+    kernel; result == forward(|X|, X.real, X.imag) up to the rounding of |X| (hypotf vs torch.abs)."""
+    g = Golden("b1_2s_default")
+    m = _model(g.args, g.state_dict(), "full")
+    mag, real, imag = g.inputs()
+    X = torch.complex(real[:, 0], imag[:, 0])                     # [B,F,T] with stft strides
+    Xg = torch.empty_strided(X.shape, X.stride(), dtype=X.dtype, device="cuda")
+    Xg.copy_(X)
+    a = m.forward_complex(Xg).cpu().numpy()
+    b = m(*_cuda((mag, real, imag))).cpu().numpy()
+    _record("forward_complex_vs_planes", rel=rel_err(a, b), vs_ref=rel_err(a, g.arrays["out"]))
+    assert rel_err(a, b) < 1e-5
+    assert rel_err(a, g.arrays["out"]) < TOL
+    with pytest.raises(AssertionError):
+        m.forward_complex(Xg.unsqueeze(1))
