@@ -196,11 +196,29 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
 
 // The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
 // would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
-static int coop_units(const fsnp_handle* h, const LstmPlan& lp) {   // hidden units per workgroup; 0 = use the row-tile kernel
-    if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return 0;   // the cooperative kernel is fp32 only
-    return lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
+// Which sub-band LSTM kernel runs `lp`: the row-tile kernel needs >= 256 tiles to fill the chip and costs ~208 us per
+// step however few tiles exist; the column-split kernels pay one inter-workgroup barrier per step instead.
+//   <= 42 row tiles  : lstm_coop.hip  (K split, 8..64 hidden units per workgroup, row_tiles * H/units <= CUs)
+//   43..170 row tiles: lstm_coopn.hip (3 workgroups x 128 units share 1-2 row tiles)
+struct SbKernel { int kind; int units; int groups; int rpg; };   // kind 0 = row tile, 1 = coop (K split), 2 = coopn
+static SbKernel sb_kernel(const fsnp_handle* h, const LstmPlan& lp) {
+    SbKernel k{0, 0, 0, 0};
+    if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return k;   // the cooperative kernels are fp32 only
+    k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
+    if (k.units != 0) { k.kind = 1; return k; }
+    k.rpg = lstm_coopn_plan(h->H, lp.num_tiles, h->num_cus_real, &k.groups);
+    if (k.rpg != 0) k.kind = 2;
+    return k;
 }
-static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return coop_units(h, lp) != 0; }
+static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return sb_kernel(h, lp).kind != 0; }
+static void launch_sb_lstm(const fsnp_handle* h, const LstmPlan& lp, LstmArgs& a, float* hx, unsigned* bar, hipStream_t s) {
+    const SbKernel k = sb_kernel(h, lp);
+    if (k.kind == 0) { launch_lstm(h->lw, a, s); return; }
+    a.coop_hx = hx; a.coop_bar = bar; a.coop_err = h->d_err;
+    a.coop_units = k.units; a.coop_groups = k.groups; a.coop_rows_per_group = k.rpg;
+    if (k.kind == 1) launch_lstm_coop(h->lw, a, s);
+    else launch_lstm_coopn(h->lw, a, s);
+}
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
 static int fb_row_tiles(int B) { return cdiv(B, 32); }
 static int fb_coop_units(const fsnp_handle* h, int B) {
@@ -482,6 +500,9 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm_coop_pack_weights(H, h->NIN, h->KX, units, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
                                W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[ui]);
     }
+    const size_t o_wpack_coopn = alloc(lstm_coopn_pack_floats(H, h->KX));
+    lstm_coopn_pack_weights(H, h->NIN, h->KX, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
+                            W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coopn);
     // ---- original FullSubNet: full-band LSTM (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
     size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
@@ -540,6 +561,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
     for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
+    h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
     if (fsn) {
@@ -654,13 +676,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
     a.num_rows = num_rows; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.act = h->cfg.sb_act;
-    if (use_coop(h, lp)) {
-        a.coop_hx = fptr(w.coop_hx); a.coop_bar = reinterpret_cast<unsigned*>(base + w.coop_bar); a.coop_err = h->d_err;
-        a.coop_units = coop_units(h, lp);
-        launch_lstm_coop(h->lw, a, s);
-    } else {
-        launch_lstm(h->lw, a, s);
-    }
+    launch_sb_lstm(h, lp, a, fptr(w.coop_hx), reinterpret_cast<unsigned*>(base + w.coop_bar), s);
     if (h->timing) {
         FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
         h->timing_recs.push_back(rec);
@@ -716,15 +732,8 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
-    if (coop) {
-        a.coop_hx = reinterpret_cast<float*>(h->ws + coop_off);
-        a.coop_bar = reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes);
-        a.coop_err = h->d_err;
-        a.coop_units = coop_units(h, lp);
-        launch_lstm_coop(h->lw, a, s);
-    } else {
-        launch_lstm(h->lw, a, s);
-    }
+    launch_sb_lstm(h, lp, a, reinterpret_cast<float*>(h->ws + coop_off),
+                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes), s);
     FSNP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -122,6 +122,7 @@ struct LstmWeights {
     const float* wpack_bf[2];   // bf16-ih streams (4-wave, 12-wave): layer-1 W_ih as bf16 k-steps (configs[4])
     int ih_bf16;                // 1 = use them
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
+    const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]
@@ -155,6 +156,8 @@ struct LstmArgs {
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
     unsigned* coop_err;        // set to 1 if a barrier wait timed out
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
+    int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
+    int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
@@ -167,6 +170,12 @@ size_t lstm_coop_pack_floats(int H, int KX, int units);
 void lstm_coop_pack_weights(int H, int NIN, int KX, int units, const float* wih0, const float* whh0, const float* wih1,
                             const float* whh1, float* wpack);
 size_t lstm_coop_exchange_bytes(int H, int row_tiles);
+// lstm_coopn.hip: 3 workgroups x 128 hidden units share 1-2 row tiles (43..170 row tiles)
+void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t lstm_coopn_pack_floats(int H, int KX);
+void lstm_coopn_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1,
+                             const float* whh1, float* wpack);
+int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups);   // rows tiles per group (0 = not applicable)
 int lstm_coop_pick_units(int H, int row_tiles, int num_cus, int min_units);   // 0 = not applicable
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack

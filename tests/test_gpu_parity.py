@@ -90,10 +90,13 @@ def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
     assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
 
 
-@pytest.mark.parametrize("n,steps", [(20, 5), (70, 33), (257, 128), (672, 9), (1000, 17), (1300, 12)])
+@pytest.mark.parametrize("n,steps", [(20, 5), (70, 33), (257, 128), (672, 9), (1000, 17), (1300, 12),
+                                     (1400, 9), (2700, 21), (2750, 8), (4112, 14), (5440, 6)])
 def test_lstm2_fc_cooperative_kernel(n, steps):
-    """Column-split kernel (csrc/lstm_coop.hip): 12 workgroups share each 32-row tile and exchange h through
-    global memory with one agent-scope barrier per step; must match the oracle and the row-tile kernel."""
+    """Column-split kernels: csrc/lstm_coop.hip (<= 42 row tiles: 6..48 workgroups share each 32-row tile, K split over
+    the waves) and csrc/lstm_coopn.hip (43..170 row tiles: n = 1400..5440 here - 3 workgroups share 1 or 2 row tiles,
+    incl. an odd tile count whose last group owns one tile).  h is exchanged through global memory with one agent-scope
+    barrier per step; results must match the oracle and the row-tile kernel."""
     sd = make_state_dict(9, "harsh")
     m = _model(DEFAULT_MODEL_ARGS, sd)
     rng = np.random.Generator(np.random.PCG64(77 + n))
@@ -111,6 +114,25 @@ def test_lstm2_fc_cooperative_kernel(n, steps):
     m.debug_set_lstm_coop(0)
     tile = m.lstm2_fc(x.cuda()).cpu().numpy()
     assert rel_err(tile, want) < 2e-5
+
+
+def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle():
+    """B = 8 (65 row tiles -> lstm_coopn.hip, one row tile per group) through the whole forward, cumulative norm
+    (per-row (m, d) tables) included."""
+    for norm in ("offline_laplace_norm", "cumulative_layer_norm"):
+        args = {**DEFAULT_MODEL_ARGS, "norm_type": norm}
+        sd = make_state_dict(21, "harsh")
+        m = _model(args, sd, "full")
+        cpu_in = make_spec(8, 22, 77)
+        ins = _cuda(cpu_in)
+        m.debug_set_lstm_coop(1)
+        a = m(*ins).cpu().numpy()
+        m.check_errors()
+        m.debug_set_lstm_coop(0)
+        b = m(*ins).cpu().numpy()
+        want = fsnp_torch.forward_full(sd, *[t[2:4] for t in cpu_in], norm_type=norm).numpy()
+        _record(f"forward_b8_coopn_{norm}", coop_vs_tile=rel_err(a, b), coop_vs_oracle=rel_err(a[2:4], want))
+        assert rel_err(a, b) < 1e-5 and rel_err(a[2:4], want) < TOL
 
 
 def test_forward_b1_cooperative_equals_row_tile_kernel():
