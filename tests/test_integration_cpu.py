@@ -54,3 +54,23 @@ def test_shims_cover_what_the_reference_cli_imports():
         sys.path.remove(os.path.join(ROOT, "shims"))
         for m in ("toml", "soundfile"):
             sys.modules.pop(m, None)
+
+
+def test_reference_plugin_loader_builds_hip_fullsubnet_and_loads_reference_checkpoint(tmp_path):
+    """config/inference_fullsubnet_hip.toml = the reference TOML with its own commented
+    alternatives switched on (inference.toml:11,28) and [model].path pointing here."""
+    RefModel = ref_loader.load_reference_fullsubnet()
+    from audio_zen.utils import initialize_module
+    cfg = tomli.load(open(os.path.join(ROOT, "config", "inference_fullsubnet_hip.toml"), "rb"))
+    assert cfg["model"]["args"] == ref_loader.FULLSUBNET_MODEL_ARGS
+    assert cfg["inferencer"]["type"] == "full_band_crm_mask"
+    model = initialize_module(cfg["model"]["path"], args=cfg["model"]["args"])
+    from fullsubnet_plus_amd import FullSubNet
+    assert isinstance(model, FullSubNet)
+    torch.manual_seed(0)
+    ref = RefModel(**cfg["model"]["args"])
+    ckpt = tmp_path / "rand_ckpt.tar"
+    torch.save({"model": ref.state_dict(), "epoch": 0}, ckpt)
+    model.load_state_dict(torch.load(ckpt, map_location="cpu")["model"])     # strict (base_inferencer.py:107)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v)
