@@ -26,8 +26,9 @@ def parity_output_row(sample, global_batch):
     return sample // 2 if sample % 2 == 0 else n0 + (sample - 1) // 2
 
 
-def forward_sharded(model, noisy_mag, noisy_real, noisy_imag, gather=True, group=None):
-    """Every rank passes the FULL-batch tensors' own shard (already on its device) or the full batch; here each
+def forward_sharded(model, noisy_mag, noisy_real=None, noisy_imag=None, gather=True, group=None):
+    """noisy_real / noisy_imag = None: the original FullSubNet (`model(noisy_mag)`, fullsubnet.py:68).
+    Every rank passes the FULL-batch tensors' own shard (already on its device) or the full batch; here each
     rank receives the global batch on its device and computes only its shard.
 
     Returns the global mask tensor on every rank if `gather`, else this rank's rows:
@@ -41,7 +42,8 @@ def forward_sharded(model, noisy_mag, noisy_real, noisy_imag, gather=True, group
     parity = B > 1 and model.batch_mode == "parity"
     sl = slice(lo, hi)
     if hi > lo:
-        out = model(noisy_mag[sl], noisy_real[sl], noisy_imag[sl], batch_offset=lo, global_batch=B)
+        ins = [noisy_mag[sl]] if noisy_real is None else [noisy_mag[sl], noisy_real[sl], noisy_imag[sl]]
+        out = model(*ins, batch_offset=lo, global_batch=B)
     else:
         F = model.num_freqs // 2 if parity else model.num_freqs
         out = torch.zeros((B if parity else 0, 2, F, noisy_mag.shape[-1]), dtype=torch.float32, device=noisy_mag.device)

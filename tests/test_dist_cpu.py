@@ -51,6 +51,53 @@ class _OracleShardModel:
         return out
 
 
+class _OracleShardFullSubNet(_OracleShardModel):
+    """Same for the original FullSubNet: model(noisy_mag, batch_offset, global_batch)."""
+
+    def __call__(self, mag, batch_offset=0, global_batch=None):
+        gb = mag.shape[0] if global_batch is None else global_batch
+        full = fsnp_torch.forward_fullsubnet_full(self.sd, mag)
+        if not (gb > 1 and self.batch_mode == "parity"):
+            return full
+        out = torch.zeros((gb, 2, 128, mag.shape[-1]))
+        for i in range(mag.shape[0]):
+            s = batch_offset + i
+            out[fdist.parity_output_row(s, gb)] = full[i][:, (s % 2):256:2, :]
+        return out
+
+
+def _worker_fsn(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle.weights import make_state_dict_fullsubnet
+    model = _OracleShardFullSubNet(make_state_dict_fullsubnet(3), "parity")
+    out = fdist.forward_sharded(model, make_spec(5, 12, 43)[0], gather=True)
+    if rank == 0:
+        q.put(out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forward_sharded_fullsubnet_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fsn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle.weights import make_state_dict_fullsubnet
+    want = fsnp_torch.forward_fullsubnet(make_state_dict_fullsubnet(3), make_spec(5, 12, 43)[0]).numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+
+
 def _worker(rank, world, port, mode, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
