@@ -13,7 +13,7 @@ class FsnpConfig(ctypes.Structure):
         ("num_freqs", c_i32), ("look_ahead", c_i32), ("sb_num_neighbors", c_i32), ("fb_num_neighbors", c_i32),
         ("tcn_hidden", c_i32), ("num_tcn_blocks", c_i32), ("sb_hidden", c_i32), ("output_size", c_i32),
         ("norm_type", c_i32), ("fb_act", c_i32), ("sb_act", c_i32), ("kersize", c_i32 * 3),
-        ("num_groups_in_drop_band", c_i32), ("attention", c_i32), ("model", c_i32),
+        ("num_groups_in_drop_band", c_i32), ("attention", c_i32), ("model", c_i32), ("sequence_model", c_i32),
     ]
 
 
@@ -21,6 +21,7 @@ NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_
               "cumulative_layer_norm": 3}
 ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
 ATTENTION = {"TSSE": 0, "SE": 1, "ECA": 2, "CBAM": 3}
+SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1}
 MODE_FULL, MODE_PARITY = 0, 1
 MODEL_FULLSUBNET_PLUS, MODEL_FULLSUBNET = 0, 1
 

@@ -59,6 +59,8 @@ struct fsnp_handle {
     // original FullSubNet only: full-band 2-layer LSTM(F -> CH) (cooperative kernel) + Linear(CH, F) (GEMM)
     int model = FSNP_MODEL_FULLSUBNET_PLUS;
     int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
+    int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
+    int NG = 4;                  // gate blocks per weight matrix: 4 (LSTM) or 3 (GRU)
     LstmWeights fbw{};
     const float* fsn_wf = nullptr;   // [F pad 384][CH pad 16]
     const float* fsn_bf = nullptr;   // [F pad 384]
@@ -100,14 +102,15 @@ static void build_specs(fsnp_handle* h) {
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
     if (fsn) {   // fullsubnet.py:39-47: SequenceModel(257 -> 512 x 2 -> 257), same key layout as nn.LSTM
         const std::string f = "fb_model.sequence_model.";
-        add(f + "weight_ih_l0", (int64_t)4 * CH * F);
-        add(f + "weight_hh_l0", (int64_t)4 * CH * CH);
-        add(f + "bias_ih_l0", 4 * CH);
-        add(f + "bias_hh_l0", 4 * CH);
-        add(f + "weight_ih_l1", (int64_t)4 * CH * CH);
-        add(f + "weight_hh_l1", (int64_t)4 * CH * CH);
-        add(f + "bias_ih_l1", 4 * CH);
-        add(f + "bias_hh_l1", 4 * CH);
+        const int64_t G = h->NG;
+        add(f + "weight_ih_l0", G * CH * F);
+        add(f + "weight_hh_l0", G * CH * CH);
+        add(f + "bias_ih_l0", G * CH);
+        add(f + "bias_hh_l0", G * CH);
+        add(f + "weight_ih_l1", G * CH * CH);
+        add(f + "weight_hh_l1", G * CH * CH);
+        add(f + "bias_ih_l1", G * CH);
+        add(f + "bias_hh_l1", G * CH);
         add("fb_model.fc_output_layer.weight", (int64_t)F * CH);
         add("fb_model.fc_output_layer.bias", F);
     }
@@ -150,14 +153,15 @@ static void build_specs(fsnp_handle* h) {
         add(std::string(kFb[b]) + ".fc_output_layer.bias", F);
     }
     const std::string s = "sb_model.sequence_model.";
-    add(s + "weight_ih_l0", (int64_t)4 * H * h->NIN);
-    add(s + "weight_hh_l0", (int64_t)4 * H * H);
-    add(s + "bias_ih_l0", 4 * H);
-    add(s + "bias_hh_l0", 4 * H);
-    add(s + "weight_ih_l1", (int64_t)4 * H * H);
-    add(s + "weight_hh_l1", (int64_t)4 * H * H);
-    add(s + "bias_ih_l1", 4 * H);
-    add(s + "bias_hh_l1", 4 * H);
+    const int64_t G = h->NG;
+    add(s + "weight_ih_l0", G * H * h->NIN);
+    add(s + "weight_hh_l0", G * H * H);
+    add(s + "bias_ih_l0", G * H);
+    add(s + "bias_hh_l0", G * H);
+    add(s + "weight_ih_l1", G * H * H);
+    add(s + "weight_hh_l1", G * H * H);
+    add(s + "bias_ih_l1", G * H);
+    add(s + "bias_hh_l1", G * H);
     add("sb_model.fc_output_layer.weight", (int64_t)h->cfg.output_size * H);
     add("sb_model.fc_output_layer.bias", h->cfg.output_size);
 }
@@ -203,6 +207,11 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
 struct SbKernel { int kind; int units; int groups; int rpg; };   // kind 0 = row tile, 1 = coop (K split), 2 = coopn
 static SbKernel sb_kernel(const fsnp_handle* h, const LstmPlan& lp) {
     SbKernel k{0, 0, 0, 0};
+    if (h->gru) {       // no row-tile GRU kernel: <= 42 tiles K split, otherwise chunks of <= 170 tiles on lstm_coopn.hip
+        k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
+        k.kind = k.units != 0 ? 1 : 2;
+        return k;
+    }
     if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return k;   // the cooperative kernels are fp32 only
     k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
     if (k.units != 0) { k.kind = 1; return k; }
@@ -216,8 +225,27 @@ static void launch_sb_lstm(const fsnp_handle* h, const LstmPlan& lp, LstmArgs& a
     if (k.kind == 0) { launch_lstm(h->lw, a, s); return; }
     a.coop_hx = hx; a.coop_bar = bar; a.coop_err = h->d_err;
     a.coop_units = k.units; a.coop_groups = k.groups; a.coop_rows_per_group = k.rpg;
-    if (k.kind == 1) launch_lstm_coop(h->lw, a, s);
-    else launch_lstm_coopn(h->lw, a, s);
+    if (k.kind == 1) { launch_lstm_coop(h->lw, a, s); return; }
+    if (k.rpg != 0) { launch_lstm_coopn(h->lw, a, s); return; }
+    // GRU with more row tiles than one co-resident launch takes: consecutive chunks, each with its own slice of the
+    // row descriptors, exchange images, barrier counters and per-row norm tables
+    const int S = h->H / 128, gmax = h->num_cus_real / S, chunk = 2 * gmax;
+    const size_t hx_floats_per_tile = lstm_coop_exchange_bytes(h->H, 1) / 4;
+    for (int t0 = 0; t0 < lp.num_tiles; t0 += chunk) {
+        LstmArgs c = a;
+        c.num_tiles = lp.num_tiles - t0 < chunk ? lp.num_tiles - t0 : chunk;
+        c.rows = a.rows + (size_t)t0 * 32;
+        c.coop_hx = hx + (size_t)t0 * hx_floats_per_tile;
+        c.coop_bar = bar + t0;
+        if (a.md_row) c.md_row = a.md_row + (size_t)t0 * 32 * a.Tp;
+        c.coop_rows_per_group = lstm_coopn_plan(h->H, c.num_tiles, h->num_cus_real, &c.coop_groups);
+        launch_lstm_coopn(h->lw, c, s);
+    }
+}
+// Tile plan of the sub-band problem: GRU has no VALU-row variant, always plain 32-row tiles
+static LstmPlan sb_plan(const fsnp_handle* h, int num_rows) {
+    if (h->gru) return LstmPlan{cdiv(num_rows, 32), 0, 32};
+    return plan_lstm_tiles(num_rows, h->num_cus);
 }
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
 static int fb_row_tiles(int B) { return cdiv(B, 32); }
@@ -246,7 +274,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gate = take(fsn ? 0 : (size_t)3 * B * h->FP * 4);
     w.md = take(nbr * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
-    const LstmPlan lp = plan_lstm_tiles(B * rows_per_utt(h, mode), h->num_cus);
+    const LstmPlan lp = sb_plan(h, B * rows_per_utt(h, mode));
     const size_t nrows_pad = (size_t)lp.num_tiles * lp.rows_per_slot_tile;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
@@ -277,8 +305,8 @@ static int ensure_workspace(fsnp_handle* h, size_t bytes) {
 }
 
 static double lstm_flops_per_step(const fsnp_handle* h) {
-    const double H = h->H, NIN = h->NIN, OUT = h->cfg.output_size;
-    return 2.0 * 4 * H * (NIN + H) + 2.0 * 4 * H * (2 * H) + 2.0 * H * OUT;
+    const double H = h->H, NIN = h->NIN, OUT = h->cfg.output_size, G = h->NG;
+    return 2.0 * G * H * (NIN + H) + 2.0 * G * H * (2 * H) + 2.0 * H * OUT;
 }
 static double tcn_flops_per_frame(const fsnp_handle* h) {
     const double F = h->F, CH = h->CH;
@@ -286,7 +314,7 @@ static double tcn_flops_per_frame(const fsnp_handle* h) {
 }
 static double fb_lstm_flops_per_frame(const fsnp_handle* h) {   // original FullSubNet: LSTM(F, CH) x 2 + Linear(CH, F)
     const double F = h->F, CH = h->CH;
-    return 2.0 * 4 * CH * (F + CH) + 2.0 * 4 * CH * (2 * CH) + 2.0 * CH * F;
+    return 2.0 * h->NG * CH * (F + CH) + 2.0 * h->NG * CH * (2 * CH) + 2.0 * CH * F;
 }
 
 }  // namespace fsnp
@@ -307,6 +335,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
     if (cfg->attention < 0 || cfg->attention > 3) { set_error("unknown attention model %d", cfg->attention); return 2; }
     if (cfg->model != FSNP_MODEL_FULLSUBNET_PLUS && cfg->model != FSNP_MODEL_FULLSUBNET) { set_error("unknown model %d", cfg->model); return 2; }
+    if (cfg->sequence_model != FSNP_SEQ_LSTM && cfg->sequence_model != FSNP_SEQ_GRU) { set_error("unknown sequence_model %d", cfg->sequence_model); return 2; }
     const bool fsn = cfg->model == FSNP_MODEL_FULLSUBNET;
     if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
     if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
@@ -334,6 +363,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->num_cus_real = h->num_cus;
     h->model = cfg->model;
+    h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
+    h->NG = h->gru ? 3 : 4;
     h->NFB = fsn ? 1 : 3;
     h->F = cfg->num_freqs;
     h->FP = (int)align_up(cfg->num_freqs, 4);
@@ -478,49 +509,78 @@ int fsnp_commit_weights(fsnp_handle* h) {
         const auto& bf = W(std::string(kFb[b]) + ".fc_output_layer.bias");
         std::copy(bf.begin(), bf.end(), blob.begin() + o_bf + (size_t)b * N2P);
     }
-    // ---- LSTM: MFMA B-fragment order + summed biases
-    const std::string s = "sb_model.sequence_model.";
-    const size_t o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
-    lstm_pack_weights(H, h->NIN, h->KX, 4, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                      W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack);
-    const size_t o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
-    lstm_pack_weights(H, h->NIN, h->KX, 12, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                      W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack12);
-    size_t o_wpack_bf[2];
-    for (int i = 0; i < 2; ++i) {
-        const int nw = i == 0 ? 4 : 12;
-        o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
-        lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                                 W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_bf[i]);
+    // ---- recurrent models: MFMA B-fragment order + summed biases.  Every kernel sees FOUR column slots per hidden unit:
+    // LSTM i, f, g, o (the reference's gate order); GRU r, z, n_x, n_h with W_in only in the input rows of K and W_hn only
+    // in the hidden rows (zero blocks elsewhere), biases b_ir + b_hr, b_iz + b_hz, b_in, b_hn.
+    struct Rnn4 { std::vector<float> wih0, whh0, wih1, whh1, bias; };
+    auto expand = [&](const std::string& pre, int Hh, int nin) {
+        Rnn4 r;
+        const auto &a0 = W(pre + "weight_ih_l0"), &a1 = W(pre + "weight_hh_l0"), &a2 = W(pre + "weight_ih_l1"), &a3 = W(pre + "weight_hh_l1");
+        r.bias.assign((size_t)2 * 4 * Hh, 0.0f);
+        if (!h->gru) {
+            r.wih0 = a0; r.whh0 = a1; r.wih1 = a2; r.whh1 = a3;
+            for (int l = 0; l < 2; ++l) {
+                const auto& bi = W(pre + "bias_ih_l" + std::to_string(l));
+                const auto& bh = W(pre + "bias_hh_l" + std::to_string(l));
+                for (int i = 0; i < 4 * Hh; ++i) r.bias[(size_t)l * 4 * Hh + i] = bi[i] + bh[i];
+            }
+            return r;
+        }
+        auto spread = [&](const std::vector<float>& src, int cols, bool hidden) {   // [3H][cols] -> [4H][cols]
+            std::vector<float> dst((size_t)4 * Hh * cols, 0.0f);
+            std::copy(src.begin(), src.begin() + (size_t)2 * Hh * cols, dst.begin());                        // r, z
+            std::copy(src.begin() + (size_t)2 * Hh * cols, src.end(), dst.begin() + (size_t)(hidden ? 3 : 2) * Hh * cols);   // n
+            return dst;
+        };
+        r.wih0 = spread(a0, nin, false); r.whh0 = spread(a1, Hh, true);
+        r.wih1 = spread(a2, Hh, false); r.whh1 = spread(a3, Hh, true);
+        for (int l = 0; l < 2; ++l) {
+            const auto& bi = W(pre + "bias_ih_l" + std::to_string(l));
+            const auto& bh = W(pre + "bias_hh_l" + std::to_string(l));
+            float* b = r.bias.data() + (size_t)l * 4 * Hh;
+            for (int i = 0; i < 2 * Hh; ++i) b[i] = bi[i] + bh[i];
+            for (int i = 0; i < Hh; ++i) { b[2 * Hh + i] = bi[2 * Hh + i]; b[3 * Hh + i] = bh[2 * Hh + i]; }
+        }
+        return r;
+    };
+    const Rnn4 sbw = expand("sb_model.sequence_model.", H, h->NIN);
+    size_t o_wpack = 0, o_wpack12 = 0, o_wpack_bf[2] = {0, 0};
+    if (!h->gru) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
+        o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
+        lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
+        o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
+        lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
+        for (int i = 0; i < 2; ++i) {
+            const int nw = i == 0 ? 4 : 12;
+            o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
+            lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
+                                     blob.data() + o_wpack_bf[i]);
+        }
     }
     size_t o_wpack_coop[4] = {0, 0, 0, 0};
     for (int ui = 0; ui < 4; ++ui) {
         const int units = 8 << ui;
         o_wpack_coop[ui] = alloc(lstm_coop_pack_floats(H, h->KX, units));
-        lstm_coop_pack_weights(H, h->NIN, h->KX, units, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                               W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coop[ui]);
+        lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
+                               blob.data() + o_wpack_coop[ui]);
     }
     const size_t o_wpack_coopn = alloc(lstm_coopn_pack_floats(H, h->KX));
-    lstm_coopn_pack_weights(H, h->NIN, h->KX, W(s + "weight_ih_l0").data(), W(s + "weight_hh_l0").data(),
-                            W(s + "weight_ih_l1").data(), W(s + "weight_hh_l1").data(), blob.data() + o_wpack_coopn);
-    // ---- original FullSubNet: full-band LSTM (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
+    lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
+                            blob.data() + o_wpack_coopn);
+    // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
     size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
     const int fsn_kp = (int)align_up(CH, 16), fsn_np = (int)align_up(F, 384);
     if (fsn) {
-        const std::string f = "fb_model.sequence_model.";
+        const Rnn4 fbw = expand("fb_model.sequence_model.", CH, F);
         for (int ui = 0; ui < 3; ++ui) {
             const int units = 8 << ui;
             o_fbpack[ui] = alloc(lstm_coop_pack_floats(CH, KXF, units));
-            lstm_coop_pack_weights(CH, F, KXF, units, W(f + "weight_ih_l0").data(), W(f + "weight_hh_l0").data(),
-                                   W(f + "weight_ih_l1").data(), W(f + "weight_hh_l1").data(), blob.data() + o_fbpack[ui]);
+            lstm_coop_pack_weights(CH, F, KXF, units, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(),
+                                   blob.data() + o_fbpack[ui]);
         }
-        o_fbbias = alloc((size_t)2 * 4 * CH);
-        for (int l = 0; l < 2; ++l) {
-            const auto& bi = W(f + "bias_ih_l" + std::to_string(l));
-            const auto& bh = W(f + "bias_hh_l" + std::to_string(l));
-            for (int i = 0; i < 4 * CH; ++i) blob[o_fbbias + (size_t)l * 4 * CH + i] = bi[i] + bh[i];
-        }
+        o_fbbias = alloc(fbw.bias.size());
+        std::copy(fbw.bias.begin(), fbw.bias.end(), blob.begin() + o_fbbias);
         o_fsn_wf = alloc((size_t)fsn_np * fsn_kp);
         const auto& wf = W("fb_model.fc_output_layer.weight");          // [F][CH]
         for (int n = 0; n < F; ++n)
@@ -529,12 +589,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
         const auto& bf = W("fb_model.fc_output_layer.bias");
         std::copy(bf.begin(), bf.end(), blob.begin() + o_fsn_bf);
     }
-    const size_t o_lbias = alloc((size_t)2 * 4 * H);
-    for (int l = 0; l < 2; ++l) {
-        const auto& bi = W(s + "bias_ih_l" + std::to_string(l));
-        const auto& bh = W(s + "bias_hh_l" + std::to_string(l));
-        for (int i = 0; i < 4 * H; ++i) blob[o_lbias + (size_t)l * 4 * H + i] = bi[i] + bh[i];
-    }
+    const size_t o_lbias = alloc(sbw.bias.size());
+    std::copy(sbw.bias.begin(), sbw.bias.end(), blob.begin() + o_lbias);
     const size_t o_wfc = put("sb_model.fc_output_layer.weight");
     const size_t o_bfc = put("sb_model.fc_output_layer.bias");
     // ---- unfold multiplicities w_r, by brute force over (f, j)
@@ -563,12 +619,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
-    h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size;
+    h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
     if (fsn) {
         h->fbw = LstmWeights{};
         for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
         h->fbw.bias = d + o_fbbias;
-        h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0;
+        h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0; h->fbw.gru = h->gru;
         h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
     }
     h->d_refl_w = d + o_refl;
@@ -618,7 +674,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     FSNP_HIP_CHECK(hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, s));
 
     const int num_rows = batch * rows_per_utt(h, mode);
-    const LstmPlan lp = plan_lstm_tiles(num_rows, h->num_cus);
+    const LstmPlan lp = sb_plan(h, num_rows);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_rows, lp.num_tiles,
@@ -717,7 +773,7 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
-    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
+    const LstmPlan lp = sb_plan(h, num_seq);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const bool coop = use_coop(h, lp);
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
@@ -794,8 +850,9 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_lstm_profile: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
+    if (h->gru) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
     FSNP_HIP_CHECK(hipSetDevice(h->device));
-    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
+    const LstmPlan lp = sb_plan(h, num_seq);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
     if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8)) return 4;
@@ -816,6 +873,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || (ih_bf16 != 0 && ih_bf16 != 1)) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM)"); return 1; }
+    if (ih_bf16 && h->gru) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
     h->ih_bf16 = ih_bf16;
     h->lw.ih_bf16 = ih_bf16;
     return 0;

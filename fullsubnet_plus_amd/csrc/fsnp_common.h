@@ -123,6 +123,7 @@ struct LstmWeights {
     int ih_bf16;                // 1 = use them
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
+    int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
     const float* wfc;    // [OUT][H]

@@ -77,7 +77,11 @@ constexpr int coop_units_index(int units) { return units == 8 ? 0 : units == 16 
 
 }  // namespace
 
-template <int HID, int KX, int UNITS, bool SEQ>
+// GRU = true: nn.GRU instead of nn.LSTM (sequence_model.py:39-46).  The four column slots of a hidden unit are then
+// (r, z, n_x, n_h) - the host packs W_in only into the input part of K and W_hn only into the hidden part (zero blocks
+// elsewhere), so the MFMA loops are unchanged - and the per-unit state kept in registers is h itself:
+//   r = s(a_r), z = s(a_z), n = tanh(a_nx + r * a_nh), h' = (1 - z) n + z h          (torch.nn.GRU)
+template <int HID, int KX, int UNITS, bool SEQ, bool GRU>
 __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs a) {
     constexpr int NT = UNITS / 8;                  // 32-column accumulator tiles per workgroup
     constexpr int NP = UNITS / 8;                  // (row, unit) pairs per thread in the cell update
@@ -287,13 +291,23 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                 float bi, bf, bg, bo;
                 if constexpr (BIAS_REGS) { bi = bias0[i][0]; bf = bias0[i][1]; bg = bias0[i][2]; bo = bias0[i][3]; }
                 else { bi = w.bias[pk[i]]; bf = w.bias[HID + pk[i]]; bg = w.bias[2 * HID + pk[i]]; bo = w.bias[3 * HID + pk[i]]; }
-                const float ig = fast_sigmoid(red_sum(pred[i][0]) + bi);
-                const float fg = fast_sigmoid(red_sum(pred[i][1]) + bf);
-                const float gg = fast_tanh(red_sum(pred[i][2]) + bg);
-                const float og = fast_sigmoid(red_sum(pred[i][3]) + bo);
-                const float cn = fg * c0[i] + ig * gg;
-                c0[i] = cn;
-                img[a_frag_index(prow[i], pk[i])] = og * fast_tanh(cn);
+                float hval;
+                if constexpr (GRU) {
+                    const float rg = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                    const float zg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                    const float ng = fast_tanh(red_sum(pred[i][2]) + bg + rg * (red_sum(pred[i][3]) + bo));
+                    hval = ng + zg * (c0[i] - ng);
+                    c0[i] = hval;
+                } else {
+                    const float ig = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                    const float fg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                    const float gg = fast_tanh(red_sum(pred[i][2]) + bg);
+                    const float og = fast_sigmoid(red_sum(pred[i][3]) + bo);
+                    const float cn = fg * c0[i] + ig * gg;
+                    c0[i] = cn;
+                    hval = og * fast_tanh(cn);
+                }
+                img[a_frag_index(prow[i], pk[i])] = hval;
             }
         }
         if (have_next) {
@@ -322,13 +336,22 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     bi = w.bias[4 * HID + pk[i]]; bf = w.bias[5 * HID + pk[i]];
                     bg = w.bias[6 * HID + pk[i]]; bo = w.bias[7 * HID + pk[i]];
                 }
-                const float ig = fast_sigmoid(red_sum(pred[i][0]) + bi);
-                const float fg = fast_sigmoid(red_sum(pred[i][1]) + bf);
-                const float gg = fast_tanh(red_sum(pred[i][2]) + bg);
-                const float og = fast_sigmoid(red_sum(pred[i][3]) + bo);
-                const float cn = fg * c1[i] + ig * gg;
-                c1[i] = cn;
-                const float h = og * fast_tanh(cn);
+                float h;
+                if constexpr (GRU) {
+                    const float rg = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                    const float zg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                    const float ng = fast_tanh(red_sum(pred[i][2]) + bg + rg * (red_sum(pred[i][3]) + bo));
+                    h = ng + zg * (c1[i] - ng);
+                    c1[i] = h;
+                } else {
+                    const float ig = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                    const float fg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                    const float gg = fast_tanh(red_sum(pred[i][2]) + bg);
+                    const float og = fast_sigmoid(red_sum(pred[i][3]) + bo);
+                    const float cn = fg * c1[i] + ig * gg;
+                    c1[i] = cn;
+                    h = og * fast_tanh(cn);
+                }
                 img[a_frag_index(prow[i], pk[i])] = h;
                 if constexpr (SEQ) {
                     const RowDesc rd = rows_s[prow[i]];
@@ -405,11 +428,11 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles) {
     return (size_t)row_tiles * (4 * (size_t)(H / 8) * 64 + 2 * (size_t)(H / 8) * 16) * 16;
 }
 
-template <int HID, int KX, int UNITS, bool SEQ>
+template <int HID, int KX, int UNITS, bool SEQ, bool GRU>
 static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int S = HID / UNITS, NT = UNITS / 8;
     const size_t smem = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
-    auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ>;
+    auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ, GRU>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -428,23 +451,29 @@ int lstm_coop_pick_units(int H, int row_tiles, int num_cus, int min_units) {
     return 0;
 }
 
-// sub-band model: H = 384, x gathered (or dense [seq][t][NIN]), fused Linear(384, 2)
-void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+template <int HID, int KX, bool SEQ, bool GRU>
+static void launch_coop_units(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     switch (a.coop_units) {
-        case 8: launch_coop_inst<384, 40, 8, false>(w, a, s); break;
-        case 16: launch_coop_inst<384, 40, 16, false>(w, a, s); break;
-        case 32: launch_coop_inst<384, 40, 32, false>(w, a, s); break;
-        default: launch_coop_inst<384, 40, 64, false>(w, a, s); break;
+        case 8: launch_coop_inst<HID, KX, 8, SEQ, GRU>(w, a, s); break;
+        case 16: launch_coop_inst<HID, KX, 16, SEQ, GRU>(w, a, s); break;
+        case 32: launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s); break;
+        default:
+            if constexpr (!SEQ) launch_coop_inst<HID, KX, 64, SEQ, GRU>(w, a, s);
+            else launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s);
+            break;
     }
+}
+
+// sub-band model: H = 384, x gathered (or dense [seq][t][NIN]), fused Linear(384, 2); w.gru selects nn.GRU
+void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (w.gru) launch_coop_units<384, 40, false, true>(w, a, s);
+    else launch_coop_units<384, 40, false, false>(w, a, s);
 }
 
 // full-band model of the original FullSubNet: H = 512, dense input rows of <= 264 features, h1 sequence out
 void launch_lstm_coop_seq(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    switch (a.coop_units) {
-        case 8: launch_coop_inst<512, 264, 8, true>(w, a, s); break;
-        case 16: launch_coop_inst<512, 264, 16, true>(w, a, s); break;
-        default: launch_coop_inst<512, 264, 32, true>(w, a, s); break;
-    }
+    if (w.gru) launch_coop_units<512, 264, true, true>(w, a, s);
+    else launch_coop_units<512, 264, true, false>(w, a, s);
 }
 
 }  // namespace fsnp

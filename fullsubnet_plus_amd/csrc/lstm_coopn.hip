@@ -89,7 +89,9 @@ __device__ __forceinline__ void coopn_loop(f32x16 (&acc)[4], const NStream& ws, 
 
 }  // namespace
 
-template <int HID, int KX, int R>
+// GRU = true: nn.GRU (see lstm_coop.hip): column slots (r, z, n_x, n_h), zero weight blocks packed by the host, the
+// register state is h itself.
+template <int HID, int KX, int R, bool GRU>
 __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArgs a) {
     constexpr int UNITS = 128;                     // hidden units per workgroup, 32 per wave
     constexpr int S = HID / UNITS;
@@ -259,13 +261,23 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             float* img = reinterpret_cast<float*>(a.coop_hx + ((size_t)rt[r] * HXT + (size_t)cur * HIMG) * 4);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float ig = fast_sigmoid(acc[0][q] + b0[0]);
-                const float fg = fast_sigmoid(acc[1][q] + b0[1]);
-                const float gg = fast_tanh(acc[2][q] + b0[2]);
-                const float og = fast_sigmoid(acc[3][q] + b0[3]);
-                const float cn = fg * c0[r][q] + ig * gg;
-                c0[r][q] = cn;
-                img[a_frag_index((q & 3) + 8 * (q >> 2) + rowbase, unit)] = og * fast_tanh(cn);
+                float hval;
+                if constexpr (GRU) {
+                    const float rg = fast_sigmoid(acc[0][q] + b0[0]);
+                    const float zg = fast_sigmoid(acc[1][q] + b0[1]);
+                    const float ng = fast_tanh(acc[2][q] + b0[2] + rg * (acc[3][q] + b0[3]));
+                    hval = ng + zg * (c0[r][q] - ng);
+                    c0[r][q] = hval;
+                } else {
+                    const float ig = fast_sigmoid(acc[0][q] + b0[0]);
+                    const float fg = fast_sigmoid(acc[1][q] + b0[1]);
+                    const float gg = fast_tanh(acc[2][q] + b0[2]);
+                    const float og = fast_sigmoid(acc[3][q] + b0[3]);
+                    const float cn = fg * c0[r][q] + ig * gg;
+                    c0[r][q] = cn;
+                    hval = og * fast_tanh(cn);
+                }
+                img[a_frag_index((q & 3) + 8 * (q >> 2) + rowbase, unit)] = hval;
             }
             if (have_next) {      // the other parity: last read in step t-1, before that step's barrier
                 float* Xf = reinterpret_cast<float*>(Xs[prv][r]);
@@ -291,13 +303,22 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             float* part = a.coop_hx + ((size_t)rt[r] * HXT + 4 * HIMG) * 4 + ((size_t)cur * (4 * S) + ub) * 64;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float ig = fast_sigmoid(acc[0][q] + b1[0]);
-                const float fg = fast_sigmoid(acc[1][q] + b1[1]);
-                const float gg = fast_tanh(acc[2][q] + b1[2]);
-                const float og = fast_sigmoid(acc[3][q] + b1[3]);
-                const float cn = fg * c1[r][q] + ig * gg;
-                c1[r][q] = cn;
-                const float hval = og * fast_tanh(cn);
+                float hval;
+                if constexpr (GRU) {
+                    const float rg = fast_sigmoid(acc[0][q] + b1[0]);
+                    const float zg = fast_sigmoid(acc[1][q] + b1[1]);
+                    const float ng = fast_tanh(acc[2][q] + b1[2] + rg * (acc[3][q] + b1[3]));
+                    hval = ng + zg * (c1[r][q] - ng);
+                    c1[r][q] = hval;
+                } else {
+                    const float ig = fast_sigmoid(acc[0][q] + b1[0]);
+                    const float fg = fast_sigmoid(acc[1][q] + b1[1]);
+                    const float gg = fast_tanh(acc[2][q] + b1[2]);
+                    const float og = fast_sigmoid(acc[3][q] + b1[3]);
+                    const float cn = fg * c1[r][q] + ig * gg;
+                    c1[r][q] = cn;
+                    hval = og * fast_tanh(cn);
+                }
                 const int row = (q & 3) + 8 * (q >> 2) + rowbase;
                 img[a_frag_index(row, unit)] = hval;
                 float p0 = hval * wfc0, p1 = hval * wfc1;        // partial Linear over this wave's 32 units
@@ -352,17 +373,22 @@ int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups) {
     return R;
 }
 
-template <int R>
+template <int R, bool GRU>
 static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coopn;
-    hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R>), dim3(a.coop_groups * (HID / 128)), dim3(256), 0, s, wv, a);
+    hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(a.coop_groups * (HID / 128)), dim3(256), 0, s, wv, a);
 }
 
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    if (a.coop_rows_per_group == 1) launch_coopn_inst<1>(w, a, s);
-    else launch_coopn_inst<2>(w, a, s);
+    if (w.gru) {
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true>(w, a, s);
+        else launch_coopn_inst<2, true>(w, a, s);
+    } else {
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false>(w, a, s);
+        else launch_coopn_inst<2, false>(w, a, s);
+    }
 }
 
 }  // namespace fsnp

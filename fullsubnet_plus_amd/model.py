@@ -80,9 +80,10 @@ class _FullBandParams(nn.Module):
 class _SubBandParams(nn.Module):
     """Parameter holder named like SequenceModel(sequence_model="LSTM") (sequence_model.py:31-38,78-79)."""
 
-    def __init__(self, input_size, hidden, output_size):
+    def __init__(self, input_size, hidden, output_size, kind="LSTM"):
         super().__init__()
-        self.sequence_model = nn.LSTM(input_size, hidden, num_layers=2, batch_first=True)
+        rnn = nn.LSTM if kind == "LSTM" else nn.GRU                      # sequence_model.py:31-46
+        self.sequence_model = rnn(input_size, hidden, num_layers=2, batch_first=True)
         self.fc_output_layer = nn.Linear(hidden, output_size)
 
 
@@ -128,7 +129,7 @@ def _reference_style_init(m):
     elif isinstance(m, nn.Linear):
         nn.init.xavier_normal_(m.weight)
         nn.init.normal_(m.bias)
-    elif isinstance(m, nn.LSTM):
+    elif isinstance(m, (nn.LSTM, nn.GRU)):
         for p in m.parameters():
             (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p)
 
@@ -359,8 +360,8 @@ class FullSubNet_Plus(_HipModel):
                  ):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
-        if sequence_model != "LSTM":
-            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM only)")
+        if sequence_model not in _lib.SEQUENCE_MODELS:
+            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM, GRU)")
         if channel_attention_model not in _lib.ATTENTION:
             raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
         if subband_num != 1:
@@ -391,7 +392,8 @@ class FullSubNet_Plus(_HipModel):
         self.fb_model_real = _FullBandParams(num_freqs, 512)
         self.fb_model_imag = _FullBandParams(num_freqs, 512)
         self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1),
-                                       sb_model_hidden_size, output_size)
+                                       sb_model_hidden_size, output_size, sequence_model)
+        self.sequence_model = sequence_model
 
         self.subband_num = subband_num
         self.sb_num_neighbors = sb_num_neighbors
@@ -427,6 +429,7 @@ class FullSubNet_Plus(_HipModel):
             cfg.kersize[i] = int(k)
         cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
         cfg.attention = _lib.ATTENTION[self.channel_attention_model]
+        cfg.sequence_model = _lib.SEQUENCE_MODELS[self.sequence_model]
         return cfg
 
     # ------------------------------------------------------------------ forward
@@ -445,9 +448,10 @@ class _FullBandLSTMParams(nn.Module):
     """Parameter holder named like SequenceModel(sequence_model="LSTM") of the original FullSubNet's full-band model
     (fullsubnet/model/fullsubnet.py:39-47; sequence_model.py:31-38,78-79)."""
 
-    def __init__(self, num_freqs, hidden):
+    def __init__(self, num_freqs, hidden, kind="LSTM"):
         super().__init__()
-        self.sequence_model = nn.LSTM(num_freqs, hidden, num_layers=2, batch_first=True)
+        rnn = nn.LSTM if kind == "LSTM" else nn.GRU
+        self.sequence_model = rnn(num_freqs, hidden, num_layers=2, batch_first=True)
         self.fc_output_layer = nn.Linear(hidden, num_freqs)
 
 
@@ -472,8 +476,6 @@ class FullSubNet(_HipModel):
                  ):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if sequence_model != "LSTM":
-            raise NotImplementedError(f"HIP path: sequence_model {sequence_model} is not built yet (LSTM only)")
         if fb_num_neighbors != 0:
             raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
         if norm_type not in _lib.NORM_TYPES:
@@ -482,8 +484,10 @@ class FullSubNet(_HipModel):
         for act in (fb_output_activate_function, sb_output_activate_function):
             if act and act not in _lib.ACTIVATIONS:
                 raise NotImplementedError(f"Not implemented activation function {act}")
-        self.fb_model = _FullBandLSTMParams(num_freqs, fb_model_hidden_size)
-        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), sb_model_hidden_size, 2)
+        self.fb_model = _FullBandLSTMParams(num_freqs, fb_model_hidden_size, sequence_model)
+        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), sb_model_hidden_size, 2,
+                                       sequence_model)
+        self.sequence_model = sequence_model
 
         self.sb_num_neighbors = sb_num_neighbors
         self.fb_num_neighbors = fb_num_neighbors
@@ -518,6 +522,7 @@ class FullSubNet(_HipModel):
             cfg.kersize[i] = 1
         cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
         cfg.attention = 0
+        cfg.sequence_model = _lib.SEQUENCE_MODELS[self.sequence_model]
         return cfg
 
     def forward(self, noisy_mag, batch_offset=0, global_batch=None):

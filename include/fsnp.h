@@ -56,6 +56,11 @@ enum {
  * kersize / attention are ignored, and fsnp_forward takes real = imag = NULL. */
 enum { FSNP_MODEL_FULLSUBNET_PLUS = 0, FSNP_MODEL_FULLSUBNET = 1 };
 
+/* `sequence_model` kwarg of both reference models (SequenceModel, audio_zen/model/module/sequence_model.py:31-46):
+ * the recurrent cell of the sub-band model (and, for FSNP_MODEL_FULLSUBNET, of the full-band model).  GRU runs on the
+ * column-split kernels only (csrc/lstm_coop.hip, csrc/lstm_coopn.hip) and has no bf16 variant. */
+enum { FSNP_SEQ_LSTM = 0, FSNP_SEQ_GRU = 1 };
+
 /* B > 1 semantics */
 enum {
     FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,2,F,T]          */
@@ -80,6 +85,7 @@ typedef struct fsnp_config {
     int32_t num_groups_in_drop_band; /* 2 (only 2 is supported in PARITY mode) */
     int32_t attention;          /* FSNP_ATT_* : channel_attention_model */
     int32_t model;              /* FSNP_MODEL_* (0 = FullSubNet+) */
+    int32_t sequence_model;     /* FSNP_SEQ_* : sequence_model kwarg (0 = LSTM) */
 } fsnp_config;
 
 /* Replaces `FullSubNet_Plus(**model.args)` (base_inferencer.py:99).  Needs a visible

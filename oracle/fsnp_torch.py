@@ -143,16 +143,21 @@ def fb_sequence_model(x, p, prefix, activation="ReLU"):
 
 
 def lstm2_fc(x, p, prefix="sb_model", activation=False):
-    """sequence_model.py:113-123.  x [N,in,T] -> [N,out,T]."""
+    """sequence_model.py:113-123.  x [N,in,T] -> [N,out,T].  LSTM or GRU (sequence_model.py:31-46) is told apart by
+    the gate-block count of weight_hh_l0 ([4H,H] vs [3H,H])."""
     N = x.shape[0]
     H = p[f"{prefix}.sequence_model.weight_hh_l0"].shape[1]
+    gru = p[f"{prefix}.sequence_model.weight_hh_l0"].shape[0] == 3 * H
     flat = []
     for layer in (0, 1):
         for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
             flat.append(p[f"{prefix}.sequence_model.{nm}_l{layer}"])
     seq = x.permute(0, 2, 1).contiguous()
     h0 = torch.zeros(2, N, H, dtype=x.dtype)
-    o, _, _ = torch.lstm(seq, (h0, h0.clone()), flat, True, 2, 0.0, False, False, True)
+    if gru:
+        o, _ = torch.gru(seq, h0, flat, True, 2, 0.0, False, False, True)
+    else:
+        o, _, _ = torch.lstm(seq, (h0, h0.clone()), flat, True, 2, 0.0, False, False, True)
     o = Fn.linear(o, p[prefix + ".fc_output_layer.weight"], p[prefix + ".fc_output_layer.bias"])
     return _activation(o, activation).permute(0, 2, 1).contiguous()
 

@@ -64,6 +64,13 @@ CASES = [
          inp=("spec", 1, 20, 13), stages=False),
     dict(name="b3_t20_att_CBAM", wseed=14, profile="default", args={"channel_attention_model": "CBAM"},
          inp=("spec", 3, 20, 14), stages=False),
+    # sub-band GRU (sequence_model.py:39-46)
+    dict(name="gru_b1_t24_harsh_stages", wseed=15, profile="harsh", args={"sequence_model": "GRU"},
+         inp=("spec", 1, 24, 15), stages=True),
+    dict(name="gru_b3_t20_default", wseed=16, profile="default", args={"sequence_model": "GRU"},
+         inp=("spec", 3, 20, 16), stages=False),
+    dict(name="gru_b1_t30_cum_layer", wseed=17, profile="default",
+         args={"sequence_model": "GRU", "norm_type": "cumulative_layer_norm"}, inp=("spec", 1, 30, 17), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -82,6 +89,10 @@ FSN_CASES = [
     dict(name="fsn_b1_t20_gaussian", wseed=7, profile="default", args={"norm_type": "offline_gaussian_norm"},
          inp=("spec", 1, 20, 27), stages=True),
     dict(name="fsn_b1_2s_default", wseed=8, profile="default", args={}, inp=("stft", 1, 2.0, 28), stages=False),
+    dict(name="fsn_gru_b1_t24_harsh_stages", wseed=9, profile="harsh", args={"sequence_model": "GRU"},
+         inp=("spec", 1, 24, 29), stages=True),
+    dict(name="fsn_gru_b3_t20_default", wseed=10, profile="default", args={"sequence_model": "GRU"},
+         inp=("spec", 3, 20, 30), stages=False),
 ]
 
 SB_ROWS = [0, 1, 14, 15, 16, 128, 240, 241, 242, 255, 256]   # sub-bands kept from stage sb_input (B=1)
@@ -98,7 +109,8 @@ def run_case(case, FullSubNet_Plus):
     args.update(case["args"])
     torch.manual_seed(0)
     model = FullSubNet_Plus(**args).eval()
-    sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"])
+    sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"],
+                         sequence_model=args["sequence_model"])
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]
@@ -160,7 +172,7 @@ def run_case_fsn(case, Model):
     args.update(case["args"])
     torch.manual_seed(0)
     model = Model(**args).eval()
-    sd = make_state_dict_fullsubnet(case["wseed"], case["profile"])
+    sd = make_state_dict_fullsubnet(case["wseed"], case["profile"], sequence_model=args["sequence_model"])
     res = model.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     kind, B, t, iseed = case["inp"]
@@ -240,7 +252,7 @@ def main():
         msg = f"{case['name']:28s} out{payload['out'].shape} scale {scale:.3e} " \
               f"ref32-vs-64 {np.abs(payload['out'] - payload['out64']).max() / scale:.2e} " \
               f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e}"
-        if mag.shape[-1] <= 40 and args["channel_attention_model"] == "TSSE":
+        if mag.shape[-1] <= 40 and args["channel_attention_model"] == "TSSE" and args["sequence_model"] == "LSTM":
             sdn = {k: v.numpy() for k, v in sd.items()}
             on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kw)
             msg += f" numpy64-vs-ref64 {np.abs(on[:, :, ::sub, :] - payload['out64']).max() / scale:.2e}"

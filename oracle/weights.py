@@ -37,7 +37,7 @@ def _orthogonal(rng, rows, cols):
 
 def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb_hidden=384,
                     sb_num_neighbors=15, fb_num_neighbors=0, kersize=(3, 5, 10), output_size=2,
-                    num_tcn_blocks=8, as_torch=True, attention="TSSE"):
+                    num_tcn_blocks=8, as_torch=True, attention="TSSE", sequence_model="LSTM"):
     assert profile in ("default", "harsh")
     harsh = profile == "harsh"
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -92,19 +92,20 @@ def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb
 
     sb_in = (2 * sb_num_neighbors + 1) + 3 * (2 * fb_num_neighbors + 1)
     H = sb_hidden
+    G = {"LSTM": 4, "GRU": 3}[sequence_model]          # gate blocks of nn.LSTM / nn.GRU (sequence_model.py:31-46)
     for layer, cin in ((0, sb_in), (1, H)):
         p = "sb_model.sequence_model."
         if harsh:
-            sd[p + f"weight_ih_l{layer}"] = _orthogonal(rng, 4 * H, cin)
-            sd[p + f"weight_hh_l{layer}"] = _orthogonal(rng, 4 * H, H)
-            sd[p + f"bias_ih_l{layer}"] = _normal(rng, (4 * H,))
-            sd[p + f"bias_hh_l{layer}"] = _normal(rng, (4 * H,))
+            sd[p + f"weight_ih_l{layer}"] = _orthogonal(rng, G * H, cin)
+            sd[p + f"weight_hh_l{layer}"] = _orthogonal(rng, G * H, H)
+            sd[p + f"bias_ih_l{layer}"] = _normal(rng, (G * H,))
+            sd[p + f"bias_hh_l{layer}"] = _normal(rng, (G * H,))
         else:
             b = 1.0 / np.sqrt(H)
-            sd[p + f"weight_ih_l{layer}"] = _uniform(rng, (4 * H, cin), b)
-            sd[p + f"weight_hh_l{layer}"] = _uniform(rng, (4 * H, H), b)
-            sd[p + f"bias_ih_l{layer}"] = _uniform(rng, (4 * H,), b)
-            sd[p + f"bias_hh_l{layer}"] = _uniform(rng, (4 * H,), b)
+            sd[p + f"weight_ih_l{layer}"] = _uniform(rng, (G * H, cin), b)
+            sd[p + f"weight_hh_l{layer}"] = _uniform(rng, (G * H, H), b)
+            sd[p + f"bias_ih_l{layer}"] = _uniform(rng, (G * H,), b)
+            sd[p + f"bias_hh_l{layer}"] = _uniform(rng, (G * H,), b)
     linear("sb_model.fc_output_layer", output_size, H)
 
     if as_torch:
@@ -114,7 +115,7 @@ def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb
 
 
 def make_state_dict_fullsubnet(seed=0, profile="default", num_freqs=257, fb_hidden=512, sb_hidden=384,
-                                sb_num_neighbors=15, fb_num_neighbors=0, as_torch=True):
+                                sb_num_neighbors=15, fb_num_neighbors=0, as_torch=True, sequence_model="LSTM"):
     """Original FullSubNet (speech_enhance/fullsubnet/model/fullsubnet.py:39-57): two SequenceModel(LSTM) stacks,
     keys ``fb_model.*`` (257 -> 512 x 2 -> 257) then ``sb_model.*`` (32 -> 384 x 2 -> 2)."""
     assert profile in ("default", "harsh")
@@ -122,20 +123,22 @@ def make_state_dict_fullsubnet(seed=0, profile="default", num_freqs=257, fb_hidd
     rng = np.random.Generator(np.random.PCG64(50_000 + seed))
     sd = {}
 
+    G = {"LSTM": 4, "GRU": 3}[sequence_model]
+
     def lstm(prefix, cin, H):
         for layer, c in ((0, cin), (1, H)):
             p = prefix + ".sequence_model."
             if harsh:
-                sd[p + f"weight_ih_l{layer}"] = _orthogonal(rng, 4 * H, c)
-                sd[p + f"weight_hh_l{layer}"] = _orthogonal(rng, 4 * H, H)
-                sd[p + f"bias_ih_l{layer}"] = _normal(rng, (4 * H,))
-                sd[p + f"bias_hh_l{layer}"] = _normal(rng, (4 * H,))
+                sd[p + f"weight_ih_l{layer}"] = _orthogonal(rng, G * H, c)
+                sd[p + f"weight_hh_l{layer}"] = _orthogonal(rng, G * H, H)
+                sd[p + f"bias_ih_l{layer}"] = _normal(rng, (G * H,))
+                sd[p + f"bias_hh_l{layer}"] = _normal(rng, (G * H,))
             else:
                 b = 1.0 / np.sqrt(H)
-                sd[p + f"weight_ih_l{layer}"] = _uniform(rng, (4 * H, c), b)
-                sd[p + f"weight_hh_l{layer}"] = _uniform(rng, (4 * H, H), b)
-                sd[p + f"bias_ih_l{layer}"] = _uniform(rng, (4 * H,), b)
-                sd[p + f"bias_hh_l{layer}"] = _uniform(rng, (4 * H,), b)
+                sd[p + f"weight_ih_l{layer}"] = _uniform(rng, (G * H, c), b)
+                sd[p + f"weight_hh_l{layer}"] = _uniform(rng, (G * H, H), b)
+                sd[p + f"bias_ih_l{layer}"] = _uniform(rng, (G * H,), b)
+                sd[p + f"bias_hh_l{layer}"] = _uniform(rng, (G * H,), b)
 
     def linear(name, cout, cin):
         if harsh:

@@ -32,9 +32,11 @@ class Golden:
 
     def state_dict(self):
         if self.is_fullsubnet:
-            return make_state_dict_fullsubnet(self.meta["wseed"], self.meta["profile"])
+            return make_state_dict_fullsubnet(self.meta["wseed"], self.meta["profile"],
+                                              sequence_model=self.args.get("sequence_model", "LSTM"))
         return make_state_dict(self.meta["wseed"], self.meta["profile"],
-                               attention=self.args.get("channel_attention_model", "TSSE"))
+                               attention=self.args.get("channel_attention_model", "TSSE"),
+                               sequence_model=self.args.get("sequence_model", "LSTM"))
 
     def inputs(self):
         inp = self.meta["inp"]

@@ -180,7 +180,7 @@ def test_forward_with_valu_rows(name):
     assert err < TOL, err
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if "stages" in n or "t30" in n])
+@pytest.mark.parametrize("name", [n for n in golden_names() if "stages" in n or ("t30" in n and "gru" not in n)])
 def test_stages_vs_reference(name):
     """Intermediate buffers (TSSE output, full-band outputs) vs forward-hook captures of the reference."""
     g = Golden(name)
@@ -380,3 +380,38 @@ def test_forward_complex_equals_three_plane_forward():
     assert rel_err(a, g.arrays["out"]) < TOL
     with pytest.raises(AssertionError):
         m.forward_complex(Xg.unsqueeze(1))
+
+
+# ---------------------------------------------------------------- sub-band GRU (sequence_model.py:39-46)
+@pytest.mark.parametrize("n,steps", [(50, 9), (257, 40), (1300, 7), (2750, 6), (6000, 5), (9000, 4)])
+def test_gru2_fc_dense_vs_oracle(n, steps):
+    """nn.GRU cells on the column-split kernels: K-split (<= 42 tiles), three-way split (1-2 tiles per group) and,
+    beyond 170 tiles, consecutive chunks (6000 rows = 170 + 18 tiles, 9000 rows = 170 + 112)."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"}
+    sd = make_state_dict(31, "harsh", sequence_model="GRU")
+    m = _model(args, sd)
+    rng = np.random.Generator(np.random.PCG64(99 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    m.check_errors()
+    err = rel_err(got, want)
+    _record(f"gru2_fc_{n}x{steps}", rel=err)
+    assert err < 2e-5, err
+    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+    with pytest.raises(RuntimeError, match="LSTM sub-band model only"):
+        m.set_precision("bf16_ih")
+
+
+def test_gru_forward_b32_full_vs_oracle():
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"}
+    sd = make_state_dict(32, "default", sequence_model="GRU")
+    mag, real, imag = make_inputs(32, 1.0, 300)
+    m = _model(args, sd, "full")
+    out = m(*_cuda((mag, real, imag))).cpu().numpy()
+    m.check_errors()
+    pick = [0, 17, 31]
+    want = fsnp_torch.forward_full(sd, mag[pick], real[pick], imag[pick]).numpy()
+    err = rel_err(out[pick], want)
+    _record("gru_forward_b32_full", rel=err)
+    assert err < TOL, err

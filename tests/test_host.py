@@ -80,8 +80,8 @@ def test_error_behaviour_matches_reference():
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "RNN"})
     with pytest.raises(NotImplementedError):      # fullsubnet_plus.py:70
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": "XYZ"})
-    with pytest.raises(NotImplementedError):
-        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"})
+    with pytest.raises(NotImplementedError):      # the sub-band TCN of sequence_model.py:47-58 is not built
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "TCN"})
 
 
 def test_weight_init_true_reinitialises():
@@ -272,3 +272,19 @@ def test_fullsubnet_error_behaviour_matches_reference():
         m(torch.zeros(1, 257, 10))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 257, 10))
+
+
+@pytest.mark.parametrize("cls,args,maker", [(FullSubNet_Plus, DEFAULT_MODEL_ARGS, make_state_dict),
+                                            (FullSubNet, FULLSUBNET_MODEL_ARGS, make_state_dict_fullsubnet)])
+def test_gru_variant_has_reference_parameter_tree(cls, args, maker):
+    """sequence_model="GRU" (sequence_model.py:39-46) - nn.GRU key names and [3H, .] shapes."""
+    m = cls(**{**args, "sequence_model": "GRU"})
+    sd = maker(0, sequence_model="GRU")
+    own = m.state_dict()
+    assert list(own.keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(own[k].shape) == tuple(sd[k].shape), k
+    assert own["sb_model.sequence_model.weight_hh_l0"].shape == (3 * 384, 384)
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):             # an LSTM checkpoint must not load into the GRU model
+        m.load_state_dict(maker(0), strict=True)
