@@ -415,3 +415,43 @@ def test_gru_forward_b32_full_vs_oracle():
     err = rel_err(out[pick], want)
     _record("gru_forward_b32_full", rel=err)
     assert err < TOL, err
+
+
+# ---------------------------------------------------------------- drop-in behaviour of the nn.Module shell
+def test_weight_update_repacks_device_weights():
+    """The packed device blob is rebuilt lazily when a parameter changes (load_state_dict / in-place update), as a
+    torch module would behave (base_inferencer.py:100-107 loads AFTER construction)."""
+    g = Golden("b1_t24_default_stages")
+    m = _model(g.args, g.state_dict())
+    ins = _cuda(g.inputs())
+    a = m(*ins).cpu().numpy()
+    sd2 = make_state_dict(123, "harsh")
+    m.load_state_dict(sd2, strict=True)
+    b = m(*ins).cpu().numpy()
+    want = fsnp_torch.forward(sd2, *g.inputs(), **g.fwd_kwargs()).numpy()
+    assert rel_err(b, want) < TOL and rel_err(a, b) > 1e-2
+    with torch.no_grad():
+        m.sb_model.fc_output_layer.bias += 0.5           # in-place edit bumps the parameter version
+    c = m(*ins).cpu().numpy()
+    assert abs(float((c - b).mean()) - 0.5) < 1e-4
+
+
+def test_forward_on_side_stream_and_second_handle():
+    """fsnp_forward enqueues on the caller's current HIP stream (no device sync inside); two modules own two
+    independent handles."""
+    g = Golden("b3_t20_harsh")
+    m1 = _model(g.args, g.state_dict(), "full")
+    m2 = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    ref = m1(*ins).cpu().numpy()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o1 = m1(*ins)
+        o2 = m2(*ins)
+    side.synchronize()
+    assert np.array_equal(o1.cpu().numpy(), ref) and np.array_equal(o2.cpu().numpy(), ref)
+    assert rel_err(ref, g.arrays["full"]) < TOL
+    import copy
+    m3 = copy.deepcopy(m1)                                # a copied module gets its own handle lazily
+    assert np.array_equal(m3(*ins).cpu().numpy(), ref)
