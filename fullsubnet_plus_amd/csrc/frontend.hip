@@ -335,8 +335,10 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
 }
 
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
-                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s) {
-    if (is_complex) {
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s, int phase) {
+    if (phase == FE_PHASE_REST) {
+        // the caller's tensors are only touched by the repack kernels
+    } else if (is_complex) {
         hipLaunchKernelGGL(fe_repack_complex_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s,
                            reinterpret_cast<const float2*>(in[0]), (long)strides[0][0], (long)strides[0][1],
                            (long)strides[0][2], buf.raw, 3, d.B, d.T, d.Tp, d.F, d.FP);
@@ -349,6 +351,7 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
         hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw,
                            d.B, d.T, d.Tp, d.F, d.FP);
     }
+    if (phase == FE_PHASE_REPACK) return;
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
     hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, FSUM_ROWS), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,

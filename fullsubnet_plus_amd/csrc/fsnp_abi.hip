@@ -36,6 +36,19 @@ struct Workspace {
         fb_hx, fb_bar, zero_end, dbg_tcn0, total;
 };
 
+// The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1, of
+// which most is launch latency): it is captured once per (shape, mode, plan) into a hipGraph and replayed.
+struct GraphKey {
+    int B, T, mode, boff, gb, num_cus, coop, bf16, debug;
+    const void* ws;
+    const void* weights;
+    bool operator==(const GraphKey& o) const {
+        return B == o.B && T == o.T && mode == o.mode && boff == o.boff && gb == o.gb && num_cus == o.num_cus &&
+               coop == o.coop && bf16 == o.bf16 && debug == o.debug && ws == o.ws && weights == o.weights;
+    }
+};
+struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
+
 struct TimingRec {
     hipEvent_t e[3];  // start, after full-band stages, after lstm (= end)
 };
@@ -80,6 +93,11 @@ struct fsnp_handle {
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in the cooperative LSTM kernel
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
+    int use_graph = 1;           // 0 = plain launches (FSNP_GRAPH=0)
+    hipStream_t cap_stream = nullptr;   // private stream: graph capture and replay
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::vector<GraphEntry> graphs;
+
     bool timing = false;
     std::vector<TimingRec> timing_recs;
     double acc_ms[3] = {0, 0, 0};
@@ -94,6 +112,57 @@ static const char* kFb[3] = {"fb_model", "fb_model_real", "fb_model_imag"};
 static const char* kConvNames[3] = {"smallConv1d", "middleConv1d", "largeConv1d"};
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void drop_graphs(fsnp_handle* h) {
+    for (auto& e : h->graphs) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
+    h->graphs.clear();
+}
+
+// Launches a cached graph on the handle's private stream, ordered after / before the caller's stream with events
+// (the caller's stream is usually torch's legacy default stream, which cannot be captured; keeping the replay on the
+// capture stream makes the ordering explicit instead of relying on default-stream semantics).
+static int launch_graph_between(fsnp_handle* h, hipGraphExec_t exec, hipStream_t s) {
+    FSNP_HIP_CHECK(hipEventRecord(h->ev_in, s));
+    FSNP_HIP_CHECK(hipStreamWaitEvent(h->cap_stream, h->ev_in, 0));
+    FSNP_HIP_CHECK(hipGraphLaunch(exec, h->cap_stream));
+    FSNP_HIP_CHECK(hipEventRecord(h->ev_out, h->cap_stream));
+    FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_out, 0));
+    return 0;
+}
+
+// Replays `middle` (workspace-only launches) from a cached hipGraph; captures it on the private stream the first time.
+template <typename F>
+static int run_graphed(fsnp_handle* h, const GraphKey& key, hipStream_t s, F middle) {
+    if (!h->cap_stream) {
+        FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
+    for (auto& e : h->graphs)
+        if (e.key == key) return launch_graph_between(h, e.exec, s);
+    FSNP_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    middle(h->cap_stream);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(h->cap_stream, &g);
+    if (ec != hipSuccess || g == nullptr) {
+        set_error("hipGraph capture of the full-band stages failed: %s (set FSNP_GRAPH=0 to launch kernel by kernel)", hipGetErrorString(ec));
+        return 4;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        set_error("hipGraphInstantiate failed: %s (set FSNP_GRAPH=0 to launch kernel by kernel)", hipGetErrorString(ei));
+        return 4;
+    }
+    if (h->graphs.size() >= 8) {
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        (void)hipGraphDestroy(h->graphs.front().graph);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back({key, g, ex});
+    return launch_graph_between(h, ex, s);
+}
 
 static void build_specs(fsnp_handle* h) {
     auto add = [&](const std::string& n, int64_t numel) { h->specs.push_back({n, numel}); };
@@ -198,6 +267,20 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
     rows[slot] = r;
 }
 
+// Zeroes the accumulator / exchange / barrier region of the workspace.  A kernel rather than hipMemsetAsync: a memset
+// node captured into the hipGraph was NOT re-executed reliably on replay (ROCm 7.2: stale barrier counters and
+// accumulators after the first launch - tests/test_gpu_parity.py::test_b32_batch_independence caught it).
+__global__ __launch_bounds__(256) void zero_region_kernel(uint4* __restrict__ p, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static void launch_zero_region(void* p, size_t bytes, hipStream_t s) {      // bytes is a multiple of 256
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_region_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16);
+}
+
 // The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
 // would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
 // Which sub-band LSTM kernel runs `lp`: the row-tile kernel needs >= 256 tiles to fill the chip and costs ~208 us per
@@ -298,6 +381,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
 
 static int ensure_workspace(fsnp_handle* h, size_t bytes) {
     if (bytes <= h->ws_bytes) return 0;
+    drop_graphs(h);
     if (h->ws) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes));
     h->ws_bytes = bytes;
@@ -383,6 +467,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         delete h;
         return 4;
     }
+    const char* gp = getenv("FSNP_GRAPH");
+    if (gp && gp[0] == '0') h->use_graph = 0;
     const char* nw = getenv("FSNP_LSTM_WAVES");
     if (nw && atoi(nw) == 4) h->lstm_waves = 4;
     if (nw && atoi(nw) == 12) h->lstm_waves = 12;
@@ -395,6 +481,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
 void fsnp_destroy(fsnp_handle* h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
+    drop_graphs(h);
+    if (h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); }
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_err) (void)hipFree(h->d_err);
@@ -599,6 +687,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         for (int j = 0; j < h->NSB; ++j) blob[o_refl + reflect_index(f - h->cfg.sb_num_neighbors + j, F)] += 1.0f;
 
     FSNP_HIP_CHECK(hipSetDevice(h->device));
+    drop_graphs(h);
     if (h->d_weights) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->d_weights)); h->d_weights = nullptr; }
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_weights), blob.size() * sizeof(float)));
     FSNP_HIP_CHECK(hipMemcpy(h->d_weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -671,14 +760,22 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         for (auto& e : rec.e) FSNP_HIP_CHECK(hipEventCreate(&e));
         FSNP_HIP_CHECK(hipEventRecord(rec.e[0], s));
     }
-    FSNP_HIP_CHECK(hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, s));
-
     const int num_rows = batch * rows_per_utt(h, mode);
     const LstmPlan lp = sb_plan(h, num_rows);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
-    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_rows, lp.num_tiles,
-                       lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
+    const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
+    SubbandBuffers sbuf;
+    sbuf.att_mag = fptr(w.att); sbuf.fb = fptr(w.fb); sbuf.refl_w = h->d_refl_w;
+    sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
+    sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
+    sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
+    // workspace-only prologue shared by both models: zero the accumulators, describe the sub-band rows
+    auto prologue = [&](hipStream_t st) {
+        launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
+        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, st, rows, num_rows, lp.num_tiles,
+                           lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
+    };
 
     if (!fsn) {
         FrontendBuffers fbuf;
@@ -686,14 +783,27 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
         fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
         const float* in[3] = {mag, real, imag};
-        launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s);
-
         TcnBuffers tbuf;
         tbuf.att = fptr(w.att); tbuf.x = fptr(w.x); tbuf.y1 = fptr(w.y1); tbuf.y2 = fptr(w.y2);
         tbuf.gn = reinterpret_cast<double*>(base + w.gn); tbuf.fb = fptr(w.fb);
         tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
-        launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+        // the caller's tensors are read by the repack kernel only; everything up to the LSTM then stays in the workspace
+        launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s, FE_PHASE_REPACK);
+        auto middle = [&](hipStream_t st) {
+            prologue(st);
+            launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, st, FE_PHASE_REST);
+            launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, st);
+            launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, st);
+        };
+        if (h->use_graph) {
+            const GraphKey key{batch, frames, mode, batch_offset, global_batch, h->num_cus, h->lstm_coop, h->ih_bf16,
+                               h->debug ? 1 : 0, h->ws, h->d_weights};
+            if (run_graphed(h, key, s, middle)) return 4;
+        } else {
+            middle(s);
+        }
     } else {
+        prologue(s);
         // fullsubnet.py:82-90: pad, norm(noisy_mag), 2-layer LSTM(F -> CH), Linear(CH, F) + fb_act
         FrontendBuffers fbuf{};
         fbuf.raw = fptr(w.att); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
@@ -712,15 +822,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         launch_lstm_coop_seq(h->fbw, fa, s);
         launch_linear_act(fptr(w.y1), d.CH, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
+        launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     }
-
-    const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
-    SubbandBuffers sbuf;
-    sbuf.att_mag = fptr(w.att); sbuf.fb = fptr(w.fb); sbuf.refl_w = h->d_refl_w;
-    sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
-    sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
-    sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
-    launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[1], s));
 
     LstmArgs a{};
@@ -891,6 +994,12 @@ int fsnp_check_errors(fsnp_handle* h) {
                   "results of that forward are invalid - set FSNP_LSTM_COOP=0");
         return 5;
     }
+    return 0;
+}
+
+int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_graph: mode must be 0 (plain launches) or 1 (hipGraph replay)"); return 1; }
+    h->use_graph = mode;
     return 0;
 }
 

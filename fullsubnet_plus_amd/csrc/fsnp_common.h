@@ -55,8 +55,11 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
                        const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
 // is_complex: in[0] is the interleaved complex64 STFT buffer (strides[0] in complex elements); mag / real / imag are
 // derived inside the repack kernel
+// phase: everything, only the repack of the caller's tensors into buf.raw, or everything after it (workspace only:
+// the part fsnp_forward replays from a hipGraph)
+enum { FE_PHASE_ALL = 0, FE_PHASE_REPACK = 1, FE_PHASE_REST = 2 };
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
-                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s, int phase = FE_PHASE_ALL);
 // original FullSubNet: magnitude only - repack into buf.raw [B][Tp][FP] and the norm's (m_t, d_t) table into buf.md
 void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3], bool is_complex,
                          const FrontendBuffers& buf, hipStream_t s);

@@ -311,6 +311,14 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
+    def debug_set_graph(self, mode, device="cuda"):
+        """Tuning hook: 1 = replay the full-band stages from a hipGraph (default), 0 = launch kernel by kernel."""
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        lib = self._ensure_handle(dev)
+        _lib.check(lib.fsnp_debug_set_graph(self._handle, int(mode)), "fsnp_debug_set_graph")
+
     def set_precision(self, mode, device="cuda"):
         """"fp32" (default) or "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16)."""
         assert mode in ("fp32", "bf16_ih")

@@ -187,6 +187,10 @@ int fsnp_check_errors(fsnp_handle* h);
  * row_tiles * H/32 workgroups fit the chip (small batches, e.g. the reference CLI's batch of one); 0 = never
  * (also FSNP_LSTM_COOP=0 at fsnp_create time). */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
+/* Tuning hook: 1 (default; env FSNP_GRAPH=0 turns it off) = the ~75 workspace-only launches between the input repack and
+ * the sub-band LSTM of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph and replayed on
+ * the caller's stream; 0 = plain launches. */
+int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode);
 
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
  * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the

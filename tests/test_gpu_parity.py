@@ -455,3 +455,33 @@ def test_forward_on_side_stream_and_second_handle():
     import copy
     m3 = copy.deepcopy(m1)                                # a copied module gets its own handle lazily
     assert np.array_equal(m3(*ins).cpu().numpy(), ref)
+
+
+def test_graph_replay_equals_plain_launches():
+    """The hipGraph replay of the full-band stages (fsnp_abi.hip run_graphed) is bit-identical to kernel-by-kernel
+    launches, survives shape changes (new graphs), workspace growth and weight re-packing (graphs dropped)."""
+    g = Golden("b1_t24_default_stages")
+    m = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    m.debug_set_graph(0)
+    plain = m(*ins).cpu().numpy()
+    m.debug_set_graph(1)
+    first = m(*ins).cpu().numpy()                      # captures
+    second = m(*ins).cpu().numpy()                     # replays
+    assert np.array_equal(plain, first) and np.array_equal(plain, second)
+    big = _cuda(make_spec(4, 40, 5))                   # other shape + workspace growth
+    b1 = m(*big).cpu().numpy()
+    m.debug_set_graph(0)
+    assert np.array_equal(m(*big).cpu().numpy(), b1)
+    m.debug_set_graph(1)
+    assert np.array_equal(m(*ins).cpu().numpy(), plain)    # back to the first shape (re-captured after the growth)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        on_side = m(*ins)
+    side.synchronize()
+    assert np.array_equal(on_side.cpu().numpy(), plain)
+    m.load_state_dict(make_state_dict(5, "harsh"), strict=True)
+    changed = m(*ins).cpu().numpy()
+    m.debug_set_graph(0)
+    assert np.array_equal(m(*ins).cpu().numpy(), changed) and not np.array_equal(changed, plain)
