@@ -21,7 +21,7 @@ NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_
               "cumulative_layer_norm": 3}
 ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
 ATTENTION = {"TSSE": 0, "SE": 1, "ECA": 2, "CBAM": 3}
-SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1}
+SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1, "TCN": 2}
 MODE_FULL, MODE_PARITY = 0, 1
 MODEL_FULLSUBNET_PLUS, MODEL_FULLSUBNET = 0, 1
 

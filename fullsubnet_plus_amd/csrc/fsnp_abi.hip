@@ -32,8 +32,8 @@ struct WeightSpec {
 
 struct Workspace {
     // offsets in bytes from the workspace base
-    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, zero_begin, fsum, gn, sb_acc, coop_hx, coop_bar,
-        fb_hx, fb_bar, zero_end, dbg_tcn0, total;
+    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, sbt_x0, sbt_x, sbt_fb, sbt_y1, sbt_y2, zero_begin,
+        fsum, gn, sb_acc, coop_hx, coop_bar, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
 };
 
 // The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1, of
@@ -73,6 +73,9 @@ struct fsnp_handle {
     int model = FSNP_MODEL_FULLSUBNET_PLUS;
     int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
     int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
+    int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
+    TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
+    int XS = 0;                  //     row stride of its [slot][t][NIN] activations
     int NG = 4;                  // gate blocks per weight matrix: 4 (LSTM) or 3 (GRU)
     LstmWeights fbw{};
     const float* fsn_wf = nullptr;   // [F pad 384][CH pad 16]
@@ -221,6 +224,26 @@ static void build_specs(fsnp_handle* h) {
         add(std::string(kFb[b]) + ".fc_output_layer.weight", (int64_t)F * F);
         add(std::string(kFb[b]) + ".fc_output_layer.bias", F);
     }
+    if (h->sb_tcn) {
+        for (int i = 0; i < 8; ++i) {
+            const std::string p = "sb_model.sequence_model." + std::to_string(i);
+            add(p + ".conv1x1.weight", (int64_t)CH * h->NIN);
+            add(p + ".conv1x1.bias", CH);
+            add(p + ".prelu1.weight", 1);
+            add(p + ".norm1.weight", CH);
+            add(p + ".norm1.bias", CH);
+            add(p + ".depthwise_conv.weight", (int64_t)CH * 3);
+            add(p + ".depthwise_conv.bias", CH);
+            add(p + ".prelu2.weight", 1);
+            add(p + ".norm2.weight", CH);
+            add(p + ".norm2.bias", CH);
+            add(p + ".sconv.weight", (int64_t)h->NIN * CH);
+            add(p + ".sconv.bias", h->NIN);
+        }
+        add("sb_model.fc_output_layer.weight", (int64_t)h->cfg.output_size * h->NIN);
+        add("sb_model.fc_output_layer.bias", h->cfg.output_size);
+        return;
+    }
     const std::string s = "sb_model.sequence_model.";
     const int64_t G = h->NG;
     add(s + "weight_ih_l0", G * H * h->NIN);
@@ -290,6 +313,7 @@ static void launch_zero_region(void* p, size_t bytes, hipStream_t s) {      // b
 struct SbKernel { int kind; int units; int groups; int rpg; };   // kind 0 = row tile, 1 = coop (K split), 2 = coopn
 static SbKernel sb_kernel(const fsnp_handle* h, const LstmPlan& lp) {
     SbKernel k{0, 0, 0, 0};
+    if (h->sb_tcn) return k;      // no recurrent kernel at all
     if (h->gru) {       // no row-tile GRU kernel: <= 42 tiles K split, otherwise chunks of <= 170 tiles on lstm_coopn.hip
         k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
         k.kind = k.units != 0 ? 1 : 2;
@@ -327,7 +351,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const LstmPlan& lp, LstmArgs& a
 }
 // Tile plan of the sub-band problem: GRU has no VALU-row variant, always plain 32-row tiles
 static LstmPlan sb_plan(const fsnp_handle* h, int num_rows) {
-    if (h->gru) return LstmPlan{cdiv(num_rows, 32), 0, 32};
+    if (h->gru || h->sb_tcn) return LstmPlan{cdiv(num_rows, 32), 0, 32};
     return plan_lstm_tiles(num_rows, h->num_cus);
 }
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
@@ -364,6 +388,8 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.rows = take(nrows_pad * sizeof(RowDesc));
     w.fb_rows = take(fsn ? (size_t)fb_row_tiles(B) * 32 * sizeof(RowDesc) : 0);
     w.frame = take(nbr * B * Tp * 2 * 8);
+    const size_t sbt_x = h->sb_tcn ? nrows_pad * Tp * h->XS * 4 : 0, sbt_y = h->sb_tcn ? nrows_pad * Tp * h->CH * 4 : 0;
+    w.sbt_x0 = take(sbt_x); w.sbt_x = take(sbt_x); w.sbt_fb = take(sbt_x); w.sbt_y1 = take(sbt_y); w.sbt_y2 = take(sbt_y);
     w.zero_begin = o;
     w.fsum = take(fsn ? 0 : (size_t)3 * B * h->FP * 8);
     w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
@@ -373,6 +399,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.coop_bar = take(coop ? (size_t)lp.num_tiles * 4 : 0);
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
+    w.sbt_gn = take(h->sb_tcn ? (size_t)8 * 2 * nrows_pad * 2 * 8 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
     w.total = o;
@@ -389,6 +416,7 @@ static int ensure_workspace(fsnp_handle* h, size_t bytes) {
 }
 
 static double lstm_flops_per_step(const fsnp_handle* h) {
+    if (h->sb_tcn) return 8 * (2.0 * h->NIN * h->CH + 2.0 * h->CH * 3 + 2.0 * h->CH * h->NIN) + 2.0 * h->NIN * h->cfg.output_size;
     const double H = h->H, NIN = h->NIN, OUT = h->cfg.output_size, G = h->NG;
     return 2.0 * G * H * (NIN + H) + 2.0 * G * H * (2 * H) + 2.0 * H * OUT;
 }
@@ -413,14 +441,15 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     *out = nullptr;
     if (cfg->fb_num_neighbors != 0) { set_error("fb_num_neighbors != 0 is not supported by the HIP path"); return 2; }
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
-    if (cfg->sb_hidden != 384) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
+    if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
     if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
     if (cfg->attention < 0 || cfg->attention > 3) { set_error("unknown attention model %d", cfg->attention); return 2; }
     if (cfg->model != FSNP_MODEL_FULLSUBNET_PLUS && cfg->model != FSNP_MODEL_FULLSUBNET) { set_error("unknown model %d", cfg->model); return 2; }
-    if (cfg->sequence_model != FSNP_SEQ_LSTM && cfg->sequence_model != FSNP_SEQ_GRU) { set_error("unknown sequence_model %d", cfg->sequence_model); return 2; }
+    if (cfg->sequence_model < FSNP_SEQ_LSTM || cfg->sequence_model > FSNP_SEQ_TCN) { set_error("unknown sequence_model %d", cfg->sequence_model); return 2; }
     const bool fsn = cfg->model == FSNP_MODEL_FULLSUBNET;
+    if (fsn && cfg->sequence_model == FSNP_SEQ_TCN) { set_error("FullSubNet only supports GRU and LSTM"); return 2; }
     if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
     if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
     const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3);
@@ -448,6 +477,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->num_cus_real = h->num_cus;
     h->model = cfg->model;
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
+    h->sb_tcn = cfg->sequence_model == FSNP_SEQ_TCN;
+    h->XS = (int)align_up(nin, 4);
     h->NG = h->gru ? 3 : 4;
     h->NFB = fsn ? 1 : 3;
     h->F = cfg->num_freqs;
@@ -631,9 +662,9 @@ int fsnp_commit_weights(fsnp_handle* h) {
         }
         return r;
     };
-    const Rnn4 sbw = expand("sb_model.sequence_model.", H, h->NIN);
+    const Rnn4 sbw = h->sb_tcn ? Rnn4{} : expand("sb_model.sequence_model.", H, h->NIN);
     size_t o_wpack = 0, o_wpack12 = 0, o_wpack_bf[2] = {0, 0};
-    if (!h->gru) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
+    if (!h->gru && !h->sb_tcn) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
         o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
         lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
         o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
@@ -646,15 +677,55 @@ int fsnp_commit_weights(fsnp_handle* h) {
         }
     }
     size_t o_wpack_coop[4] = {0, 0, 0, 0};
-    for (int ui = 0; ui < 4; ++ui) {
+    for (int ui = 0; ui < 4 && !h->sb_tcn; ++ui) {
         const int units = 8 << ui;
         o_wpack_coop[ui] = alloc(lstm_coop_pack_floats(H, h->KX, units));
         lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                blob.data() + o_wpack_coop[ui]);
     }
-    const size_t o_wpack_coopn = alloc(lstm_coopn_pack_floats(H, h->KX));
-    lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
-                            blob.data() + o_wpack_coopn);
+    const size_t o_wpack_coopn = alloc(h->sb_tcn ? 0 : lstm_coopn_pack_floats(H, h->KX));
+    if (!h->sb_tcn)
+        lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
+                                blob.data() + o_wpack_coopn);
+    // ---- sub-band TCN (sequence_model="TCN"): the full-band GEMM operand layouts, ONE branch, NIN input channels
+    const int sK1P = (int)align_up(h->NIN, 16), sN2P = (int)align_up(h->NIN, 384);
+    size_t so_w1 = 0, so_b1 = 0, so_a1 = 0, so_g1w = 0, so_g1b = 0, so_dw = 0, so_db = 0, so_a2 = 0, so_g2w = 0, so_g2b = 0,
+           so_w2 = 0, so_b2 = 0, so_wf = 0, so_bf = 0;
+    if (h->sb_tcn) {
+        const int SNB = 8, NINs = h->NIN;
+        so_w1 = alloc((size_t)SNB * N1P * sK1P); so_b1 = alloc((size_t)SNB * N1P); so_a1 = alloc(SNB + 1);
+        so_g1w = alloc((size_t)SNB * CH); so_g1b = alloc((size_t)SNB * CH);
+        so_dw = alloc((size_t)SNB * 3 * CH); so_db = alloc((size_t)SNB * CH); so_a2 = alloc(SNB + 1);
+        so_g2w = alloc((size_t)SNB * CH); so_g2b = alloc((size_t)SNB * CH);
+        so_w2 = alloc((size_t)SNB * sN2P * K2P); so_b2 = alloc((size_t)SNB * sN2P);
+        so_wf = alloc((size_t)sN2P * sK1P); so_bf = alloc(sN2P);
+        for (int i = 0; i < SNB; ++i) {
+            const std::string p = "sb_model.sequence_model." + std::to_string(i);
+            const auto& w1 = W(p + ".conv1x1.weight");          // [CH][NIN][1]
+            for (int n = 0; n < CH; ++n)
+                for (int k = 0; k < NINs; ++k) blob[so_w1 + ((size_t)i * N1P + n) * sK1P + k] = w1[(size_t)n * NINs + k];
+            std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + so_b1 + (size_t)i * N1P);
+            blob[so_a1 + i] = W(p + ".prelu1.weight")[0];
+            std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + so_g1w + (size_t)i * CH);
+            std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + so_g1b + (size_t)i * CH);
+            const auto& dw = W(p + ".depthwise_conv.weight");
+            for (int c = 0; c < CH; ++c)
+                for (int j = 0; j < 3; ++j) blob[so_dw + ((size_t)i * 3 + j) * CH + c] = dw[(size_t)c * 3 + j];
+            std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + so_db + (size_t)i * CH);
+            blob[so_a2 + i] = W(p + ".prelu2.weight")[0];
+            std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + so_g2w + (size_t)i * CH);
+            std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + so_g2b + (size_t)i * CH);
+            const auto& w2 = W(p + ".sconv.weight");             // [NIN][CH][1]
+            for (int n = 0; n < NINs; ++n)
+                for (int k = 0; k < CH; ++k) blob[so_w2 + ((size_t)i * sN2P + n) * K2P + k] = w2[(size_t)n * CH + k];
+            std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + so_b2 + (size_t)i * sN2P);
+        }
+        const auto& wf = W("sb_model.fc_output_layer.weight");   // [2][NIN]: rows 0..1 of a zero-padded [sN2P][sK1P]
+        for (int n = 0; n < h->cfg.output_size; ++n)
+            for (int k = 0; k < NINs; ++k) blob[so_wf + (size_t)n * sK1P + k] = wf[(size_t)n * NINs + k];
+        const auto& bfv = W("sb_model.fc_output_layer.bias");
+        std::copy(bfv.begin(), bfv.end(), blob.begin() + so_bf);
+    }
     // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
     size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
@@ -679,8 +750,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     const size_t o_lbias = alloc(sbw.bias.size());
     std::copy(sbw.bias.begin(), sbw.bias.end(), blob.begin() + o_lbias);
-    const size_t o_wfc = put("sb_model.fc_output_layer.weight");
-    const size_t o_bfc = put("sb_model.fc_output_layer.bias");
+    const size_t o_wfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.weight");
+    const size_t o_bfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.bias");
     // ---- unfold multiplicities w_r, by brute force over (f, j)
     const size_t o_refl = alloc(F);
     for (int f = 0; f < F; ++f)
@@ -709,6 +780,14 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
+    if (h->sb_tcn) {
+        TcnWeights& t = h->sbt;
+        t.w1 = d + so_w1; t.b1 = d + so_b1; t.a1 = d + so_a1; t.g1w = d + so_g1w; t.g1b = d + so_g1b;
+        t.dw = d + so_dw; t.db = d + so_db; t.a2 = d + so_a2; t.g2w = d + so_g2w; t.g2b = d + so_g2b;
+        t.w2 = d + so_w2; t.b2 = d + so_b2; t.wf = d + so_wf; t.bf = d + so_bf;
+        t.num_cus = h->num_cus; t.NB = 8; t.N1P = N1P; t.K1P = sK1P; t.N2P = sN2P; t.K2P = K2P;
+        for (int i = 0; i < 8; ++i) t.dilation[i] = kDilations[i];
+    }
     if (fsn) {
         h->fbw = LstmWeights{};
         for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
@@ -826,6 +905,31 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     }
     if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[1], s));
 
+    if (h->sb_tcn) {
+        // sequence_model="TCN": materialise the normalised sub-band input, run the TCN stack over the sub-band sequences
+        // (one "utterance" per sequence: GroupNorm(1, 512) statistics are per sequence), Linear(34, 2), scatter
+        SbGatherArgs ga{};
+        ga.att_mag = fptr(w.att); ga.fb_rel = (int)((w.fb - w.att) / 4); ga.fb_branch_stride = d.B * d.Tp * d.FP;
+        ga.rows = rows; ga.md_utt = sbuf.md_utt; ga.md_row = sbuf.md_row;
+        ga.x = fptr(w.sbt_x0); ga.xstride = h->XS;
+        ga.num_slots = num_slots; ga.Tp = d.Tp; ga.FP = d.FP; ga.F = d.F; ga.NSBN = h->cfg.sb_num_neighbors; ga.NIN = h->NIN;
+        launch_sb_gather(ga, s);
+        Dims ds = d;
+        ds.B = num_slots; ds.F = h->NIN; ds.FP = h->XS;
+        TcnBuffers tb{};
+        tb.att = fptr(w.sbt_x0); tb.x = fptr(w.sbt_x); tb.y1 = fptr(w.sbt_y1); tb.y2 = fptr(w.sbt_y2);
+        tb.gn = reinterpret_cast<double*>(base + w.sbt_gn); tb.fb = fptr(w.sbt_fb);
+        h->sbt.num_cus = h->num_cus;
+        launch_tcn(ds, h->cfg.sb_act, h->sbt, tb, s, 1);
+        launch_sb_scatter(fptr(w.sbt_fb), h->XS, rows, out, (long)rows_per_utt(h, mode) * frames, num_slots, d.Tp, d.LA, s);
+        if (h->timing) {
+            FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
+            h->timing_recs.push_back(rec);
+        }
+        FSNP_HIP_CHECK(hipGetLastError());
+        h->last_ws = w; h->last_dims = d; h->have_last = true;
+        return 0;
+    }
     LstmArgs a{};
     a.att_mag = fptr(w.att); a.fb = fptr(w.fb);
     a.fb_rel = (int)((w.fb - w.att) / 4);
@@ -872,6 +976,7 @@ int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides
 int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, void* hip_stream) {
     if (!h || !x || !out) { set_error("fsnp_lstm2_fc: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_lstm2_fc: weights not committed"); return 2; }
+    if (h->sb_tcn) { set_error("fsnp_lstm2_fc: the sub-band model of this handle is a TCN (no recurrent kernel)"); return 2; }
     if (num_seq <= 0 || steps <= 0) { set_error("fsnp_lstm2_fc: empty input"); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_HIP_CHECK(hipSetDevice(h->device));
@@ -953,7 +1058,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_lstm_profile: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
-    if (h->gru) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
+    if (h->gru || h->sb_tcn) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     const LstmPlan lp = sb_plan(h, num_seq);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
@@ -976,7 +1081,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || (ih_bf16 != 0 && ih_bf16 != 1)) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM)"); return 1; }
-    if (ih_bf16 && h->gru) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
+    if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
     h->ih_bf16 = ih_bf16;
     h->lw.ih_bf16 = ih_bf16;
     return 0;

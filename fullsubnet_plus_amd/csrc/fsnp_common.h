@@ -97,7 +97,7 @@ struct TcnBuffers {
     float* dbg_tcn0;   // optional [B][Tp][FP]: mag branch after block 0
 };
 
-void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s);
+void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s, int branches = 3);
 void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,
                        int N, int B, int Tp, int act, int num_cus, hipStream_t s);
 
@@ -116,6 +116,17 @@ struct RowDesc { int b, f, out_off, valid; };
 
 void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
                           int num_slots, hipStream_t s);
+// sequence_model="TCN" only: materialise the normalised sub-band input x[slot][t][xstride] (the recurrent kernels gather
+// it on the fly instead), and scatter y[slot][t][0..1] into the caller's mask tensor (look-ahead slice included)
+struct SbGatherArgs {
+    const float* att_mag; int fb_rel, fb_branch_stride;
+    const RowDesc* rows; const NormMD* md_utt; const NormMD* md_row;
+    float* x; int xstride;
+    int num_slots, Tp, FP, F, NSBN, NIN;
+};
+void launch_sb_gather(const SbGatherArgs& a, hipStream_t s);
+void launch_sb_scatter(const float* y, int ystride, const RowDesc* rows, float* out, long out_stride_o, int num_slots,
+                       int Tp, int LA, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile

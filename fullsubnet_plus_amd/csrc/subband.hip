@@ -113,4 +113,45 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
     }
 }
 
+// ---- sequence_model="TCN" (sequence_model.py:47-58): the sub-band model is a TCN stack over [N, 34, T'], so the
+// sub-band input of fullsubnet_plus.py:167-202 IS materialised here, time-major [slot][t][xstride], normalised.
+__global__ __launch_bounds__(256) void sb_gather_kernel(SbGatherArgs a) {
+    const int slot = blockIdx.x;
+    const RowDesc rd = a.rows[slot];
+    const int nsb = 2 * a.NSBN + 1;
+    for (int i = threadIdx.x; i < a.Tp * a.xstride; i += 256) {
+        const int t = i / a.xstride, j = i % a.xstride;
+        float v = 0.0f;
+        if (rd.valid && j < a.NIN) {
+            const int base = (rd.b * a.Tp + t) * a.FP;
+            const int off = (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
+                                      : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
+            const NormMD m = a.md_row ? a.md_row[(size_t)slot * a.Tp + t] : a.md_utt[rd.b];
+            v = (a.att_mag[off] - m.m) / m.d;
+        }
+        a.x[((size_t)slot * a.Tp + t) * a.xstride + j] = v;
+    }
+}
+
+__global__ void sb_scatter_kernel(const float* __restrict__ y, int ystride, const RowDesc* __restrict__ rows,
+                                  float* __restrict__ out, long out_stride_o, int num_slots, int Tp, int LA) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (slot, o, t)
+    const int T = Tp - LA;
+    if (i >= (long)num_slots * 2 * T) return;
+    const int t = (int)(i % T), o = (int)((i / T) % 2), slot = (int)(i / (2 * T));
+    const RowDesc rd = rows[slot];
+    if (rd.valid) out[(size_t)rd.out_off + (size_t)o * out_stride_o + t] = y[((size_t)slot * Tp + t + LA) * ystride + o];
+}
+
+void launch_sb_gather(const SbGatherArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(sb_gather_kernel, dim3(a.num_slots), dim3(256), 0, s, a);
+}
+
+void launch_sb_scatter(const float* y, int ystride, const RowDesc* rows, float* out, long out_stride_o, int num_slots,
+                       int Tp, int LA, hipStream_t s) {
+    const long n = (long)num_slots * 2 * (Tp - LA);
+    hipLaunchKernelGGL(sb_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, ystride, rows, out,
+                       out_stride_o, num_slots, Tp, LA);
+}
+
 }  // namespace fsnp

@@ -297,12 +297,14 @@ __global__ __launch_bounds__(256) void tcn_dwconv_kernel(DwArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s) {
+// `branches` sequence models run side by side (grid.z): 3 for the full-band mag / real / imag models, 1 when the same
+// stack is the SUB-BAND model (sequence_model="TCN", sequence_model.py:47-58: d.B = sub-band sequences, d.F = 34 channels).
+void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s, int branches) {
     const long x_bs = (long)d.B * d.Tp * d.FP;
     const long y_bs = (long)d.B * d.Tp * d.CH;
     const int row_tiles = cdiv(d.Tp, BM) * d.B;
     const double gn_count = (double)d.CH * d.Tp;
-    auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * 3) * d.B * 2; };
+    auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * branches) * d.B * 2; };
 
     for (int blk = 0; blk < w.NB; ++blk) {
         const float* xin = blk == 0 ? buf.att : buf.x;
@@ -315,7 +317,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gn_out = gn_slot(blk, 0);
             g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
             g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
-            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s);
+            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s, branches);
         }
         {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
             DwArgs g{};
@@ -327,7 +329,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.prelu = w.a2 + blk; g.prelu_bs = w.NB;
             g.CH = d.CH; g.Tp = d.Tp; g.B = d.B; g.dil = w.dilation[blk];
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            hipLaunchKernelGGL(tcn_dwconv_kernel, dim3(cdiv(d.Tp, DW_ROWS), d.B, 3), dim3(256), 0, s, g);
+            hipLaunchKernelGGL(tcn_dwconv_kernel, dim3(cdiv(d.Tp, DW_ROWS), d.B, branches), dim3(256), 0, s, g);
         }
         {   // GN2 (on load) -> sconv + residual: x[M][F] = xin + GN2(y2)[M][CH] * W2^T
             GemmArgs g{};
@@ -340,7 +342,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gamma = w.g2w + (long)blk * d.CH; g.beta = w.g2b + (long)blk * d.CH; g.gb_bs = (long)w.NB * d.CH;
             g.K = d.CH; g.N = d.F; g.Tp = d.Tp; g.B = d.B;
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s);
+            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s, branches);
         }
         if (blk == 0 && buf.dbg_tcn0)
             (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -352,7 +354,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
         g.bias = w.bf; g.bias_bs = w.N2P;
         g.C = buf.fb; g.c_bs = x_bs; g.ldc = d.FP;
         g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
-        launch_gemm<PRO_RELU, EPI_ACT>(g, d.F, row_tiles, w.num_cus, s);
+        launch_gemm<PRO_RELU, EPI_ACT>(g, d.F, row_tiles, w.num_cus, s, branches);
     }
 }
 

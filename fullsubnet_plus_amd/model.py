@@ -71,10 +71,10 @@ class _TCNBlockParams(nn.Module):
 class _FullBandParams(nn.Module):
     """Parameter holder named like SequenceModel(sequence_model="TCN") (sequence_model.py:47-58,80-81)."""
 
-    def __init__(self, num_freqs, hidden):
+    def __init__(self, num_freqs, hidden, output_size=None):
         super().__init__()
         self.sequence_model = nn.Sequential(*[_TCNBlockParams(num_freqs, hidden) for _ in _TCN_DILATIONS])
-        self.fc_output_layer = nn.Linear(num_freqs, num_freqs)
+        self.fc_output_layer = nn.Linear(num_freqs, num_freqs if output_size is None else output_size)
 
 
 class _SubBandParams(nn.Module):
@@ -369,7 +369,7 @@ class FullSubNet_Plus(_HipModel):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM", "TCN"), f"{self.__class__.__name__} only support GRU, LSTM and TCN."
         if sequence_model not in _lib.SEQUENCE_MODELS:
-            raise NotImplementedError(f"HIP path: sub-band sequence_model {sequence_model} is not built yet (LSTM, GRU)")
+            raise NotImplementedError(f"Not implemented {sequence_model}")                 # sequence_model.py:72
         if channel_attention_model not in _lib.ATTENTION:
             raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
         if subband_num != 1:
@@ -399,8 +399,11 @@ class FullSubNet_Plus(_HipModel):
         self.fb_model = _FullBandParams(num_freqs, 512)
         self.fb_model_real = _FullBandParams(num_freqs, 512)
         self.fb_model_imag = _FullBandParams(num_freqs, 512)
-        self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1),
-                                       sb_model_hidden_size, output_size, sequence_model)
+        sb_in = (sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1)
+        if sequence_model == "TCN":      # sequence_model.py:47-58,80-81: TCNBlocks keep the default 512 hidden channels
+            self.sb_model = _FullBandParams(sb_in, 512, output_size)
+        else:
+            self.sb_model = _SubBandParams(sb_in, sb_model_hidden_size, output_size, sequence_model)
         self.sequence_model = sequence_model
 
         self.subband_num = subband_num

@@ -59,7 +59,12 @@ enum { FSNP_MODEL_FULLSUBNET_PLUS = 0, FSNP_MODEL_FULLSUBNET = 1 };
 /* `sequence_model` kwarg of both reference models (SequenceModel, audio_zen/model/module/sequence_model.py:31-46):
  * the recurrent cell of the sub-band model (and, for FSNP_MODEL_FULLSUBNET, of the full-band model).  GRU runs on the
  * column-split kernels only (csrc/lstm_coop.hip, csrc/lstm_coopn.hip) and has no bf16 variant. */
-enum { FSNP_SEQ_LSTM = 0, FSNP_SEQ_GRU = 1 };
+enum {
+    FSNP_SEQ_LSTM = 0,
+    FSNP_SEQ_GRU = 1,
+    FSNP_SEQ_TCN = 2 /* FullSubNet+ only: the sub-band model is 8 TCNBlocks(34 -> tcn_hidden -> 34) + Linear(34, 2)
+                        (sequence_model.py:47-58,106-112); sb_hidden is ignored */
+};
 
 /* B > 1 semantics */
 enum {

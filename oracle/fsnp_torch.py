@@ -222,7 +222,10 @@ def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighb
         Fo = sb_input.shape[2]
         sb_input = sb_input.permute(0, 2, 1, 3)
     sb_input = sb_input.reshape(B * Fo, nsb + 3 * nfb, T)
-    sb_mask = lstm2_fc(sb_input, p, "sb_model", sb_output_activate_function)
+    if "sb_model.sequence_model.0.conv1x1.weight" in p:      # sequence_model="TCN" (sequence_model.py:47-58,106-112)
+        sb_mask = fb_sequence_model(sb_input, p, "sb_model", sb_output_activate_function).contiguous()
+    else:
+        sb_mask = lstm2_fc(sb_input, p, "sb_model", sb_output_activate_function)
     sb_mask = sb_mask.reshape(B, Fo, output_size, T).permute(0, 2, 1, 3).contiguous()
     return sb_mask[:, :, :, look_ahead:]
 

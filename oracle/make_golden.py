@@ -71,6 +71,11 @@ CASES = [
          inp=("spec", 3, 20, 16), stages=False),
     dict(name="gru_b1_t30_cum_layer", wseed=17, profile="default",
          args={"sequence_model": "GRU", "norm_type": "cumulative_layer_norm"}, inp=("spec", 1, 30, 17), stages=False),
+    # sub-band TCN (sequence_model.py:47-58)
+    dict(name="tcn_b1_t24_default", wseed=18, profile="default", args={"sequence_model": "TCN"},
+         inp=("spec", 1, 24, 18), stages=False),
+    dict(name="tcn_b3_t20_harsh", wseed=19, profile="harsh", args={"sequence_model": "TCN"},
+         inp=("spec", 3, 20, 19), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]

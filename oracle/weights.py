@@ -92,6 +92,23 @@ def make_state_dict(seed=0, profile="default", num_freqs=257, tcn_hidden=512, sb
 
     sb_in = (2 * sb_num_neighbors + 1) + 3 * (2 * fb_num_neighbors + 1)
     H = sb_hidden
+    if sequence_model == "TCN":                        # sequence_model.py:47-58: 8 TCNBlocks(34 -> 512 -> 34) + Linear(34, 2)
+        for i in range(num_tcn_blocks):
+            p = f"sb_model.sequence_model.{i}"
+            conv(p + ".conv1x1", tcn_hidden, sb_in, 1)
+            sd[p + ".prelu1.weight"] = rng.uniform(0.1, 0.4, size=(1,)).astype(np.float32)
+            sd[p + ".norm1.weight"] = _normal(rng, (tcn_hidden,), 0.1, 1.0)
+            sd[p + ".norm1.bias"] = _normal(rng, (tcn_hidden,), 0.1)
+            conv(p + ".depthwise_conv", tcn_hidden, 1, 3)
+            sd[p + ".prelu2.weight"] = rng.uniform(0.1, 0.4, size=(1,)).astype(np.float32)
+            sd[p + ".norm2.weight"] = _normal(rng, (tcn_hidden,), 0.1, 1.0)
+            sd[p + ".norm2.bias"] = _normal(rng, (tcn_hidden,), 0.1)
+            conv(p + ".sconv", sb_in, tcn_hidden, 1)
+        linear("sb_model.fc_output_layer", output_size, sb_in)
+        if as_torch:
+            import torch
+            return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+        return sd
     G = {"LSTM": 4, "GRU": 3}[sequence_model]          # gate blocks of nn.LSTM / nn.GRU (sequence_model.py:31-46)
     for layer, cin in ((0, sb_in), (1, H)):
         p = "sb_model.sequence_model."

@@ -485,3 +485,20 @@ def test_graph_replay_equals_plain_launches():
     changed = m(*ins).cpu().numpy()
     m.debug_set_graph(0)
     assert np.array_equal(m(*ins).cpu().numpy(), changed) and not np.array_equal(changed, plain)
+
+
+# ---------------------------------------------------------------- sub-band TCN (sequence_model.py:47-58)
+def test_subband_tcn_b32_full_vs_oracle():
+    """sequence_model="TCN": 8 TCNBlocks(34 -> 512 -> 34) + Linear(34, 2) over all 8224 sub-band sequences."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": "TCN"}
+    sd = make_state_dict(33, "default", sequence_model="TCN")
+    mag, real, imag = make_inputs(32, 1.0, 301)
+    m = _model(args, sd, "full")
+    out = m(*_cuda((mag, real, imag))).cpu().numpy()
+    pick = [0, 16, 31]
+    want = fsnp_torch.forward_full(sd, mag[pick], real[pick], imag[pick]).numpy()
+    err = rel_err(out[pick], want)
+    _record("subband_tcn_b32_full", rel=err)
+    assert err < TOL, err
+    with pytest.raises(RuntimeError, match="no recurrent kernel"):
+        m.lstm2_fc(torch.zeros(4, 34, 5, device="cuda"))

@@ -80,8 +80,10 @@ def test_error_behaviour_matches_reference():
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "RNN"})
     with pytest.raises(NotImplementedError):      # fullsubnet_plus.py:70
         FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "channel_attention_model": "XYZ"})
-    with pytest.raises(NotImplementedError):      # the sub-band TCN of sequence_model.py:47-58 is not built
-        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "TCN"})
+    m_tcn = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": "TCN"})      # sequence_model.py:47-58
+    sd_tcn = make_state_dict(0, sequence_model="TCN")
+    assert list(m_tcn.state_dict().keys()) == list(sd_tcn.keys())
+    m_tcn.load_state_dict(sd_tcn, strict=True)
 
 
 def test_weight_init_true_reinitialises():
