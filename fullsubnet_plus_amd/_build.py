@@ -31,14 +31,15 @@ def build(force=False, verbose=False):
     the refill-in-place weight pipeline and makes hipcc drain vmcnt(0) + copy 48 registers every k-group)."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"]
+    tmp = f"{LIB_PATH}.tmp{os.getpid()}"       # several ranks may find the library stale at once: build aside, rename atomically
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", tmp]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
     if verbose and res.stderr:
         print(res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

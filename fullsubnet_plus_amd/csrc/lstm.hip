@@ -581,11 +581,13 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
         hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
         return;
     }
-    static bool attr_set = false;
     auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW, BF>;
-    if (!attr_set) {
+    static bool attr_set[64] = {};             // the attribute is per device: one process may drive several GPUs
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
 }

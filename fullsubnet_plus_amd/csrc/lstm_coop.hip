@@ -433,10 +433,12 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     constexpr int S = HID / UNITS, NT = UNITS / 8;
     const size_t smem = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ, GRU>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};             // the attribute is per device: one process may drive several GPUs
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
