@@ -46,6 +46,9 @@ def parse():
                     help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
     ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
                     help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
+    ap.add_argument("--dist-backend", default="nccl", help='"nccl" (= RCCL; the real launch) or "gloo" (plumbing tests)')
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses GPU 0 (checks the N>1 plumbing on a 1-GPU box with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -98,13 +101,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.dist_backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fullsubnet_plus_amd import FullSubNet, FullSubNet_Plus
@@ -181,6 +189,13 @@ def main():
     lstm_ms = timing["lstm_ms"] / max(timing["count"], 1)
     achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms > 0 else 0.0
 
+    tiles = -(-rows // 32)      # which sub-band LSTM kernel fsnp_abi.hip:sb_kernel() picks for this many 32-row tiles
+    if args.precision != "fp32" or tiles > 170:
+        lstm_kernel_name = "lstm2_fc_kernel<384,40,2> (one 32-row tile per CU)"
+    elif tiles > 42:
+        lstm_kernel_name = "lstm2_coopn_kernel<384,40> (3 workgroups x 128 units per row-tile group)"
+    else:
+        lstm_kernel_name = "lstm2_coop_kernel<384,40> (K-split, 8-64 units per workgroup)"
     traffic = None   # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes
     pmc_path = os.path.join(ROOT, "profiles", "lstm_pmc.json")
     if os.path.exists(pmc_path) and B == 32 and abs(args.seconds - 2.0) < 1e-9 and args.mode == "full":
@@ -196,7 +211,7 @@ def main():
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
                                f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)",
                    "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)"},
-        "roofline": {"bound": "mfma", "kernel": "lstm2_fc_kernel<384,40,2>", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
