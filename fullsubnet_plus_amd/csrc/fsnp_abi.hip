@@ -93,7 +93,8 @@ struct fsnp_handle {
     int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
     int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
-    unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in the cooperative LSTM kernel
+    unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
+                                 // so the NEXT call on the handle can fail loudly without a device synchronisation
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
     int use_graph = 1;           // 0 = plain launches (FSNP_GRAPH=0)
@@ -493,11 +494,12 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_err), 256) != hipSuccess || hipMemset(h->d_err, 0, 256) != hipSuccess) {
-        set_error("hipMalloc of the error word failed");
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->d_err), 256, hipHostMallocMapped) != hipSuccess) {
+        set_error("hipHostMalloc of the error word failed");
         delete h;
         return 4;
     }
+    memset(h->d_err, 0, 256);
     const char* gp = getenv("FSNP_GRAPH");
     if (gp && gp[0] == '0') h->use_graph = 0;
     const char* nw = getenv("FSNP_LSTM_WAVES");
@@ -516,7 +518,7 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); }
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_weights) (void)hipFree(h->d_weights);
-    if (h->d_err) (void)hipFree(h->d_err);
+    if (h->d_err) (void)hipHostFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
     delete h;
@@ -813,6 +815,12 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
     if (!fsn && !is_complex && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
     if (!h->committed) { set_error("fsnp_forward: weights not committed (call fsnp_commit_weights)"); return 2; }
+    if (*reinterpret_cast<volatile unsigned*>(h->d_err) != 0) {     // set by an earlier launch that has finished since
+        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
+        set_error("an earlier forward on this handle failed: an inter-workgroup wait timed out in a column-split LSTM kernel "
+                  "(its workgroups were not co-resident - is the GPU shared?); that result was invalid - set FSNP_LSTM_COOP=0");
+        return 5;
+    }
     if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
     if (mode == FSNP_MODE_PARITY && h->cfg.num_groups_in_drop_band != 2) { set_error("PARITY mode needs num_groups_in_drop_band == 2"); return 2; }
@@ -1091,14 +1099,19 @@ int fsnp_check_errors(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     FSNP_HIP_CHECK(hipDeviceSynchronize());
-    unsigned e = 0;
-    FSNP_HIP_CHECK(hipMemcpy(&e, h->d_err, 4, hipMemcpyDeviceToHost));
+    const unsigned e = *reinterpret_cast<volatile unsigned*>(h->d_err);
     if (e != 0) {
-        (void)hipMemset(h->d_err, 0, 4);
+        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
         set_error("cooperative LSTM kernel: an inter-workgroup wait timed out (a workgroup was not resident); the "
                   "results of that forward are invalid - set FSNP_LSTM_COOP=0");
         return 5;
     }
+    return 0;
+}
+
+int fsnp_debug_inject_error(fsnp_handle* h) {
+    if (!h) { set_error("null handle"); return 1; }
+    *reinterpret_cast<volatile unsigned*>(h->d_err) = 1u;
     return 0;
 }
 

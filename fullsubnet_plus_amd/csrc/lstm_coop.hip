@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
             while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {                         // seconds: a peer is not resident - give up loudly
-                    __hip_atomic_store(a.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word
                     break;
                 }
             }

@@ -328,6 +328,10 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(dev)
         _lib.check(lib.fsnp_set_precision(self._handle, int(mode == "bf16_ih")), "fsnp_set_precision")
 
+    def debug_inject_error(self):
+        """Test hook: pretend an inter-workgroup wait timed out (see fsnp_debug_inject_error)."""
+        _lib.check(_lib.load().fsnp_debug_inject_error(self._handle), "fsnp_debug_inject_error")
+
     def check_errors(self):
         """Synchronise and raise if an earlier call failed on the device (see fsnp_check_errors)."""
         _lib.check(_lib.load().fsnp_check_errors(self._handle), "fsnp_check_errors")

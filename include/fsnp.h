@@ -185,7 +185,9 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
 
 /* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
- * inter-workgroup wait in the cooperative small-batch LSTM kernel).  0 = none. */
+ * inter-workgroup wait in a column-split LSTM kernel, whose workgroups must all be co-resident).  0 = none.
+ * The error word is host-mapped: without calling this, the NEXT fsnp_forward on the handle fails instead (once) as soon
+ * as the failed launch has completed - a wrong result is never silent for long. */
 int fsnp_check_errors(fsnp_handle* h);
 
 /* Tuning hook: 1 (default) = use the column-split cooperative LSTM kernel (csrc/lstm_coop.hip) whenever
@@ -196,6 +198,9 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
  * the sub-band LSTM of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph and replayed on
  * the caller's stream; 0 = plain launches. */
 int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode);
+/* Test hook: sets the device error word as a timed-out inter-workgroup wait would (the next fsnp_forward /
+ * fsnp_check_errors on the handle must then fail, once). */
+int fsnp_debug_inject_error(fsnp_handle* h);
 
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
  * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the

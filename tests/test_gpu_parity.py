@@ -502,3 +502,20 @@ def test_subband_tcn_b32_full_vs_oracle():
     assert err < TOL, err
     with pytest.raises(RuntimeError, match="no recurrent kernel"):
         m.lstm2_fc(torch.zeros(4, 34, 5, device="cuda"))
+
+
+def test_device_side_failure_is_reported_by_the_next_call():
+    """A timed-out inter-workgroup wait sets a host-mapped error word: the next forward (or check_errors) raises once,
+    then the handle works again."""
+    g = Golden("b1_t8_min")
+    m = _model(g.args, g.state_dict())
+    ins = _cuda(g.inputs())
+    ok = m(*ins).cpu().numpy()
+    m.debug_inject_error()
+    with pytest.raises(RuntimeError, match="timed out"):
+        m(*ins)
+    assert np.array_equal(m(*ins).cpu().numpy(), ok)
+    m.debug_inject_error()
+    with pytest.raises(RuntimeError, match="timed out"):
+        m.check_errors()
+    m.check_errors()
