@@ -37,6 +37,9 @@ SYMBOLS = {
     "fsnp_forward": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64 * 3 * 3), c_vp, c_i32, c_i32, c_i32,
                              c_i32, c_i32, c_vp]),
     "fsnp_forward_complex": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "fsnp_stft": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
+    "fsnp_istft": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "fsnp_enhance_wave": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "fsnp_apply_cirm": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, ctypes.POINTER(c_i64 * 3), c_i32, c_i32,
                                 c_i32, c_vp]),
     "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

@@ -98,8 +98,17 @@ struct TcnBuffers {
 };
 
 void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s, int branches = 3);
+// C[utt][t][0..N) = act(A[utt][t][0..K) * W^T + bias), W [N pad 384][ldw] zero padded.  a_utt_stride / a_cols: optional
+// utterance stride of A and readable floats per row when rows overlap (lda < K: the STFT's hop-strided frames).
 void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,
-                       int N, int B, int Tp, int act, int num_cus, hipStream_t s);
+                       int N, int B, int Tp, int act, int num_cus, hipStream_t s, long a_utt_stride = 0, int a_cols = 0);
+// stft.hip : SURVEY.md 8(f-3) second half - torch.stft / torch.istft of audio_zen/acoustics/feature.py:10-56 as
+// reflect-pad + DFT GEMM and inverse-DFT GEMM + windowed overlap-add (n_fft = win_length, hop = n_fft / 2, hann)
+void launch_stft_pad(const float* wav, long wav_stride, float* xp, long xp_stride, int B, int L, int n_fft, hipStream_t s);
+void launch_istft_ola(const float* frames, const float* window, float* wav, long wav_stride, int B, int T, int L, int n_fft,
+                      hipStream_t s);
+void stft_build_matrices(int n_fft, float* fwd /*[N2 pad 384][n_fft]*/, float* inv /*[n_fft pad 384][K pad 16]*/,
+                         float* window /*[n_fft]*/);
 
 // ---------------------------------------------------------------------------------------------
 // subband.hip : statistics of the (never materialised) sub-band input tensor

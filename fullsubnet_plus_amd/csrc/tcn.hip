@@ -24,6 +24,8 @@ enum { EPI_PRELU_STATS = 0, EPI_RESIDUAL = 1, EPI_ACT = 2 };
 
 struct GemmArgs {
     const float* A; long a_bs; int lda;        // A[branch][utt][t][lda]
+    long a_us; int a_cols;                     // optional: utterance stride (0 = Tp * lda) and readable floats per row
+                                               // (0 = lda); the STFT reads OVERLAPPING frames: lda = hop < K = n_fft
     const float* W; long w_bs; int ldw;        // W[branch][Npad][ldw], zero padded
     const float* bias; long bias_bs;           // [branch][Npad]
     float* C; long c_bs; int ldc;              // C[branch][utt][t][ldc]
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     const int t0 = (blockIdx.y % tiles_per_utt) * BM;
     const int n0 = blockIdx.x * BN;
 
-    const float* __restrict__ A = g.A + branch * g.a_bs + ((long)utt * g.Tp) * g.lda;
+    const float* __restrict__ A = g.A + branch * g.a_bs + (g.a_us ? (long)utt * g.a_us : ((long)utt * g.Tp) * g.lda);
+    const int a_cols = g.a_cols ? g.a_cols : g.lda;
     const float* __restrict__ W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
 
     float mean = 0.f, rstd = 1.f;
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < g.Tp && k < g.K) {
                 const float* p = A + (long)t * g.lda + k;
-                if (k + 4 <= g.lda) v = *reinterpret_cast<const float4*>(p);
-                else { v.x = p[0]; if (k + 1 < g.lda) v.y = p[1]; if (k + 2 < g.lda) v.z = p[2]; }
+                if (k + 4 <= a_cols) v = *reinterpret_cast<const float4*>(p);
+                else { v.x = p[0]; if (k + 1 < a_cols) v.y = p[1]; if (k + 2 < a_cols) v.z = p[2]; }
                 if constexpr (PRO == PRO_GN) {
                     const float4 ga = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
                     const float4 be = *reinterpret_cast<const float4*>(beta + k);
@@ -361,9 +364,10 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
 // C[utt][t][0..N) = act(A[utt][t][0..K) * W^T + bias): the Linear(512, 257) + ReLU after the full-band LSTM of the
 // original FullSubNet (SequenceModel.forward, sequence_model.py:119-122).  W is [N pad 384][ldw], zero padded.
 void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,
-                       int N, int B, int Tp, int act, int num_cus, hipStream_t s) {
+                       int N, int B, int Tp, int act, int num_cus, hipStream_t s, long a_utt_stride, int a_cols) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.a_us = a_utt_stride; g.a_cols = a_cols;
     g.K = K; g.N = N; g.Tp = Tp; g.B = B; g.act = act;
     launch_gemm<PRO_NONE, EPI_ACT>(g, N, cdiv(Tp, BM) * B, num_cus, s, 1);
 }

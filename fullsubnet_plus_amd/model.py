@@ -253,6 +253,56 @@ class _HipModel(nn.Module):
             self.batch_mode = mode
         return self._apply_cirm(mask, noisy_complex)
 
+    # ------------------------------------------------------------------ STFT / iSTFT in HIP
+    def _wave_args(self, wav):
+        assert wav.dim() == 2, "expected [B, samples]"
+        if not wav.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; there is deliberately no CPU fallback.")
+        wav = wav.float()
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        return wav, self._ensure_handle(wav.device), torch.cuda.current_stream(wav.device).cuda_stream
+
+    def stft(self, wav):
+        """audio_zen/acoustics/feature.py:10-31 (torch.stft, n_fft = 2 (F - 1), hop = n_fft / 2, hann, center) in HIP:
+        wav [B, samples] -> complex64 [B, F, T] with torch.stft's strides."""
+        wav, lib, stream = self._wave_args(wav)
+        B, L = wav.shape
+        T = 1 + L // (self.num_freqs - 1)
+        spec = torch.empty((B, T, self.num_freqs), dtype=torch.complex64, device=wav.device)
+        with torch.cuda.device(wav.device):
+            _lib.check(lib.fsnp_stft(self._handle, wav.data_ptr(), wav.stride(0), torch.view_as_real(spec).data_ptr(), B, L,
+                                     ctypes.c_void_p(stream)), "fsnp_stft")
+        return spec.permute(0, 2, 1)
+
+    def istft(self, spec, length):
+        """feature.py:34-56 (torch.istft(..., length=length)) in HIP: complex64 [B, F, T] (any strides) -> [B, length]."""
+        assert spec.dim() == 3 and spec.dtype == torch.complex64 and spec.shape[1] == self.num_freqs
+        if not spec.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; there is deliberately no CPU fallback.")
+        lib = self._ensure_handle(spec.device)
+        B, _, T = spec.shape
+        out = torch.empty((B, int(length)), dtype=torch.float32, device=spec.device)
+        st = (ctypes.c_int64 * 3)(*spec.stride())
+        stream = torch.cuda.current_stream(spec.device).cuda_stream
+        with torch.cuda.device(spec.device):
+            _lib.check(lib.fsnp_istft(self._handle, torch.view_as_real(spec).data_ptr(), ctypes.byref(st), out.data_ptr(),
+                                      out.stride(0), B, T, int(length), ctypes.c_void_p(stream)), "fsnp_istft")
+        return out
+
+    def enhance_wave(self, noisy):
+        """The reference inferencer's inner loop in ONE call (fullsubnet_plus/inferencer/inferencer.py:142-158,
+        `mag_complex_full_band_crm_mask`; `full_band_crm_mask` of fullsubnet/inferencer/inferencer.py for the original
+        FullSubNet): noisy waveform [B, samples] -> enhanced waveform [B, samples]; STFT, model (all bins), cIRM
+        decompression, complex multiply and iSTFT all run in HIP on the caller's stream."""
+        wav, lib, stream = self._wave_args(noisy)
+        B, L = wav.shape
+        out = torch.empty((B, L), dtype=torch.float32, device=wav.device)
+        with torch.cuda.device(wav.device):
+            _lib.check(lib.fsnp_enhance_wave(self._handle, wav.data_ptr(), wav.stride(0), out.data_ptr(), out.stride(0), B, L,
+                                             ctypes.c_void_p(stream)), "fsnp_enhance_wave")
+        return out
+
     def _apply_cirm(self, mask, noisy_complex):
         B, F, T = noisy_complex.shape
         out = torch.empty_strided((B, F, T), noisy_complex.stride(), dtype=torch.complex64, device=noisy_complex.device)

@@ -137,6 +137,22 @@ int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const floa
 int fsnp_forward_complex(fsnp_handle* h, const float* noisy, const int64_t strides[3], float* out, int32_t batch,
                          int32_t frames, int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream);
 
+/* SURVEY.md 8(f-3), second half: the transforms around the model, so that the reference inferencer's inner loop
+ * (`mag_complex_full_band_crm_mask`, speech_enhance/fullsubnet_plus/inferencer/inferencer.py:142-158) is one call.
+ * n_fft = win_length = 2 (num_freqs - 1), hop_length = n_fft / 2, periodic hann window (config/inference.toml:1-5).
+ *   fsnp_stft   replaces audio_zen/acoustics/feature.py:10-31 (torch.stft, center / reflect, onesided):
+ *               wav DEVICE fp32 [B][samples] (row stride wav_stride) -> spec DEVICE complex64 in torch.stft's memory
+ *               order [B][T][num_freqs] (i.e. the [B,F,T] tensor with strides (T F, 1, F)), T = 1 + samples / hop.
+ *   fsnp_istft  replaces feature.py:34-56 (torch.istft(..., length=samples)): spec element (b,f,t) at
+ *               spec + 2 (b strides[0] + f strides[1] + t strides[2]) -> wav [B][samples].
+ *   fsnp_enhance_wave = stft -> fsnp_forward_complex (all bins) -> fsnp_apply_cirm -> istft, noisy waveform in,
+ *               enhanced waveform out (DEVICE fp32, row strides in floats). */
+int fsnp_stft(fsnp_handle* h, const float* wav, int64_t wav_stride, float* spec, int32_t batch, int32_t samples, void* hip_stream);
+int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], float* wav, int64_t wav_stride, int32_t batch,
+               int32_t frames, int32_t samples, void* hip_stream);
+int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, float* out, int64_t out_stride, int32_t batch,
+                      int32_t samples, void* hip_stream);
+
 /* the step right after the model in the reference inferencer
  * (`decompress_cIRM` speech_enhance/audio_zen/acoustics/mask.py:60-63 + complex multiply
  * speech_enhance/fullsubnet_plus/inferencer/inferencer.py:152-157) as one kernel.

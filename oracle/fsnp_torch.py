@@ -272,3 +272,25 @@ def forward_fullsubnet(p, noisy_mag, *, look_ahead=2, sb_num_neighbors=15, fb_nu
 
 def forward_fullsubnet_full(p, mag, **kw):
     return forward_fullsubnet(p, mag, apply_drop_band=False, **kw)
+
+
+def stft(y, n_fft=512, hop_length=256, win_length=512):
+    """audio_zen/acoustics/feature.py:10-31"""
+    return torch.stft(y, n_fft, hop_length, win_length, window=torch.hann_window(n_fft), return_complex=True)
+
+
+def istft(spec, length, n_fft=512, hop_length=256, win_length=512):
+    """audio_zen/acoustics/feature.py:34-56 (complex input)"""
+    return torch.istft(spec, n_fft, hop_length, win_length, window=torch.hann_window(n_fft), length=length)
+
+
+@torch.no_grad()
+def enhance_wave(p, noisy, fullsubnet=False, **kw):
+    """fullsubnet_plus/inferencer/inferencer.py:142-158 (`mag_complex_full_band_crm_mask`), per utterance (the
+    reference inferencer runs batch 1: no drop_band); fullsubnet=True: `full_band_crm_mask` with the magnitude only."""
+    X = stft(noisy)
+    if fullsubnet:
+        mask = forward_fullsubnet_full(p, X.abs().unsqueeze(1), **kw)
+    else:
+        mask = forward_full(p, X.abs().unsqueeze(1), X.real.unsqueeze(1), X.imag.unsqueeze(1), **kw)
+    return istft(apply_cirm(mask, X), noisy.shape[-1])

@@ -124,3 +124,15 @@ def test_fullsubnet_rejects_oversized_batch():
     x = torch.rand(513, 1, 257, 9, device="cuda")
     with pytest.raises(RuntimeError, match="split the batch"):
         m(x)
+
+
+def test_fullsubnet_enhance_wave_vs_oracle():
+    from oracle.weights import make_wave
+    sd = make_state_dict_fullsubnet(13, "harsh")
+    m = _model(dict(FULLSUBNET_MODEL_ARGS), sd)
+    wav = torch.from_numpy(make_wave(2, 1.0, 501))
+    got = m.enhance_wave(wav.cuda()).cpu()
+    want = fsnp_torch.enhance_wave(sd, wav, fullsubnet=True)
+    err = float((got - want).abs().max() / want.abs().max())
+    _record("fullsubnet_enhance_wave", rel=err)
+    assert err < TOL, err

@@ -519,3 +519,45 @@ def test_device_side_failure_is_reported_by_the_next_call():
     with pytest.raises(RuntimeError, match="timed out"):
         m.check_errors()
     m.check_errors()
+
+
+# ---------------------------------------------------------------- STFT / iSTFT / waveform -> waveform
+@pytest.mark.parametrize("B,L", [(1, 32000), (3, 16000), (2, 12345), (1, 300)])
+def test_stft_istft_vs_torch(B, L):
+    """fsnp_stft / fsnp_istft (DFT as an fp32 MFMA GEMM) vs torch.stft / torch.istft on the CPU, the calls of
+    audio_zen/acoustics/feature.py:10-56; plus the size-independent round trip istft(stft(x)) == x."""
+    from oracle.weights import make_wave
+    m = _model(DEFAULT_MODEL_ARGS, make_state_dict(0))
+    wav = torch.from_numpy(make_wave(B, L / 16000.0, 400 + L))
+    assert wav.shape == (B, L)
+    want = fsnp_torch.stft(wav)
+    got = m.stft(wav.cuda())
+    assert got.shape == want.shape and got.stride() == want.stride()
+    e_stft = float((got.cpu() - want).abs().max() / want.abs().max())
+    back = m.istft(got, L).cpu()
+    e_rt = float((back - wav).abs().max() / wav.abs().max())
+    rng = torch.Generator().manual_seed(L)
+    spec = torch.complex(torch.randn(B, 257, want.shape[-1], generator=rng), torch.randn(B, 257, want.shape[-1], generator=rng))
+    w_i = fsnp_torch.istft(spec, L)
+    g_i = m.istft(spec.cuda(), L).cpu()
+    e_istft = float((g_i - w_i).abs().max() / w_i.abs().max())
+    _record(f"stft_B{B}_L{L}", stft=e_stft, round_trip=e_rt, istft=e_istft)
+    assert e_stft < 1e-5 and e_rt < 1e-5 and e_istft < 1e-5
+    with pytest.raises(RuntimeError, match="reflect padding"):
+        m.stft(torch.zeros(1, 200, device="cuda"))
+
+
+def test_enhance_wave_vs_oracle():
+    """fsnp_enhance_wave == inferencer.py:142-158 (stft -> model -> cIRM -> istft) run with torch on the CPU."""
+    from oracle.weights import make_wave
+    sd = make_state_dict(41, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd, "parity")
+    wav = torch.from_numpy(make_wave(3, 1.0, 500))
+    got = m.enhance_wave(wav.cuda()).cpu()
+    want = fsnp_torch.enhance_wave(sd, wav)
+    err = float((got - want).abs().max() / want.abs().max())
+    _record("enhance_wave", rel=err)
+    assert got.shape == wav.shape and err < TOL, err
+    # the two-step form (HIP stft -> enhance() -> HIP istft) is the same computation
+    two = m.istft(m.enhance(m.stft(wav.cuda())), wav.shape[-1]).cpu()
+    assert float((two - got).abs().max() / want.abs().max()) < 1e-5
