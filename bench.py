@@ -46,6 +46,9 @@ def parse():
                     help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
     ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
                     help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
+    ap.add_argument("--wave", action="store_true",
+                    help="time waveform -> waveform (HIP STFT + forward + cIRM + iSTFT, model.enhance_wave) instead of the "
+                         "headline forward; extra information, not BASELINE.json's metric")
     ap.add_argument("--dist-backend", default="nccl", help='"nccl" (= RCCL; the real launch) or "gloo" (plumbing tests)')
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (checks the N>1 plumbing on a 1-GPU box with --dist-backend gloo)")
@@ -148,20 +151,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if args.wave:
+        from oracle.weights import make_wave
+        wav = torch.from_numpy(make_wave(B, args.seconds, 1000 + rank)).to(dev)
+
+    def run_once():
+        return model.enhance_wave(wav) if args.wave else model(*gpu_in)
+
     with torch.no_grad():
-        out = model(*[t[:1] for t in gpu_in])                    # creates the handle
+        out = model.enhance_wave(wav[:1]) if args.wave else model(*[t[:1] for t in gpu_in])   # creates the handle
         model.set_precision(args.precision)
         out = None
         for _ in range(args.warmup):
-            out = model(*gpu_in)
+            out = run_once()
         if out is None:
-            out = model(*gpu_in)
+            out = run_once()
         sync_all()
         model.set_timing(True)
         model.get_timing(reset=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = model(*gpu_in)
+            out = run_once()
         sync_all()
         elapsed = time.perf_counter() - t0
         timing = model.get_timing(reset=True)
@@ -203,7 +213,8 @@ def main():
             traffic = json.load(f).get("traffic_bytes_per_launch")
 
     result = {
-        "metric": "STFT frames/sec (257-bin, 2 s clips), " + ("FullSubNet forward" if fsn else "FullSubNet+ forward"),
+        "metric": "STFT frames/sec (257-bin, 2 s clips), " + ("FullSubNet" if fsn else "FullSubNet+") +
+                  (" waveform -> waveform (HIP STFT + forward + cIRM + iSTFT)" if args.wave else " forward"),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 + bf16 ih-GEMM (configs[4])",
@@ -222,7 +233,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref0 = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
         result["cpu_baseline"] = base
-        if args.mode == "full":
+        if args.mode == "full" and not args.wave:
             got = out[:1].cpu()
             result["cirm_max_abs_err"] = float((got - ref0).abs().max())
             result["cirm_rel_err"] = float((got - ref0).abs().max() / ref0.abs().max())
