@@ -600,43 +600,62 @@ int fsnp_commit_weights(fsnp_handle* h) {
         o_fc1b[a] = put(p + ".fc1.bias");
         o_fc2b[a] = put(p + ".fc2.bias");
     }
-    // ---- TCN: zero-padded row-major [N pad 64][K pad 16] GEMM operands, [branch][block] major
-    const int N1P = (int)align_up(CH, 384), K1P = (int)align_up(F, 16), N2P = (int)align_up(F, 384), K2P = (int)align_up(CH, 16);
-    const size_t o_w1 = alloc((size_t)3 * NB * N1P * K1P), o_b1 = alloc((size_t)3 * NB * N1P), o_a1 = alloc(3 * NB + 1);
-    const size_t o_g1w = alloc((size_t)3 * NB * CH), o_g1b = alloc((size_t)3 * NB * CH);
-    const size_t o_dw = alloc((size_t)3 * NB * 3 * CH), o_db = alloc((size_t)3 * NB * CH), o_a2 = alloc(3 * NB + 1);
-    const size_t o_g2w = alloc((size_t)3 * NB * CH), o_g2b = alloc((size_t)3 * NB * CH);
-    const size_t o_w2 = alloc((size_t)3 * NB * N2P * K2P), o_b2 = alloc((size_t)3 * NB * N2P);
-    const size_t o_wf = alloc((size_t)3 * N2P * K1P), o_bf = alloc((size_t)3 * N2P);
-    for (int b = 0; b < nbr_w; ++b) {
-        for (int i = 0; i < NB; ++i) {
-            const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
-            const size_t bi = (size_t)b * NB + i;
-            const auto& w1 = W(p + ".conv1x1.weight");
-            for (int n = 0; n < CH; ++n)
-                for (int k = 0; k < F; ++k) blob[o_w1 + (bi * N1P + n) * K1P + k] = w1[(size_t)n * F + k];
-            std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + o_b1 + bi * N1P);
-            blob[o_a1 + bi] = W(p + ".prelu1.weight")[0];
-            std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + o_g1w + bi * CH);
-            std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + o_g1b + bi * CH);
-            const auto& dw = W(p + ".depthwise_conv.weight");   // [CH][1][3]
-            for (int c = 0; c < CH; ++c)
-                for (int j = 0; j < 3; ++j) blob[o_dw + (bi * 3 + j) * CH + c] = dw[(size_t)c * 3 + j];
-            std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + o_db + bi * CH);
-            blob[o_a2 + bi] = W(p + ".prelu2.weight")[0];
-            std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + o_g2w + bi * CH);
-            std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + o_g2b + bi * CH);
-            const auto& w2 = W(p + ".sconv.weight");             // [F][CH][1]
-            for (int n = 0; n < F; ++n)
-                for (int k = 0; k < CH; ++k) blob[o_w2 + (bi * N2P + n) * K2P + k] = w2[(size_t)n * CH + k];
-            std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + o_b2 + bi * N2P);
+    // ---- TCN stacks (SequenceModel(sequence_model="TCN"), sequence_model.py:47-58,80-81): zero-padded row-major
+    // [N pad 384][K pad 16] GEMM operands, [model][block] major.  `cin` channels in / out of every TCNBlock, `fc_out` rows of
+    // the final Linear(cin, fc_out).  Used for the three full-band models and for a sub-band TCN.
+    struct TcnOff { size_t w1, b1, a1, g1w, g1b, dw, db, a2, g2w, g2b, w2, b2, wf, bf; int NB, N1P, K1P, N2P, K2P; };
+    auto pack_tcn = [&](const std::vector<std::string>& models, int nb, int cin, int fc_out) {
+        TcnOff t{};
+        const size_t nm = models.size() ? models.size() : 1;
+        t.NB = nb; t.N1P = (int)align_up(CH, 384); t.K1P = (int)align_up(cin, 16); t.N2P = (int)align_up(cin, 384); t.K2P = (int)align_up(CH, 16);
+        t.w1 = alloc(nm * nb * t.N1P * t.K1P); t.b1 = alloc(nm * nb * t.N1P); t.a1 = alloc(nm * nb + 1);
+        t.g1w = alloc(nm * nb * CH); t.g1b = alloc(nm * nb * CH);
+        t.dw = alloc(nm * nb * 3 * CH); t.db = alloc(nm * nb * CH); t.a2 = alloc(nm * nb + 1);
+        t.g2w = alloc(nm * nb * CH); t.g2b = alloc(nm * nb * CH);
+        t.w2 = alloc(nm * nb * t.N2P * t.K2P); t.b2 = alloc(nm * nb * t.N2P);
+        t.wf = alloc(nm * t.N2P * t.K1P); t.bf = alloc(nm * t.N2P);
+        for (size_t b = 0; b < models.size(); ++b) {
+            for (int i = 0; i < nb; ++i) {
+                const std::string p = models[b] + ".sequence_model." + std::to_string(i);
+                const size_t bi = b * nb + i;
+                const auto& w1 = W(p + ".conv1x1.weight");           // [CH][cin][1]
+                for (int n = 0; n < CH; ++n)
+                    for (int k = 0; k < cin; ++k) blob[t.w1 + (bi * t.N1P + n) * t.K1P + k] = w1[(size_t)n * cin + k];
+                std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + t.b1 + bi * t.N1P);
+                blob[t.a1 + bi] = W(p + ".prelu1.weight")[0];
+                std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + t.g1w + bi * CH);
+                std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + t.g1b + bi * CH);
+                const auto& dw = W(p + ".depthwise_conv.weight");     // [CH][1][3] -> tap major
+                for (int c = 0; c < CH; ++c)
+                    for (int jj = 0; jj < 3; ++jj) blob[t.dw + (bi * 3 + jj) * CH + c] = dw[(size_t)c * 3 + jj];
+                std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + t.db + bi * CH);
+                blob[t.a2 + bi] = W(p + ".prelu2.weight")[0];
+                std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + t.g2w + bi * CH);
+                std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + t.g2b + bi * CH);
+                const auto& w2 = W(p + ".sconv.weight");              // [cin][CH][1]
+                for (int n = 0; n < cin; ++n)
+                    for (int k = 0; k < CH; ++k) blob[t.w2 + (bi * t.N2P + n) * t.K2P + k] = w2[(size_t)n * CH + k];
+                std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + t.b2 + bi * t.N2P);
+            }
+            const auto& wf = W(models[b] + ".fc_output_layer.weight");   // [fc_out][cin]: top rows of a zero-padded [N2P][K1P]
+            for (int n = 0; n < fc_out; ++n)
+                for (int k = 0; k < cin; ++k) blob[t.wf + (b * t.N2P + n) * t.K1P + k] = wf[(size_t)n * cin + k];
+            const auto& bf = W(models[b] + ".fc_output_layer.bias");
+            std::copy(bf.begin(), bf.end(), blob.begin() + t.bf + b * t.N2P);
         }
-        const auto& wf = W(std::string(kFb[b]) + ".fc_output_layer.weight");
-        for (int n = 0; n < F; ++n)
-            for (int k = 0; k < F; ++k) blob[o_wf + ((size_t)b * N2P + n) * K1P + k] = wf[(size_t)n * F + k];
-        const auto& bf = W(std::string(kFb[b]) + ".fc_output_layer.bias");
-        std::copy(bf.begin(), bf.end(), blob.begin() + o_bf + (size_t)b * N2P);
-    }
+        return t;
+    };
+    auto bind_tcn = [&](TcnWeights& t, const TcnOff& o, const float* d) {
+        t.w1 = d + o.w1; t.b1 = d + o.b1; t.a1 = d + o.a1; t.g1w = d + o.g1w; t.g1b = d + o.g1b;
+        t.dw = d + o.dw; t.db = d + o.db; t.a2 = d + o.a2; t.g2w = d + o.g2w; t.g2b = d + o.g2b;
+        t.w2 = d + o.w2; t.b2 = d + o.b2; t.wf = d + o.wf; t.bf = d + o.bf;
+        t.num_cus = h->num_cus; t.NB = o.NB; t.N1P = o.N1P; t.K1P = o.K1P; t.N2P = o.N2P; t.K2P = o.K2P;
+        for (int i = 0; i < o.NB; ++i) t.dilation[i] = kDilations[i];
+    };
+    std::vector<std::string> fb_models;
+    for (int b = 0; b < nbr_w; ++b) fb_models.push_back(kFb[b]);
+    const TcnOff fb_off = pack_tcn(fb_models, NB, F, F);
+    const TcnOff sb_off = h->sb_tcn ? pack_tcn({"sb_model"}, 8, h->NIN, h->cfg.output_size) : TcnOff{};
     // ---- recurrent models: MFMA B-fragment order + summed biases.  Every kernel sees FOUR column slots per hidden unit:
     // LSTM i, f, g, o (the reference's gate order); GRU r, z, n_x, n_h with W_in only in the input rows of K and W_hn only
     // in the hidden rows (zero blocks elsewhere), biases b_ir + b_hr, b_iz + b_hz, b_in, b_hn.
@@ -696,45 +715,6 @@ int fsnp_commit_weights(fsnp_handle* h) {
     if (!h->sb_tcn)
         lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                 blob.data() + o_wpack_coopn);
-    // ---- sub-band TCN (sequence_model="TCN"): the full-band GEMM operand layouts, ONE branch, NIN input channels
-    const int sK1P = (int)align_up(h->NIN, 16), sN2P = (int)align_up(h->NIN, 384);
-    size_t so_w1 = 0, so_b1 = 0, so_a1 = 0, so_g1w = 0, so_g1b = 0, so_dw = 0, so_db = 0, so_a2 = 0, so_g2w = 0, so_g2b = 0,
-           so_w2 = 0, so_b2 = 0, so_wf = 0, so_bf = 0;
-    if (h->sb_tcn) {
-        const int SNB = 8, NINs = h->NIN;
-        so_w1 = alloc((size_t)SNB * N1P * sK1P); so_b1 = alloc((size_t)SNB * N1P); so_a1 = alloc(SNB + 1);
-        so_g1w = alloc((size_t)SNB * CH); so_g1b = alloc((size_t)SNB * CH);
-        so_dw = alloc((size_t)SNB * 3 * CH); so_db = alloc((size_t)SNB * CH); so_a2 = alloc(SNB + 1);
-        so_g2w = alloc((size_t)SNB * CH); so_g2b = alloc((size_t)SNB * CH);
-        so_w2 = alloc((size_t)SNB * sN2P * K2P); so_b2 = alloc((size_t)SNB * sN2P);
-        so_wf = alloc((size_t)sN2P * sK1P); so_bf = alloc(sN2P);
-        for (int i = 0; i < SNB; ++i) {
-            const std::string p = "sb_model.sequence_model." + std::to_string(i);
-            const auto& w1 = W(p + ".conv1x1.weight");          // [CH][NIN][1]
-            for (int n = 0; n < CH; ++n)
-                for (int k = 0; k < NINs; ++k) blob[so_w1 + ((size_t)i * N1P + n) * sK1P + k] = w1[(size_t)n * NINs + k];
-            std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + so_b1 + (size_t)i * N1P);
-            blob[so_a1 + i] = W(p + ".prelu1.weight")[0];
-            std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + so_g1w + (size_t)i * CH);
-            std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + so_g1b + (size_t)i * CH);
-            const auto& dw = W(p + ".depthwise_conv.weight");
-            for (int c = 0; c < CH; ++c)
-                for (int j = 0; j < 3; ++j) blob[so_dw + ((size_t)i * 3 + j) * CH + c] = dw[(size_t)c * 3 + j];
-            std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + so_db + (size_t)i * CH);
-            blob[so_a2 + i] = W(p + ".prelu2.weight")[0];
-            std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + so_g2w + (size_t)i * CH);
-            std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + so_g2b + (size_t)i * CH);
-            const auto& w2 = W(p + ".sconv.weight");             // [NIN][CH][1]
-            for (int n = 0; n < NINs; ++n)
-                for (int k = 0; k < CH; ++k) blob[so_w2 + ((size_t)i * sN2P + n) * K2P + k] = w2[(size_t)n * CH + k];
-            std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + so_b2 + (size_t)i * sN2P);
-        }
-        const auto& wf = W("sb_model.fc_output_layer.weight");   // [2][NIN]: rows 0..1 of a zero-padded [sN2P][sK1P]
-        for (int n = 0; n < h->cfg.output_size; ++n)
-            for (int k = 0; k < NINs; ++k) blob[so_wf + (size_t)n * sK1P + k] = wf[(size_t)n * NINs + k];
-        const auto& bfv = W("sb_model.fc_output_layer.bias");
-        std::copy(bfv.begin(), bfv.end(), blob.begin() + so_bf);
-    }
     // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
     size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
@@ -780,23 +760,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
     h->fw.attention = h->cfg.attention;
-    h->tw.w1 = d + o_w1; h->tw.b1 = d + o_b1; h->tw.a1 = d + o_a1; h->tw.g1w = d + o_g1w; h->tw.g1b = d + o_g1b;
-    h->tw.dw = d + o_dw; h->tw.db = d + o_db; h->tw.a2 = d + o_a2; h->tw.g2w = d + o_g2w; h->tw.g2b = d + o_g2b;
-    h->tw.w2 = d + o_w2; h->tw.b2 = d + o_b2; h->tw.wf = d + o_wf; h->tw.bf = d + o_bf;
-    h->tw.num_cus = h->num_cus; h->tw.NB = NB; h->tw.N1P = N1P; h->tw.K1P = K1P; h->tw.N2P = N2P; h->tw.K2P = K2P;
-    for (int i = 0; i < NB; ++i) h->tw.dilation[i] = kDilations[i];
+    bind_tcn(h->tw, fb_off, d);
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
-    if (h->sb_tcn) {
-        TcnWeights& t = h->sbt;
-        t.w1 = d + so_w1; t.b1 = d + so_b1; t.a1 = d + so_a1; t.g1w = d + so_g1w; t.g1b = d + so_g1b;
-        t.dw = d + so_dw; t.db = d + so_db; t.a2 = d + so_a2; t.g2w = d + so_g2w; t.g2b = d + so_g2b;
-        t.w2 = d + so_w2; t.b2 = d + so_b2; t.wf = d + so_wf; t.bf = d + so_bf;
-        t.num_cus = h->num_cus; t.NB = 8; t.N1P = N1P; t.K1P = sK1P; t.N2P = sN2P; t.K2P = K2P;
-        for (int i = 0; i < 8; ++i) t.dilation[i] = kDilations[i];
-    }
+    if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
     if (fsn) {
         h->fbw = LstmWeights{};
         for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
