@@ -561,3 +561,25 @@ def test_enhance_wave_vs_oracle():
     # the two-step form (HIP stft -> enhance() -> HIP istft) is the same computation
     two = m.istft(m.enhance(m.stft(wav.cuda())), wav.shape[-1]).cpu()
     assert float((two - got).abs().max() / want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("splits", [(16, 16), (5, 20, 7)])
+def test_sharded_parity_mode_on_one_gpu(b32, splits):
+    """Multi-GPU plumbing on the real kernels: a shard passes (batch_offset, global_batch) and writes only its rows of
+    the GLOBAL drop_band output (frequency parity and row order follow the global sample index, feature.py:254-285);
+    the shards' outputs sum to the unsharded call (what dist.forward_sharded's all_reduce does)."""
+    sd, (mag, real, imag), m, _ = b32
+    m.batch_mode = "parity"
+    ins = _cuda((mag, real, imag))
+    whole = m(*ins).cpu().numpy()
+    acc = np.zeros_like(whole)
+    lo = 0
+    for n in splits:
+        part = m(*[t[lo:lo + n] for t in ins], batch_offset=lo, global_batch=32).cpu().numpy()
+        assert part.shape == whole.shape
+        acc += part
+        lo += n
+    assert lo == 32
+    m.batch_mode = "full"
+    # shards of other sizes run other sub-band kernels (K-split / three-way split): same rows, different summation order
+    assert rel_err(acc, whole) < 1e-5
