@@ -195,17 +195,17 @@ def main():
     rows = B * (model.num_freqs // 2 if (args.mode == "parity" and B > 1) else model.num_freqs)
     Tp = T + model.look_ahead
     from fullsubnet_plus_amd import _lib
-    lstm_flops = float(_lib.load().fsnp_lstm_flops(model._handle, rows, Tp))
-    lstm_ms = timing["lstm_ms"] / max(timing["count"], 1)
+    # roofline of the DOMINANT kernel = the first chunk of the sub-band plan (B=32: 8192 of the 8224 sequences on the
+    # one-tile-per-CU kernel; the 32 left over run on the K-split kernel afterwards); stage_* = the whole sub-band model
+    plan = model.describe_plan(B, parity=(args.mode == "parity" and B > 1))
+    stage_flops = float(_lib.load().fsnp_lstm_flops(model._handle, rows, Tp))
+    stage_ms = timing["lstm_ms"] / max(timing["count"], 1)
+    lstm_flops = float(_lib.load().fsnp_lstm_flops(model._handle, plan[0]["sequences"], Tp))
+    lstm_ms = timing["lstm_first_chunk_ms"] / max(timing["count"], 1)
     achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms > 0 else 0.0
+    stage_achieved = stage_flops / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
 
-    tiles = -(-rows // 32)      # which sub-band LSTM kernel fsnp_abi.hip:sb_kernel() picks for this many 32-row tiles
-    if args.precision != "fp32" or tiles > 170:
-        lstm_kernel_name = "lstm2_fc_kernel<384,40,2> (one 32-row tile per CU)"
-    elif tiles > 42:
-        lstm_kernel_name = "lstm2_coopn_kernel<384,40> (3 workgroups x 128 units per row-tile group)"
-    else:
-        lstm_kernel_name = "lstm2_coop_kernel<384,40> (K-split, 8-64 units per workgroup)"
+    lstm_kernel_name = plan[0]["kernel"]
     traffic = None   # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes
     pmc_path = os.path.join(ROOT, "profiles", "lstm_pmc.json")
     if os.path.exists(pmc_path) and B == 32 and abs(args.seconds - 2.0) < 1e-9 and args.mode == "full":
@@ -225,6 +225,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
+                     "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
                      "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
     }

@@ -50,7 +50,7 @@ struct GraphKey {
 struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
 
 struct TimingRec {
-    hipEvent_t e[3];  // start, after full-band stages, after lstm (= end)
+    hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
 };
 
 }  // namespace fsnp
@@ -102,6 +102,7 @@ struct fsnp_handle {
     unsigned char* io = nullptr;
     size_t io_bytes = 0;
 
+    double composite_gain = 0.97;   // a row-tile + remainder plan must be estimated this much cheaper to be chosen
     int use_graph = 1;           // 0 = plain launches (FSNP_GRAPH=0)
     hipStream_t cap_stream = nullptr;   // private stream: graph capture and replay
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -109,8 +110,8 @@ struct fsnp_handle {
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;
-    double acc_ms[3] = {0, 0, 0};
-    int64_t acc_cnt[3] = {0, 0, 0};
+    double acc_ms[4] = {0, 0, 0, 0};
+    int64_t acc_cnt[4] = {0, 0, 0, 0};
 };
 
 namespace fsnp {
@@ -267,13 +268,13 @@ static void build_specs(fsnp_handle* h) {
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
 // base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
 __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
-                                  int batch_offset, int global_batch, int dense_out) {
+                                  int batch_offset, int global_batch, int dense_out, int n_base) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= num_tiles * rt) return;
     const int tile = slot / rt, sl = slot % rt;
     const int base = num_rows / num_tiles, rem = num_rows % num_tiles;
     const int cnt = base + (tile < rem ? 1 : 0);
-    const int n = tile * base + (tile < rem ? tile : rem) + sl;
+    const int n = n_base + tile * base + (tile < rem ? tile : rem) + sl;      // n_base: first sequence of this chunk
     RowDesc r{0, 0, 0, 0};
     if (sl < cnt) {
         r.valid = 1;
@@ -310,55 +311,102 @@ static void launch_zero_region(void* p, size_t bytes, hipStream_t s) {      // b
     hipLaunchKernelGGL(zero_region_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16);
 }
 
-// The column-split kernel pays one inter-workgroup barrier per step, so it is used only while the row-tile kernel
-// would leave most of the chip idle: row_tiles * (H/32) workgroups must all be resident at once.
-// Which sub-band LSTM kernel runs `lp`: the row-tile kernel needs >= 256 tiles to fill the chip and costs ~208 us per
-// step however few tiles exist; the column-split kernels pay one inter-workgroup barrier per step instead.
+// ---- plan of the sub-band recurrent model: which kernel runs which sequences.
+// The row-tile kernel (lstm.hip) needs >= 256 tiles to fill the chip and costs ~208 us per step however few tiles it
+// gets; the column-split kernels pay one inter-workgroup barrier per step instead:
 //   <= 42 row tiles  : lstm_coop.hip  (K split, 8..64 hidden units per workgroup, row_tiles * H/units <= CUs)
 //   43..170 row tiles: lstm_coopn.hip (3 workgroups x 128 units share 1-2 row tiles)
-struct SbKernel { int kind; int units; int groups; int rpg; };   // kind 0 = row tile, 1 = coop (K split), 2 = coopn
-static SbKernel sb_kernel(const fsnp_handle* h, const LstmPlan& lp) {
-    SbKernel k{0, 0, 0, 0};
-    if (h->sb_tcn) return k;      // no recurrent kernel at all
-    if (h->gru) {       // no row-tile GRU kernel: <= 42 tiles K split, otherwise chunks of <= 170 tiles on lstm_coopn.hip
-        k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
-        k.kind = k.units != 0 ? 1 : 2;
-        return k;
-    }
-    if (h->lstm_coop == 0 || lp.ex != 0 || h->ih_bf16) return k;   // the cooperative kernels are fp32 only
-    k.units = lstm_coop_pick_units(h->H, lp.num_tiles, h->num_cus_real, 8);
-    if (k.units != 0) { k.kind = 1; return k; }
-    k.rpg = lstm_coopn_plan(h->H, lp.num_tiles, h->num_cus_real, &k.groups);
-    if (k.rpg != 0) k.kind = 2;
-    return k;
+// A problem is cut into CHUNKS of consecutive sequences that run back to back: e.g. B = 40 (10280 sequences) = one full
+// round of the row-tile kernel (8192) + 66 tiles on lstm_coopn.hip instead of two rounds; GRU (column-split only) =
+// chunks of <= 170 tiles.  Every chunk owns a slice of the row descriptors / per-row norm tables (slot0) and, if it is
+// column-split, of the exchange images and barrier counters (coop_tile0).
+struct SbChunk {
+    int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn
+    int row0, nrows;           // sequences [row0, row0 + nrows)
+    int num_tiles, ex, rps;    // tiles, VALU rows per tile, slots per tile (32 + ex)
+    int units, groups, rpg;    // column-split parameters
+    int slot0, coop_tile0;
+};
+struct SbPlan {
+    std::vector<SbChunk> chunks;
+    int total_slots = 0, coop_tiles = 0;
+};
+static double est_step_us(const fsnp_handle* h, const SbChunk& c) {      // measured per-step costs
+    if (c.kind == 1) return 191.0 * c.units / h->H + 11.0;
+    if (c.kind == 2) return c.rpg == 1 ? 79.0 : 153.0;
+    return cdiv(c.num_tiles, h->num_cus) * 208.0 * (1.0 + 0.11 * c.ex);
 }
-static bool use_coop(const fsnp_handle* h, const LstmPlan& lp) { return sb_kernel(h, lp).kind != 0; }
-static void launch_sb_lstm(const fsnp_handle* h, const LstmPlan& lp, LstmArgs& a, float* hx, unsigned* bar, hipStream_t s) {
-    const SbKernel k = sb_kernel(h, lp);
-    if (k.kind == 0) { launch_lstm(h->lw, a, s); return; }
-    a.coop_hx = hx; a.coop_bar = bar; a.coop_err = h->d_err;
-    a.coop_units = k.units; a.coop_groups = k.groups; a.coop_rows_per_group = k.rpg;
-    if (k.kind == 1) { launch_lstm_coop(h->lw, a, s); return; }
-    if (k.rpg != 0) { launch_lstm_coopn(h->lw, a, s); return; }
-    // GRU with more row tiles than one co-resident launch takes: consecutive chunks, each with its own slice of the
-    // row descriptors, exchange images, barrier counters and per-row norm tables
-    const int S = h->H / 128, gmax = h->num_cus_real / S, chunk = 2 * gmax;
+static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
+    const LstmPlan lp = plan_lstm_tiles(nrows, h->num_cus);
+    return SbChunk{0, row0, nrows, lp.num_tiles, lp.ex, lp.rows_per_slot_tile, 0, 0, 0, 0, 0};
+}
+static SbChunk column_chunk(const fsnp_handle* h, int row0, int nrows) {   // kind 0 = not applicable (too many tiles)
+    SbChunk c{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};
+    c.units = lstm_coop_pick_units(h->H, c.num_tiles, h->num_cus_real, 8);
+    if (c.units != 0) { c.kind = 1; return c; }
+    c.rpg = lstm_coopn_plan(h->H, c.num_tiles, h->num_cus_real, &c.groups);
+    if (c.rpg != 0) c.kind = 2;
+    return c;
+}
+static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
+    SbPlan p;
+    auto push = [&](SbChunk c) {
+        c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
+        c.coop_tile0 = p.coop_tiles; if (c.kind != 0) p.coop_tiles += c.num_tiles;
+        p.chunks.push_back(c);
+    };
+    if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
+    const int col_max_rows = 2 * (h->num_cus_real / (h->H / 128)) * 32;      // one lstm_coopn launch: 170 tiles on 256 CUs
+    if (h->gru) {                                                             // no row-tile GRU kernel
+        for (int r0 = 0; r0 < num_rows; r0 += col_max_rows) push(column_chunk(h, r0, num_rows - r0 < col_max_rows ? num_rows - r0 : col_max_rows));
+        return p;
+    }
+    const SbChunk whole = rowtile_chunk(h, 0, num_rows);
+    if (h->lstm_coop == 0 || h->ih_bf16) { push(whole); return p; }           // the column-split kernels are fp32 only
+    if (num_rows <= col_max_rows) {
+        const SbChunk c = column_chunk(h, 0, num_rows);
+        push(c.kind != 0 ? c : whole);
+        return p;
+    }
+    // full rounds on the row-tile kernel + the remainder on whatever runs it fastest, if that beats VALU rows / one more round
+    const int full = h->num_cus * 32, q = num_rows / full, rem = num_rows - q * full;
+    if (q >= 1 && rem > 0) {
+        SbChunk rc = rem <= col_max_rows ? column_chunk(h, q * full, rem) : rowtile_chunk(h, q * full, rem);
+        if (rc.kind == 0 && rem <= col_max_rows) rc = rowtile_chunk(h, q * full, rem);
+        const SbChunk main_c{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0};
+        if (est_step_us(h, main_c) + est_step_us(h, rc) < h->composite_gain * est_step_us(h, whole)) { push(main_c); push(rc); return p; }
+    }
+    push(whole);
+    return p;
+}
+static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmArgs& a, float* hx, unsigned* bar, hipStream_t s,
+                           hipEvent_t after_first = nullptr) {
     const size_t hx_floats_per_tile = lstm_coop_exchange_bytes(h->H, 1) / 4;
-    for (int t0 = 0; t0 < lp.num_tiles; t0 += chunk) {
-        LstmArgs c = a;
-        c.num_tiles = lp.num_tiles - t0 < chunk ? lp.num_tiles - t0 : chunk;
-        c.rows = a.rows + (size_t)t0 * 32;
-        c.coop_hx = hx + (size_t)t0 * hx_floats_per_tile;
-        c.coop_bar = bar + t0;
-        if (a.md_row) c.md_row = a.md_row + (size_t)t0 * 32 * a.Tp;
-        c.coop_rows_per_group = lstm_coopn_plan(h->H, c.num_tiles, h->num_cus_real, &c.coop_groups);
-        launch_lstm_coopn(h->lw, c, s);
+    bool first = true;
+    for (const SbChunk& c : plan.chunks) {
+        if (!first && after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
+        first = false;
+        LstmArgs ca = a;
+        ca.rows = a.rows + c.slot0;
+        ca.num_rows = c.nrows; ca.num_tiles = c.num_tiles; ca.ex = c.ex;
+        if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
+        if (c.kind == 0) { launch_lstm(h->lw, ca, s); continue; }
+        ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
+        ca.coop_bar = bar + c.coop_tile0;
+        ca.coop_err = h->d_err;
+        ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
+        if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
+        else launch_lstm_coopn(h->lw, ca, s);
     }
+    if (after_first) (void)hipEventRecord(after_first, s);
 }
-// Tile plan of the sub-band problem: GRU has no VALU-row variant, always plain 32-row tiles
-static LstmPlan sb_plan(const fsnp_handle* h, int num_rows) {
-    if (h->gru || h->sb_tcn) return LstmPlan{cdiv(num_rows, 32), 0, 32};
-    return plan_lstm_tiles(num_rows, h->num_cus);
+static void launch_build_rows(const SbPlan& plan, RowDesc* rows, int F, int T, int mode, int batch_offset, int global_batch,
+                              int dense_out, hipStream_t s) {
+    for (const SbChunk& c : plan.chunks) {
+        const int slots = c.num_tiles * c.rps;
+        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, s, rows + c.slot0, c.nrows, c.num_tiles, c.rps,
+                           F, T, mode, batch_offset, global_batch, dense_out, c.row0);
+    }
 }
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
 static int fb_row_tiles(int B) { return cdiv(B, 32); }
@@ -387,8 +435,8 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gate = take(fsn ? 0 : (size_t)3 * B * h->FP * 4);
     w.md = take(nbr * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
-    const LstmPlan lp = sb_plan(h, B * rows_per_utt(h, mode));
-    const size_t nrows_pad = (size_t)lp.num_tiles * lp.rows_per_slot_tile;
+    const SbPlan plan = plan_sb(h, B * rows_per_utt(h, mode));
+    const size_t nrows_pad = (size_t)plan.total_slots;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
     w.rows = take(nrows_pad * sizeof(RowDesc));
@@ -400,9 +448,8 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.fsum = take(fsn ? 0 : (size_t)3 * B * h->FP * 8);
     w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
-    const bool coop = use_coop(h, lp);
-    w.coop_hx = take(coop ? lstm_coop_exchange_bytes(h->H, lp.num_tiles) : 0);
-    w.coop_bar = take(coop ? (size_t)lp.num_tiles * 4 : 0);
+    w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
+    w.coop_bar = take((size_t)plan.coop_tiles * 4);
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
     w.sbt_gn = take(h->sb_tcn ? (size_t)8 * 2 * nrows_pad * 2 * 8 : 0);
@@ -505,6 +552,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         return 4;
     }
     memset(h->d_err, 0, 256);
+    const char* cg = getenv("FSNP_COMPOSITE_GAIN");      // tuning: 0 = never split a batch into row-tile rounds + remainder
+    if (cg) h->composite_gain = atof(cg);
     const char* gp = getenv("FSNP_GRAPH");
     if (gp && gp[0] == '0') h->use_graph = 0;
     const char* nw = getenv("FSNP_LSTM_WAVES");
@@ -824,8 +873,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         FSNP_HIP_CHECK(hipEventRecord(rec.e[0], s));
     }
     const int num_rows = batch * rows_per_utt(h, mode);
-    const LstmPlan lp = sb_plan(h, num_rows);
-    const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
+    const SbPlan plan = plan_sb(h, num_rows);
+    const int num_slots = plan.total_slots;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     SubbandBuffers sbuf;
@@ -836,8 +885,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     // workspace-only prologue shared by both models: zero the accumulators, describe the sub-band rows
     auto prologue = [&](hipStream_t st) {
         launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
-        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, st, rows, num_rows, lp.num_tiles,
-                           lp.rows_per_slot_tile, h->F, frames, mode, batch_offset, global_batch, 0);
+        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, st);
     };
 
     if (!fsn) {
@@ -875,7 +923,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int fb_tiles = fb_row_tiles(batch);
         RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * 32, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, 32,
-                           1, frames, 0, 0, 1, 1);
+                           1, frames, 0, 0, 1, 1, 0);
         LstmArgs fa{};
         fa.rows = fb_rows; fa.dense = fptr(w.att); fa.dense_stride = d.FP; fa.md_seq = fbuf.md;
         fa.seq_out = fptr(w.y1);
@@ -908,6 +956,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         launch_sb_scatter(fptr(w.sbt_fb), h->XS, rows, out, (long)rows_per_utt(h, mode) * frames, num_slots, d.Tp, d.LA, s);
         if (h->timing) {
             FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
+            FSNP_HIP_CHECK(hipEventRecord(rec.e[3], s));
             h->timing_recs.push_back(rec);
         }
         FSNP_HIP_CHECK(hipGetLastError());
@@ -921,9 +970,9 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     a.rows = rows; a.md_utt = sbuf.md_utt; a.md_row = sbuf.md_row; a.dense = nullptr;
     a.out = out;
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
-    a.num_rows = num_rows; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
+    a.num_rows = num_rows; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.act = h->cfg.sb_act;
-    launch_sb_lstm(h, lp, a, fptr(w.coop_hx), reinterpret_cast<unsigned*>(base + w.coop_bar), s);
+    launch_sb_lstm(h, plan, a, fptr(w.coop_hx), reinterpret_cast<unsigned*>(base + w.coop_bar), s, h->timing ? rec.e[3] : nullptr);
     if (h->timing) {
         FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
         h->timing_recs.push_back(rec);
@@ -1093,22 +1142,21 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
-    const LstmPlan lp = sb_plan(h, num_seq);
-    const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
-    const bool coop = use_coop(h, lp);
+    const SbPlan plan = plan_sb(h, num_seq);
+    const int num_slots = plan.total_slots;
+    const bool coop = plan.coop_tiles != 0;
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, lp.num_tiles), 256) : 0;
-    const size_t coop_bytes = coop ? coop_hx_bytes + align_up((size_t)lp.num_tiles * 4, 256) : 0;
+    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
+    const size_t coop_bytes = coop ? coop_hx_bytes + align_up((size_t)plan.coop_tiles * 4, 256) : 0;
     if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
     if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
-    hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, s, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, s);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
-    a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
-    launch_sb_lstm(h, lp, a, reinterpret_cast<float*>(h->ws + coop_off),
+    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
+    launch_sb_lstm(h, plan, a, reinterpret_cast<float*>(h->ws + coop_off),
                    reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes), s);
     FSNP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1147,22 +1195,35 @@ int fsnp_set_timing(fsnp_handle* h, int32_t enable) {
     return 0;
 }
 
-int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t reset) {
+int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset) {
     if (!h || !ms || !count) { set_error("fsnp_get_timing: null argument"); return 1; }
     for (auto& r : h->timing_recs) {
         FSNP_HIP_CHECK(hipEventSynchronize(r.e[2]));
-        float fb = 0, lstm = 0, all = 0;
+        float fb = 0, lstm = 0, all = 0, first = 0;
         FSNP_HIP_CHECK(hipEventElapsedTime(&fb, r.e[0], r.e[1]));
         FSNP_HIP_CHECK(hipEventElapsedTime(&lstm, r.e[1], r.e[2]));
         FSNP_HIP_CHECK(hipEventElapsedTime(&all, r.e[0], r.e[2]));
-        h->acc_ms[0] += lstm; h->acc_ms[1] += fb; h->acc_ms[2] += all;
-        for (int i = 0; i < 3; ++i) h->acc_cnt[i] += 1;
+        FSNP_HIP_CHECK(hipEventElapsedTime(&first, r.e[1], r.e[3]));
+        h->acc_ms[0] += lstm; h->acc_ms[1] += fb; h->acc_ms[2] += all; h->acc_ms[3] += first;
+        for (int i = 0; i < 4; ++i) h->acc_cnt[i] += 1;
         for (auto& e : r.e) if (e) (void)hipEventDestroy(e);
     }
     h->timing_recs.clear();
-    for (int i = 0; i < 3; ++i) { ms[i] = h->acc_ms[i]; count[i] = h->acc_cnt[i]; }
-    if (reset) for (int i = 0; i < 3; ++i) { h->acc_ms[i] = 0; h->acc_cnt[i] = 0; }
+    for (int i = 0; i < 4; ++i) { ms[i] = h->acc_ms[i]; count[i] = h->acc_cnt[i]; }
+    if (reset) for (int i = 0; i < 4; ++i) { h->acc_ms[i] = 0; h->acc_cnt[i] = 0; }
     return 0;
+}
+
+int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks) {
+    if (!h || !out || batch <= 0 || max_chunks <= 0) { set_error("fsnp_describe_plan: bad argument"); return -1; }
+    const SbPlan plan = plan_sb(h, batch * rows_per_utt(h, mode));
+    int n = 0;
+    for (const SbChunk& c : plan.chunks) {
+        if (n >= max_chunks) break;
+        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind; out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
+        ++n;
+    }
+    return n;
 }
 
 int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
@@ -1172,7 +1233,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
     if (h->gru || h->sb_tcn) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
     FSNP_HIP_CHECK(hipSetDevice(h->device));
-    const LstmPlan lp = sb_plan(h, num_seq);
+    const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
     if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8)) return 4;
@@ -1180,7 +1241,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
     h->have_last = false;
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, 0, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1);
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, 0);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.F = 1;

@@ -391,11 +391,23 @@ class _HipModel(nn.Module):
 
     def get_timing(self, reset=True):
         """-> {"lstm_ms", "fullband_ms", "forward_ms", "count"}: hipEvent sums on the forward's stream."""
-        ms = (ctypes.c_double * 3)()
-        cnt = (ctypes.c_int64 * 3)()
+        ms = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int64 * 4)()
         _lib.check(_lib.load().fsnp_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(cnt), int(reset)),
                    "fsnp_get_timing")
-        return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "count": int(cnt[0])}
+        return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "lstm_first_chunk_ms": ms[3], "count": int(cnt[0])}
+
+    def describe_plan(self, batch, parity=False):
+        """-> [{"kernel", "sequences", "tiles", "valu_rows"}, ...]: how the sub-band sequences of a `batch`-utterance
+        forward are cut into kernel launches (fsnp_describe_plan)."""
+        buf = (ctypes.c_int32 * 64)()
+        n = _lib.load().fsnp_describe_plan(self._handle, int(batch), int(parity), buf, 16)
+        if n < 0:
+            raise RuntimeError(_lib.last_error())
+        names = {0: "lstm2_fc_kernel (one 32-row tile per CU)", 1: "lstm2_coop_kernel (K split)",
+                 2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN"}
+        return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
+                for i in range(n)]
 
     def forward_flops(self, batch, frames, parity=False):
         return float(_lib.load().fsnp_forward_flops(self._handle, batch, frames, int(parity)))

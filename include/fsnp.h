@@ -179,10 +179,15 @@ int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t n
 /* Per-kernel timing with hipEvents recorded on the forward's own stream.
  * enable != 0 turns it on for subsequent forwards (adds event records only).
  * fsnp_get_timing synchronises, then returns the accumulated milliseconds and launch
- * counts since the last reset: index 0 = fused sub-band LSTM kernel, 1 = full-band
- * (frontend+TCN) kernels, 2 = whole forward. */
+ * counts since the last reset: index 0 = the sub-band model (all of its kernels), 1 = full-band
+ * (frontend+TCN) kernels, 2 = whole forward, 3 = the FIRST chunk of the sub-band plan alone (the dominant kernel:
+ * see fsnp_describe_plan). */
 int fsnp_set_timing(fsnp_handle* h, int32_t enable);
-int fsnp_get_timing(fsnp_handle* h, double ms[3], int64_t count[3], int32_t reset);
+int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset);
+/* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
+ * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN),
+ *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
+int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 
 /* Static facts for roofline accounting: algorithmic FLOPs of one forward. */
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);

@@ -583,3 +583,37 @@ def test_sharded_parity_mode_on_one_gpu(b32, splits):
     m.batch_mode = "full"
     # shards of other sizes run other sub-band kernels (K-split / three-way split): same rows, different summation order
     assert rel_err(acc, whole) < 1e-5
+
+
+@pytest.mark.parametrize("n,steps", [(8192 + 40, 5), (8192 + 1500, 4), (8192 + 4000, 4), (8192 + 6000, 3), (16384 + 70, 3)])
+def test_lstm2_fc_composite_plans(n, steps):
+    """More sequences than one round of the row-tile kernel: full rounds (256 x 32 rows) + the remainder on a column-split
+    kernel when that is estimated cheaper than VALU rows / another round (fsnp_abi.hip plan_sb): 2 / 47 / 125 remainder
+    tiles, a remainder too large for one column-split launch, and two full rounds + 3 tiles."""
+    sd = make_state_dict(9, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    rng = np.random.Generator(np.random.PCG64(177 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    m.check_errors()
+    err = rel_err(got, want)
+    _record(f"lstm_composite_{n}x{steps}", rel=err)
+    assert err < 2e-5, err
+    m.debug_set_lstm_coop(0)                               # single row-tile plan
+    assert rel_err(m.lstm2_fc(x.cuda()).cpu().numpy(), want) < 2e-5
+
+
+def test_forward_b40_composite_vs_oracle():
+    """B = 40 in full mode: 10280 sequences = one full row-tile round + 66 tiles on lstm_coopn.hip."""
+    sd = make_state_dict(51, "default")
+    mag, real, imag = make_inputs(40, 0.5, 302)
+    for norm in ("offline_laplace_norm", "cumulative_layer_norm"):
+        m = _model({**DEFAULT_MODEL_ARGS, "norm_type": norm}, sd, "full")
+        out = m(*_cuda((mag, real, imag))).cpu().numpy()
+        m.check_errors()
+        pick = [0, 31, 32, 39]                             # utterances on both sides of the chunk boundary (row 8192 = utt 31)
+        want = fsnp_torch.forward_full(sd, mag[pick], real[pick], imag[pick], norm_type=norm).numpy()
+        err = rel_err(out[pick], want)
+        _record(f"forward_b40_composite_{norm}", rel=err)
+        assert err < TOL, err
