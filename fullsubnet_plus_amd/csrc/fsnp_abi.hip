@@ -36,8 +36,9 @@ struct Workspace {
         fsum, gn, sb_acc, coop_hx, coop_bar, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
 };
 
-// The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1, of
-// which most is launch latency): it is captured once per (shape, mode, plan) into a hipGraph and replayed.
+// The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1); it
+// can be captured once per (shape, mode, plan) into a hipGraph and replayed (opt-in: FSNP_GRAPH=1).  Measured: no gain -
+// the launches are asynchronous and the host runs ahead of the GPU, so the chain is bound by the kernels' own latency.
 struct GraphKey {
     int B, T, mode, boff, gb, num_cus, coop, bf16, debug;
     const void* ws;
@@ -103,7 +104,8 @@ struct fsnp_handle {
     size_t io_bytes = 0;
 
     double composite_gain = 0.97;   // a row-tile + remainder plan must be estimated this much cheaper to be chosen
-    int use_graph = 1;           // 0 = plain launches (FSNP_GRAPH=0)
+    int use_graph = 0;           // 0 = plain launches (default: measured no gain), 1 = replay on the
+                                 // private stream, 2 = replay straight into the caller's stream (FSNP_GRAPH=1|2)
     hipStream_t cap_stream = nullptr;   // private stream: graph capture and replay
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<GraphEntry> graphs;
@@ -132,6 +134,7 @@ static void drop_graphs(fsnp_handle* h) {
 // (the caller's stream is usually torch's legacy default stream, which cannot be captured; keeping the replay on the
 // capture stream makes the ordering explicit instead of relying on default-stream semantics).
 static int launch_graph_between(fsnp_handle* h, hipGraphExec_t exec, hipStream_t s) {
+    if (h->use_graph == 2) { FSNP_HIP_CHECK(hipGraphLaunch(exec, s)); return 0; }     // straight into the caller's stream
     FSNP_HIP_CHECK(hipEventRecord(h->ev_in, s));
     FSNP_HIP_CHECK(hipStreamWaitEvent(h->cap_stream, h->ev_in, 0));
     FSNP_HIP_CHECK(hipGraphLaunch(exec, h->cap_stream));
@@ -555,7 +558,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     const char* cg = getenv("FSNP_COMPOSITE_GAIN");      // tuning: 0 = never split a batch into row-tile rounds + remainder
     if (cg) h->composite_gain = atof(cg);
     const char* gp = getenv("FSNP_GRAPH");
-    if (gp && gp[0] == '0') h->use_graph = 0;
+    if (gp && gp[0] == '1') h->use_graph = 1;
+    if (gp && gp[0] == '2') h->use_graph = 2;
     const char* nw = getenv("FSNP_LSTM_WAVES");
     if (nw && atoi(nw) == 4) h->lstm_waves = 4;
     if (nw && atoi(nw) == 12) h->lstm_waves = 12;
@@ -1281,7 +1285,7 @@ int fsnp_debug_inject_error(fsnp_handle* h) {
 }
 
 int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_graph: mode must be 0 (plain launches) or 1 (hipGraph replay)"); return 1; }
+    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_graph: mode must be 0 (plain launches), 1 or 2 (hipGraph replay)"); return 1; }
     h->use_graph = mode;
     return 0;
 }

@@ -73,6 +73,30 @@ __device__ __forceinline__ void coop_layer(f32x16 (&acc)[NT], const CoopStream& 
     }
 }
 
+// The same with the wave's weights RESIDENT in registers (bw[i][n], loaded once before the time loop): with <= 16 hidden
+// units per workgroup a wave's whole share of both layers is 152..228 registers, so a step issues no weight loads at
+// all - only the A operands travel (D-deep register pipeline as above).
+template <int NT, int G, int XG, typename SrcX, typename SrcH>
+__device__ __forceinline__ void coop_layer_resident(f32x16 (&acc)[NT], const float4 (&bw)[G][NT], SrcX srcx, SrcH srch) {
+    constexpr int D = 8 < G ? 8 : G;
+    float4 a[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = k < XG ? srcx(k) : srch(k - XG);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int slot = i % D;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot].x, bw[i][n].x, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot].y, bw[i][n].y, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot].z, bw[i][n].z, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot].w, bw[i][n].w, acc[n], 0, 0, 0);
+        }
+        if (i + D < G) a[slot] = (i + D) < XG ? srcx(i + D) : srch(i + D - XG);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 constexpr int coop_units_index(int units) { return units == 8 ? 0 : units == 16 ? 1 : units == 32 ? 2 : 3; }
 
 }  // namespace
@@ -93,6 +117,9 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     constexpr int HIMG = KGH * 64;                 // float4 per exchange image (32 rows x HID)
     constexpr bool GATHER = KX <= 64;              // sub-band input built from att_mag / fb; else dense rows only
     constexpr bool BIAS_REGS = UNITS <= 32;
+    // weights resident in VGPRs (see coop_layer_resident): 152 (H = 384) / 228 (H = 512) registers at 8 units per workgroup.
+    // Not at 16 units (304): half of them would live in AGPRs and be copied back before every MFMA - measured 16 % SLOWER.
+    constexpr bool WREG = NT * (G0W + G1W) * 4 <= 232;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* Xs = reinterpret_cast<float4*>(smem_raw);                     // [KGXP][64] A image of x_t
@@ -177,6 +204,17 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(w.wpack) + (size_t)(cs * 4 + wave) * (G0W + G1W) * NT * 256, 0, (G0W + G1W) * NT * 1024, 0x00020000);
     ws.voff = lane * 16;
+    float4 bw0[WREG ? G0W : 1][NT], bw1[WREG ? G1W : 1][NT];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int i = 0; i < G0W; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw0[i][n] = coop_wload<NT>(ws, i, n);
+#pragma unroll
+        for (int i = 0; i < G1W; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw1[i][n] = coop_wload<NT>(ws, G0W + i, n);
+    }
     const float4* Xw = Xs + wave * 64 + lane;           // local group i of this wave = global k-group 4 i + wave
     // A operands from the exchange images: buffer loads too (a flat load would make hipcc drain vmcnt AND lgkmcnt)
     CoopStream hs;
@@ -281,8 +319,12 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-        coop_layer<NT, G0W, KGXP / 4, 0>(acc, ws, [&](int i) -> float4 { return Xw[i * 256]; },
-                                         [&](int i) -> float4 { return hload(prv, i); });
+        if constexpr (WREG)
+            coop_layer_resident<NT, G0W, KGXP / 4>(acc, bw0, [&](int i) -> float4 { return Xw[i * 256]; },
+                                                   [&](int i) -> float4 { return hload(prv, i); });
+        else
+            coop_layer<NT, G0W, KGXP / 4, 0>(acc, ws, [&](int i) -> float4 { return Xw[i * 256]; },
+                                             [&](int i) -> float4 { return hload(prv, i); });
         publish_tiles(acc);
         {
             float* img = reinterpret_cast<float*>(h0img[cur]);
@@ -323,8 +365,12 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-        coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(2 + prv, i); },
-                                          [&](int i) -> float4 { return hload(cur, i); });
+        if constexpr (WREG)
+            coop_layer_resident<NT, G1W, KGH / 4>(acc, bw1, [&](int i) -> float4 { return hload(2 + prv, i); },
+                                                  [&](int i) -> float4 { return hload(cur, i); });
+        else
+            coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(2 + prv, i); },
+                                              [&](int i) -> float4 { return hload(cur, i); });
         publish_tiles(acc);
         {
             float* img = reinterpret_cast<float*>(h1img[cur]);

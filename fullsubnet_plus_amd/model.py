@@ -362,7 +362,7 @@ class _HipModel(nn.Module):
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
     def debug_set_graph(self, mode, device="cuda"):
-        """Tuning hook: 1 = replay the full-band stages from a hipGraph (default), 0 = launch kernel by kernel."""
+        """Tuning hook: 1 / 2 = replay the full-band stages from a hipGraph, 0 = launch kernel by kernel (default)."""
         dev = torch.device(device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())

@@ -215,9 +215,10 @@ int fsnp_check_errors(fsnp_handle* h);
  * row_tiles * H/32 workgroups fit the chip (small batches, e.g. the reference CLI's batch of one); 0 = never
  * (also FSNP_LSTM_COOP=0 at fsnp_create time). */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
-/* Tuning hook: 1 (default; env FSNP_GRAPH=0 turns it off) = the ~75 workspace-only launches between the input repack and
- * the sub-band LSTM of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph and replayed on
- * the caller's stream; 0 = plain launches. */
+/* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
+ * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph
+ * and replayed on a private stream ordered by events (1) or straight into the caller's stream (2).  Off by default:
+ * bit-identical, but no faster - the chain is bound by kernel latency, not by launch overhead. */
 int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode);
 /* Test hook: sets the device error word as a timed-out inter-workgroup wait would (the next fsnp_forward /
  * fsnp_check_errors on the handle must then fail, once). */
