@@ -22,4 +22,18 @@ __host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
 }
 
 
+// ---- inter-workgroup exchange of the column-split kernels (lstm_coop.hip, lstm_coopn.hip): WRITE-THROUGH protocol.
+// Producers store h / Linear partials with sc1 (write-through) stores - a relaxed agent-scope atomic store of 4 bytes is
+// exactly `global_store_dword ... sc1` - every storing wave drains vmcnt, __syncthreads, ONE lane arrives on the counter;
+// consumers poll relaxed, __syncthreads, and read with sc1 loads (buffer aux = 16 / relaxed agent atomic loads), which
+// bypass the CU's L1.  No release / acquire fence: `buffer_wbl2 sc1` + `buffer_inv sc1` issued by ~200 workgroups
+// every step cost 4.6 us of a 23 us step at B = 1 (measured by deleting them).  cdna_hip_programming.md, Guideline 16 R1.
+constexpr int kSc1 = 16;   // buffer-load aux bit: sc1
+__device__ __forceinline__ void xchg_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xchg_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace fsnp

@@ -15,9 +15,9 @@
 //     exchange image in global memory that is ALREADY in MFMA A-fragment order, so consumers read their A operands
 //     straight from L2 with one coalesced 16-byte load per lane per k-group (no LDS copy);
 //   * ONE inter-workgroup barrier per step (after h0_t is published) orders everything: h1_{t-1} was published
-//     before its writer arrived.  The barrier is the MI355X hand-off recipe (MI355X_MICROARCH.md): every storing wave
-//     drains vmcnt, __syncthreads, ONE lane: agent-scope release + asm vmcnt(0) + relaxed atomic arrive, relaxed
-//     polling with s_sleep, ONE agent-scope acquire, __syncthreads, plain vector loads.  Spins are bounded; all
+//     before its writer arrived.  The hand-off is the write-through recipe (lstm_common.h; cdna_hip_programming.md G16 R1):
+//     sc1 stores, every storing wave drains vmcnt, __syncthreads, ONE lane: asm vmcnt(0) + relaxed atomic arrive, relaxed
+//     polling with s_sleep, __syncthreads, sc1 loads - no release / acquire fence.  Spins are bounded; all
 //     workgroups of a launch must be co-resident (the host only launches RT * S <= number of CUs).
 //   * SEQ = false (sub-band model): the Linear(H, 2) epilogue is a per-workgroup partial dot over its own units,
 //     published with h1 and summed in a fixed order by workgroup cs == 0 one step later (deterministic, no float
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     hs.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(hx), 0, 4 * HIMG * 16, 0x00020000);
     hs.voff = (wave * 64 + lane) * 16;
     auto hload = [&](int image, int i) -> float4 {      // image: 0/1 = h0 parity 0/1, 2/3 = h1 parity 0/1
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hs.rsrc, hs.voff, image * (HIMG * 16) + i * 4096, 0));
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hs.rsrc, hs.voff, image * (HIMG * 16) + i * 4096, kSc1));
     };
 
     // ---- cell update ownership: pair p = tid + 256 i  ->  unit u = p % UNITS (fastest: conflict-free LDS reads),
@@ -272,7 +272,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
@@ -283,7 +282,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     };
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
             const RowDesc rd = rows_s[row];
             const float* part = fcp + (size_t)(t_done & 1) * S * 64;
             float sum = w.bfc[o];
-            for (int p = 0; p < S; ++p) sum += part[p * 64 + o * 32 + row];
+            for (int p = 0; p < S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
             if (rd.valid && t_done >= a.LA)
                 a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
         }
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     c0[i] = cn;
                     hval = og * fast_tanh(cn);
                 }
-                img[a_frag_index(prow[i], pk[i])] = hval;
+                xchg_store(img + a_frag_index(prow[i], pk[i]), hval);
             }
         }
         if (have_next) {
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     c1[i] = cn;
                     h = og * fast_tanh(cn);
                 }
-                img[a_frag_index(prow[i], pk[i])] = h;
+                xchg_store(img + a_frag_index(prow[i], pk[i]), h);
                 if constexpr (SEQ) {
                     const RowDesc rd = rows_s[prow[i]];
                     if (rd.valid) a.seq_out[((size_t)rd.b * Tp + t) * HID + pk[i]] = h;
@@ -409,8 +407,8 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     for (int m = UNITS / 2; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
                     if ((tid & (UNITS - 1)) == 0) {
                         float* part = fcp + ((size_t)cur * S + cs) * 64;
-                        part[prow[i]] = p0;
-                        part[32 + prow[i]] = p1;
+                        xchg_store(part + prow[i], p0);
+                        xchg_store(part + 32 + prow[i], p1);
                     }
                 }
             }

@@ -11,7 +11,8 @@
 // one (row, unit) share lane and register index, the cell update is lane-local, c stays in registers - the row-tile
 // kernel's 12-wave layout spread over three CUs).  h0_t / h1_t travel through the per-tile, double-buffered global
 // exchange images of lstm_coop.hip (already in MFMA A-fragment order; consumers read A operands straight from L2),
-// with ONE inter-workgroup barrier per step per group (MI355X_MICROARCH.md hand-off recipe, bounded spins).
+// with ONE inter-workgroup barrier per step per group (write-through hand-off of lstm_common.h: sc1 stores, drained
+// arrive, sc1 loads, no fences; bounded spins).
 // The Linear(H, 2) epilogue is a per-wave partial dot, summed in a fixed order by workgroup cs == 0 one step later.
 #include "fsnp_common.h"
 #include "lstm_common.h"
@@ -27,6 +28,9 @@ struct NStream {
 
 __device__ __forceinline__ float4 nload(const NStream& s, int soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff, soff, 0));
+}
+__device__ __forceinline__ float4 nload_sc1(const NStream& s, int soff) {    // exchange images: bypass L1 (lstm_common.h)
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff, soff, kSc1));
 }
 
 __device__ __forceinline__ void mfma16(f32x16 (&acc)[4], const float4& a, const float4 (&b)[4]) {
@@ -207,7 +211,6 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
@@ -218,7 +221,6 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     };
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             const RowDesc rd = rows_s[r][row];
             const float* part = a.coop_hx + ((size_t)rt[r] * HXT + 4 * HIMG) * 4 + (size_t)(t_done & 1) * (4 * S) * 64;
             float sum = w.bfc[o];
-            for (int p = 0; p < 4 * S; ++p) sum += part[p * 64 + o * 32 + row];
+            for (int p = 0; p < 4 * S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
             if (rd.valid && t_done >= a.LA)
                 a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
         }
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                 for (int q = 0; q < 16; ++q) acc[n][q] = 0.0f;
             const float4* xw = Xs[cur][r] + lane;
             coopn_unrolled<KGX>(acc, ws, 0, [&](int k) -> float4 { return xw[k * 64]; });
-            coopn_loop<KGH>(acc, ws, KGX, [&](int k) -> float4 { return nload(hs[r], prv * (HIMG * 16) + k * 1024); });
+            coopn_loop<KGH>(acc, ws, KGX, [&](int k) -> float4 { return nload_sc1(hs[r], prv * (HIMG * 16) + k * 1024); });
             float* img = reinterpret_cast<float*>(a.coop_hx + ((size_t)rt[r] * HXT + (size_t)cur * HIMG) * 4);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                     c0[r][q] = cn;
                     hval = og * fast_tanh(cn);
                 }
-                img[a_frag_index((q & 3) + 8 * (q >> 2) + rowbase, unit)] = hval;
+                xchg_store(img + a_frag_index((q & 3) + 8 * (q >> 2) + rowbase, unit), hval);
             }
             if (have_next) {      // the other parity: last read in step t-1, before that step's barrier
                 float* Xf = reinterpret_cast<float*>(Xs[prv][r]);
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[n][q] = 0.0f;
-            coopn_loop<KGH>(acc, ws, KG0, [&](int k) -> float4 { return nload(hs[r], (2 + prv) * (HIMG * 16) + k * 1024); });
-            coopn_loop<KGH>(acc, ws, KG0 + KGH, [&](int k) -> float4 { return nload(hs[r], cur * (HIMG * 16) + k * 1024); });
+            coopn_loop<KGH>(acc, ws, KG0, [&](int k) -> float4 { return nload_sc1(hs[r], (2 + prv) * (HIMG * 16) + k * 1024); });
+            coopn_loop<KGH>(acc, ws, KG0 + KGH, [&](int k) -> float4 { return nload_sc1(hs[r], cur * (HIMG * 16) + k * 1024); });
             float* img = reinterpret_cast<float*>(a.coop_hx + ((size_t)rt[r] * HXT + (size_t)(2 + cur) * HIMG) * 4);
             float* part = a.coop_hx + ((size_t)rt[r] * HXT + 4 * HIMG) * 4 + ((size_t)cur * (4 * S) + ub) * 64;
 #pragma unroll
@@ -320,11 +322,11 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                     hval = og * fast_tanh(cn);
                 }
                 const int row = (q & 3) + 8 * (q >> 2) + rowbase;
-                img[a_frag_index(row, unit)] = hval;
+                xchg_store(img + a_frag_index(row, unit), hval);
                 float p0 = hval * wfc0, p1 = hval * wfc1;        // partial Linear over this wave's 32 units
 #pragma unroll
                 for (int m = 16; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
-                if ((lane & 31) == 0) { part[row] = p0; part[32 + row] = p1; }
+                if ((lane & 31) == 0) { xchg_store(part + row, p0); xchg_store(part + 32 + row, p1); }
             }
         }
     }

@@ -617,3 +617,29 @@ def test_forward_b40_composite_vs_oracle():
         err = rel_err(out[pick], want)
         _record(f"forward_b40_composite_{norm}", rel=err)
         assert err < TOL, err
+
+
+@pytest.mark.parametrize("n,steps", [(257, 60), (1300, 20), (2750, 12)])
+def test_column_split_exchange_under_load(n, steps):
+    """The write-through inter-workgroup hand-off (sc1 stores / sc1 loads, no fences; csrc/lstm_common.h) under UNEVEN
+    load: a bandwidth-heavy torch kernel hammers HBM / L2 on a second stream while the column-split kernels run;
+    25 repetitions must be bit-identical to the quiet run and match the oracle (a stale read shows up as garbage)."""
+    sd = make_state_dict(61, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    rng = np.random.Generator(np.random.PCG64(277 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
+    quiet = m.lstm2_fc(x)
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
+    assert rel_err(quiet.cpu().numpy(), want) < 2e-5
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 * 1024 * 1024, device="cuda")           # 256 MB: beyond every cache level
+    outs = []
+    for i in range(25):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                junk.mul_(1.0001).add_(0.5)
+        outs.append(m.lstm2_fc(x))
+    torch.cuda.synchronize()
+    m.check_errors()
+    for o in outs:
+        assert torch.equal(o, quiet)
