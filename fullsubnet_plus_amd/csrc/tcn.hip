@@ -54,10 +54,9 @@ template <int PRO, int EPI, int BN>
 __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     constexpr int NTILE = BN / 32;
     constexpr int BLD = (BN * 4 + 255) / 256;   // float4 B loads per thread per k-tile
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * 4 + 2 * 2 * BN * 4 + 16];
-    float* As = smem;                       // [kg 2][kh 2][BM][4]
-    float* Bs = smem + 2 * 2 * BM * 4;      // [kg 2][kh 2][BN][4]
-    double* red = reinterpret_cast<double*>(smem + 2 * 2 * BM * 4 + 2 * 2 * BN * 4);  // [8]
+    constexpr int STAGE = 2 * 2 * BM * 4 + 2 * 2 * BN * 4;      // floats of one (A, B) k-tile stage
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 16];   // double buffered: ONE barrier per k-tile
+    double* red = reinterpret_cast<double*>(smem + 2 * STAGE);  // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int branch = blockIdx.z;
@@ -86,8 +85,11 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     // staging assignment: A rows ar0, ar0+64 ; k quad kq ; B columns (tid + 256 i) >> 2
     const int kq = (tid & 3) * 4;
     const int ar0 = tid >> 2;
-    float4 areg[2], breg[BLD];
+    float4 areg[2], breg[BLD], ga4, be4;
 
+    // Phase 1: ISSUE the global loads of k-tile k0 (raw values only - nothing here consumes them, so they stay in flight
+    // while the MFMAs of the previous tile run).  Phase 2 (finish_tiles, just before the LDS store) applies the operand
+    // prologue: GroupNorm + affine / ReLU / zeroing of the K tail.
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq;
 #pragma unroll
@@ -98,13 +100,33 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
                 const float* p = A + (long)t * g.lda + k;
                 if (k + 4 <= a_cols) v = *reinterpret_cast<const float4*>(p);
                 else { v.x = p[0]; if (k + 1 < a_cols) v.y = p[1]; if (k + 2 < a_cols) v.z = p[2]; }
+            }
+            areg[i] = v;
+        }
+        if constexpr (PRO == PRO_GN) {
+            if (k < g.K) {
+                ga4 = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
+                be4 = *reinterpret_cast<const float4*>(beta + k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BLD; ++i) {
+            const int bc = (tid + 256 * i) >> 2;
+            breg[i] = bc < BN ? *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto finish_tiles = [&](int k0) {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = t0 + ar0 + 64 * i;
+            float4 v = areg[i];
+            if (t < g.Tp && k < g.K) {
                 if constexpr (PRO == PRO_GN) {
-                    const float4 ga = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
-                    const float4 be = *reinterpret_cast<const float4*>(beta + k);
-                    v.x = (v.x - mean) * rstd * ga.x + be.x;
-                    v.y = (v.y - mean) * rstd * ga.y + be.y;
-                    v.z = (v.z - mean) * rstd * ga.z + be.z;
-                    v.w = (v.w - mean) * rstd * ga.w + be.w;
+                    v.x = (v.x - mean) * rstd * ga4.x + be4.x;
+                    v.y = (v.y - mean) * rstd * ga4.y + be4.y;
+                    v.z = (v.z - mean) * rstd * ga4.z + be4.z;
+                    v.w = (v.w - mean) * rstd * ga4.w + be4.w;
                 }
                 if constexpr (PRO == PRO_RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -115,11 +137,6 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
             }
             areg[i] = v;
         }
-#pragma unroll
-        for (int i = 0; i < BLD; ++i) {
-            const int bc = (tid + 256 * i) >> 2;
-            breg[i] = bc < BN ? *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
     // a float4 of 4 consecutive k = (kh0,p) (kh1,p) (kh0,p+1) (kh1,p+1) with p = (kq>>1)&3  ->  two 8-byte LDS stores
     auto store_frag = [&](float* base, int ld, int row, const float4& v) {
@@ -127,7 +144,9 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         *reinterpret_cast<float2*>(base + ((kg * 2 + 0) * ld + row) * 4 + p) = make_float2(v.x, v.z);
         *reinterpret_cast<float2*>(base + ((kg * 2 + 1) * ld + row) * 4 + p) = make_float2(v.y, v.w);
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int stage) {
+        float* As = smem + stage * STAGE;               // [kg 2][kh 2][BM][4]
+        float* Bs = As + 2 * 2 * BM * 4;                // [kg 2][kh 2][BN][4]
 #pragma unroll
         for (int i = 0; i < 2; ++i) store_frag(As, BM, ar0 + 64 * i, areg[i]);
 #pragma unroll
@@ -145,13 +164,15 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
 
     const int ktiles = g.ldw / BK;
     load_tiles(0);
+    finish_tiles(0);
+    store_tiles(0);
+    __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
+        // global -> registers for tile kt+1 while tile kt is multiplied out of LDS stage kt & 1; the registers go to
+        // the OTHER stage (last read in iteration kt-1, before that iteration's barrier), then one barrier
         if (kt + 1 < ktiles) load_tiles((kt + 1) * BK);
-        const float4* As4 = reinterpret_cast<const float4*>(As);
-        const float4* Bs4 = reinterpret_cast<const float4*>(Bs);
+        const float4* As4 = reinterpret_cast<const float4*>(smem + (kt & 1) * STAGE);
+        const float4* Bs4 = As4 + 2 * 2 * BM;
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             const float4 a4 = As4[(kg * 2 + (lane >> 5)) * BM + wave * 32 + (lane & 31)];
@@ -164,6 +185,8 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
             }
         }
+        if (kt + 1 < ktiles) { finish_tiles((kt + 1) * BK); store_tiles((kt + 1) & 1); }
+        __syncthreads();
     }
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
