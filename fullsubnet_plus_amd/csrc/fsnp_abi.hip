@@ -365,7 +365,9 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
         return p;
     }
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
-    if (h->lstm_coop == 0 || h->ih_bf16) { push(whole); return p; }           // the column-split kernels are fp32 only
+    // bf16-ih mode (configs[4]) only changes the row-tile kernel: sequences that run on a column-split kernel (small
+    // batches, remainder tiles) stay fp32 - more accurate and, there, faster
+    if (h->lstm_coop == 0) { push(whole); return p; }
     if (num_rows <= col_max_rows) {
         const SbChunk c = column_chunk(h, 0, num_rows);
         push(c.kind != 0 ? c : whole);

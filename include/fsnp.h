@@ -201,7 +201,9 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 
 /* BASELINE.json configs[4]: 0 = fp32 everywhere (default, the headline path); 1 = the layer-1 input-to-hidden GEMM of
  * the sub-band LSTM (W_ih_l1 x h0_t, 32 % of the LSTM FLOPs) runs on v_mfma_f32_32x32x16_bf16 with bf16 operands
- * and fp32 accumulation; the recurrent GEMMs, layer 0, the cell and everything else stay fp32.  Tolerance of this
+ * and fp32 accumulation; the recurrent GEMMs, layer 0, the cell and everything else stay fp32.  Only the one-tile-per-CU
+ * kernel has this variant: sequences scheduled on the column-split kernels (small batches, the remainder tile of a
+ * composite plan) are computed in fp32.  Tolerance of this
  * mode vs the fp32 reference: 2e-2 rel (tests/test_gpu_parity.py::test_bf16_ih_variant). */
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
 
