@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        for (int i = tid; i < KGX * 64; i += 256) { Xs[0][r][i] = make_float4(0.f, 0.f, 0.f, 0.f); Xs[1][r][i] = Xs[0][r][i]; }
+        for (int i = tid; i < KGX * 64; i += 256) {
+            Xs[0][r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            Xs[1][r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (tid < 32) {
             RowDesc rd{0, 0, 0, 0};
             if (live[r]) rd = a.rows[rt[r] * 32 + tid];

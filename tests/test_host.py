@@ -290,3 +290,19 @@ def test_gru_variant_has_reference_parameter_tree(cls, args, maker):
     m.load_state_dict(sd, strict=True)
     with pytest.raises(RuntimeError):             # an LSTM checkpoint must not load into the GRU model
         m.load_state_dict(maker(0), strict=True)
+
+
+def test_column_split_kernels_keep_their_asm_invariants():
+    """Static check (tools/check_lstm_asm.py analyse_column_split) of every lstm2_coop / lstm2_coopn instantiation:
+    MFMAs present, no scratch inside the time loop, no buffer_wbl2 / buffer_inv (the write-through hand-off
+    of csrc/lstm_common.h needs no cache maintenance) and the exchange images really are read / written with sc1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_column_split()
+    assert len(res) >= 18, sorted(res)
+    for name, r in res.items():
+        assert r["mfma"] >= 48, (name, r)
+        assert r["scratch_in_loop"] == 0 and r["cache_maint"] == 0, (name, r)
+        assert r["sc1_loads"] > 0 and r["sc1_stores"] > 0, (name, r)

@@ -44,6 +44,29 @@ def analyse(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_column_split(flags=("-fno-slp-vectorize",)):
+    """Whole-kernel invariants of the column-split kernels (lstm_coop.hip, lstm_coopn.hip), per instantiation:
+    scratch accesses from the first MFMA on (i.e. inside the time loop), flat accesses (reported only), cache-maintenance
+    instructions (the write-through hand-off needs none), sc1 loads / stores of the exchange images, MFMAs."""
+    res = {}
+    for fn, sym in (("lstm_coop.hip", "_ZN4fsnp17lstm2_coop_kernelI"), ("lstm_coopn.hip", "_ZN4fsnp18lstm2_coopn_kernelI")):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", fn)
+            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                           check=True, capture_output=True)
+            text = open(out).read()
+        for m in re.finditer(r"^(" + sym + r"\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+            name, body = m.group(1), m.group(2).split("\n")
+            first_mfma = next(i for i, l in enumerate(body) if "v_mfma" in l)
+            inloop = body[first_mfma:]                                                            # the time loop and after
+            cnt = lambda seg, pat: sum(1 for x in seg if re.search(pat, x))
+            res[name] = dict(mfma=cnt(body, r"v_mfma"), scratch_in_loop=cnt(inloop, r"scratch_"), flat=cnt(body, r"flat_load|flat_store"),
+                             cache_maint=cnt(body, r"buffer_wbl2|buffer_inv"), sc1_loads=cnt(body, r"buffer_load_dwordx4.*sc1"),
+                             sc1_stores=cnt(body, r"global_store_dword\b.*sc1|buffer_store_dword\b.*sc1"))
+    return res
+
+
 if __name__ == "__main__":
     r = analyse()
     bad = 0
