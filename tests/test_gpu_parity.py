@@ -643,3 +643,20 @@ def test_column_split_exchange_under_load(n, steps):
     m.check_errors()
     for o in outs:
         assert torch.equal(o, quiet)
+
+
+def test_c_abi_argument_errors_are_loud():
+    """Error behaviour behind the Python asserts: too few frames for the TSSE kernels (the reference would fail inside
+    Conv1d, attention_model.py:86), empty batches, wrong frequency count - a RuntimeError with the C message, never a
+    wrong result; the handle keeps working afterwards."""
+    g = Golden("b1_t8_min")
+    m = _model(g.args, g.state_dict())
+    ins = _cuda(g.inputs())
+    ok = m(*ins).cpu().numpy()
+    with pytest.raises(RuntimeError, match="too few frames"):
+        m(*[t[..., :7] for t in ins])                       # T + look_ahead = 9 < kernel size 10
+    with pytest.raises(RuntimeError, match="empty input"):
+        m(*[t[:0] for t in ins])
+    with pytest.raises(AssertionError):
+        m(*[t[:, :, :200] for t in ins])
+    assert np.array_equal(m(*ins).cpu().numpy(), ok)
