@@ -271,7 +271,7 @@ static void build_specs(fsnp_handle* h) {
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
 // base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
 __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
-                                  int batch_offset, int global_batch, int dense_out, int n_base) {
+                                  int batch_offset, int global_batch, int dense_out, int n_base, int groups) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= num_tiles * rt) return;
     const int tile = slot / rt, sl = slot % rt;
@@ -286,14 +286,15 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
         } else if (mode == FSNP_MODE_FULL) {
             r.b = n / F; r.f = n % F;
             r.out_off = ((r.b * 2) * F + r.f) * T;
-        } else {                       // drop_band (feature.py:254-285), num_groups == 2
-            const int Fh = F / 2;
+        } else {                       // drop_band (feature.py:254-285) with G = num_groups_in_drop_band groups:
+            // global sample s keeps bins p + G i (p = s % G, i < (F - F % G) / G); output rows = group 0's samples, group 1's, ...
+            const int G = groups, Fh = F / G;
             r.b = n / Fh;
             const int i = n % Fh;
-            const int s = batch_offset + r.b, p = s & 1;
-            const int n0 = (global_batch + 1) / 2;
-            const int orow = p == 0 ? s / 2 : n0 + (s - 1) / 2;
-            r.f = p + 2 * i;
+            const int s = batch_offset + r.b, p = s % G;
+            int orow = s / G;
+            for (int q = 0; q < p; ++q) orow += (global_batch - q + G - 1) / G;     // samples of the groups in front
+            r.f = p + G * i;
             r.out_off = ((orow * 2) * Fh + i) * T;
         }
     }
@@ -406,11 +407,11 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
     if (after_first) (void)hipEventRecord(after_first, s);
 }
 static void launch_build_rows(const SbPlan& plan, RowDesc* rows, int F, int T, int mode, int batch_offset, int global_batch,
-                              int dense_out, hipStream_t s) {
+                              int dense_out, int groups, hipStream_t s) {
     for (const SbChunk& c : plan.chunks) {
         const int slots = c.num_tiles * c.rps;
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, s, rows + c.slot0, c.nrows, c.num_tiles, c.rps,
-                           F, T, mode, batch_offset, global_batch, dense_out, c.row0);
+                           F, T, mode, batch_offset, global_batch, dense_out, c.row0, groups);
     }
 }
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
@@ -420,7 +421,9 @@ static int fb_coop_units(const fsnp_handle* h, int B) {
     return u > 32 ? 0 : u;
 }
 
-static int rows_per_utt(const fsnp_handle* h, int mode) { return mode == FSNP_MODE_PARITY ? h->F / 2 : h->F; }
+static int rows_per_utt(const fsnp_handle* h, int mode) {
+    return mode == FSNP_MODE_PARITY ? h->F / h->cfg.num_groups_in_drop_band : h->F;
+}
 
 static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     Workspace w{};
@@ -842,6 +845,7 @@ size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames,
 static int forward_impl(fsnp_handle* h, const float* mag, const float* real, const float* imag, bool is_complex,
                         const int64_t strides[3][3], float* out, int32_t batch, int32_t frames,
                         int32_t mode, int32_t batch_offset, int32_t global_batch, void* hip_stream) {
+    if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (!h || !mag || !out || !strides) { set_error("fsnp_forward: null argument"); return 1; }
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
     if (!fsn && !is_complex && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
@@ -854,7 +858,10 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     }
     if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
-    if (mode == FSNP_MODE_PARITY && h->cfg.num_groups_in_drop_band != 2) { set_error("PARITY mode needs num_groups_in_drop_band == 2"); return 2; }
+    if (mode == FSNP_MODE_PARITY && (h->cfg.num_groups_in_drop_band < 2 || global_batch <= h->cfg.num_groups_in_drop_band)) {
+        set_error("PARITY mode needs num_groups_in_drop_band >= 2 and a global batch larger than it (feature.py:263)");
+        return 2;
+    }
     if (batch_offset < 0 || global_batch < batch_offset + batch) { set_error("bad batch_offset/global_batch"); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     Dims d;
@@ -891,7 +898,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     // workspace-only prologue shared by both models: zero the accumulators, describe the sub-band rows
     auto prologue = [&](hipStream_t st) {
         launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
-        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, st);
+        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, st);
     };
 
     if (!fsn) {
@@ -929,7 +936,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int fb_tiles = fb_row_tiles(batch);
         RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * 32, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, 32,
-                           1, frames, 0, 0, 1, 1, 0);
+                           1, frames, 0, 0, 1, 1, 0, 2);
         LstmArgs fa{};
         fa.rows = fb_rows; fa.dense = fptr(w.att); fa.dense_stride = d.FP; fa.md_seq = fbuf.md;
         fa.seq_out = fptr(w.y1);
@@ -1158,7 +1165,7 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
     if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
-    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, s);
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, s);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
@@ -1247,7 +1254,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
     h->have_last = false;
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, 0, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, 0);
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, 0, 2);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.F = 1;

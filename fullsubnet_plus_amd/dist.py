@@ -20,10 +20,11 @@ def shard_bounds(global_batch, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def parity_output_row(sample, global_batch):
-    """Row of the reference's drop_band output that holds global sample `sample` (even samples first)."""
-    n0 = (global_batch + 1) // 2
-    return sample // 2 if sample % 2 == 0 else n0 + (sample - 1) // 2
+def parity_output_row(sample, global_batch, num_groups=2):
+    """Row of the reference's drop_band output that holds global sample `sample`: the samples of group 0
+    (sample % num_groups == 0) come first, then group 1's, ... (feature.py:270-283)."""
+    g = sample % num_groups
+    return sum(-(-(global_batch - q) // num_groups) for q in range(g)) + sample // num_groups
 
 
 def forward_sharded(model, noisy_mag, noisy_real=None, noisy_imag=None, gather=True, group=None):
@@ -39,13 +40,14 @@ def forward_sharded(model, noisy_mag, noisy_real=None, noisy_imag=None, gather=T
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = noisy_mag.shape[0]
     lo, hi = shard_bounds(B, rank, world)
-    parity = B > 1 and model.batch_mode == "parity"
+    groups = getattr(model, "num_groups_in_drop_band", 2)
+    parity = B > 1 and model.batch_mode == "parity" and groups > 1
     sl = slice(lo, hi)
     if hi > lo:
         ins = [noisy_mag[sl]] if noisy_real is None else [noisy_mag[sl], noisy_real[sl], noisy_imag[sl]]
         out = model(*ins, batch_offset=lo, global_batch=B)
     else:
-        F = model.num_freqs // 2 if parity else model.num_freqs
+        F = model.num_freqs // groups if parity else model.num_freqs
         out = torch.zeros((B if parity else 0, 2, F, noisy_mag.shape[-1]), dtype=torch.float32, device=noisy_mag.device)
     if not gather or world == 1:
         return out

@@ -200,14 +200,13 @@ class _HipModel(nn.Module):
             assert gb > self.num_groups_in_drop_band, \
                 f"Batch size = {gb}, num_groups = {self.num_groups_in_drop_band}. " \
                 f"The batch size should larger than the num_groups."
-            if self.num_groups_in_drop_band != 2:
-                raise NotImplementedError("HIP path: drop_band with num_groups != 2 is not built yet")
+            parity = self.num_groups_in_drop_band > 1        # drop_band with one group returns its input (feature.py:265)
         if not complex_in:
             ins = [t if t.dtype == torch.float32 else t.float() for t in ins]
         for t in ins:
             assert t.device == device
         lib = self._ensure_handle(device)
-        out_f = num_freqs // 2 if parity else num_freqs
+        out_f = num_freqs // self.num_groups_in_drop_band if parity else num_freqs
         standalone = global_batch is None
         out = torch.empty((gb if parity else batch_size, 2, out_f, num_frames), dtype=torch.float32, device=device)
         if parity and not standalone:

@@ -76,6 +76,8 @@ CASES = [
          inp=("spec", 1, 24, 18), stages=False),
     dict(name="tcn_b3_t20_harsh", wseed=19, profile="harsh", args={"sequence_model": "TCN"},
          inp=("spec", 3, 20, 19), stages=False),
+    dict(name="b5_t16_groups3", wseed=20, profile="harsh", args={"num_groups_in_drop_band": 3},
+         inp=("spec", 5, 16, 20), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -259,7 +261,8 @@ def main():
               f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e}"
         if mag.shape[-1] <= 40 and args["channel_attention_model"] == "TSSE" and args["sequence_model"] == "LSTM":
             sdn = {k: v.numpy() for k, v in sd.items()}
-            on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kw)
+            kwn = {k: v for k, v in kw.items() if k != "channel_attention_model"}
+            on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kwn)
             msg += f" numpy64-vs-ref64 {np.abs(on[:, :, ::sub, :] - payload['out64']).max() / scale:.2e}"
         print(msg, f"[{os.path.getsize(path) / 1024:.0f} KB]", flush=True)
 

@@ -31,6 +31,11 @@ def test_parity_rows_match_drop_band_order():
         order = list(range(0, B, 2)) + list(range(1, B, 2))
         for s in range(B):
             assert order[fdist.parity_output_row(s, B)] == s
+    for G in (3, 4):                                          # num_groups_in_drop_band != 2
+        for B in (G + 1, 7, 10):
+            order = [s for g in range(G) for s in range(g, B, G)]
+            for s in range(B):
+                assert order[fdist.parity_output_row(s, B, G)] == s
 
 
 class _OracleShardModel:
