@@ -83,6 +83,7 @@ struct fsnp_handle {
     const float* fsn_bf = nullptr;   // [F pad 384]
     int fsn_kp = 0;
     const float* d_refl_w = nullptr;
+    const float* d_refl_wfb = nullptr;
 
     unsigned char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -500,7 +501,7 @@ const char* fsnp_version(void) { return "fsnp-hip 0.1 (gfx950)"; }
 int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (!cfg || !out) { set_error("fsnp_create: null argument"); return 1; }
     *out = nullptr;
-    if (cfg->fb_num_neighbors != 0) { set_error("fb_num_neighbors != 0 is not supported by the HIP path"); return 2; }
+    if (cfg->fb_num_neighbors < 0) { set_error("fb_num_neighbors must be >= 0"); return 2; }
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
     if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
@@ -513,9 +514,9 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (fsn && cfg->sequence_model == FSNP_SEQ_TCN) { set_error("FullSubNet only supports GRU and LSTM"); return 2; }
     if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
     if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
-    const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3);
-    if (nin > 40) { set_error("sb_num_neighbors too large for the KX=40 LSTM instantiation"); return 2; }
-    if (cfg->num_freqs <= cfg->sb_num_neighbors) { set_error("num_freqs must exceed sb_num_neighbors (reflect pad)"); return 2; }
+    const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3) * (2 * cfg->fb_num_neighbors + 1);
+    if (nin > 40) { set_error("sb_num_neighbors / fb_num_neighbors too large: the sub-band input has %d features, the KX=40 kernel instantiation takes 40", nin); return 2; }
+    if (cfg->num_freqs <= cfg->sb_num_neighbors || cfg->num_freqs <= cfg->fb_num_neighbors) { set_error("num_freqs must exceed the neighbour counts (reflect pad)"); return 2; }
     for (int c = 0; c < 3; ++c)
         if (cfg->kersize[c] < 1 || cfg->kersize[c] > 16) { set_error("kersize must be in [1,16]"); return 2; }
     int ndev = 0;
@@ -800,9 +801,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
     const size_t o_wfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.weight");
     const size_t o_bfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.bias");
     // ---- unfold multiplicities w_r, by brute force over (f, j)
-    const size_t o_refl = alloc(F);
-    for (int f = 0; f < F; ++f)
+    const size_t o_refl = alloc(F), o_reflfb = alloc(F);
+    for (int f = 0; f < F; ++f) {
         for (int j = 0; j < h->NSB; ++j) blob[o_refl + reflect_index(f - h->cfg.sb_num_neighbors + j, F)] += 1.0f;
+        for (int j = 0; j < 2 * h->cfg.fb_num_neighbors + 1; ++j) blob[o_reflfb + reflect_index(f - h->cfg.fb_num_neighbors + j, F)] += 1.0f;
+    }
 
     FSNP_HIP_CHECK(hipSetDevice(h->device));
     drop_graphs(h);
@@ -832,6 +835,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
     }
     h->d_refl_w = d + o_refl;
+    h->d_refl_wfb = d + o_reflfb;
     h->committed = true;
     (void)Fr;
     return 0;
@@ -891,7 +895,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     SubbandBuffers sbuf;
-    sbuf.att_mag = fptr(w.att); sbuf.fb = fptr(w.fb); sbuf.refl_w = h->d_refl_w;
+    sbuf.att_mag = fptr(w.att); sbuf.fb = fptr(w.fb); sbuf.refl_w = h->d_refl_w; sbuf.refl_wfb = h->d_refl_wfb;
+    sbuf.NFBN = h->cfg.fb_num_neighbors;
     sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
     sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
     sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
@@ -958,6 +963,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         ga.rows = rows; ga.md_utt = sbuf.md_utt; ga.md_row = sbuf.md_row;
         ga.x = fptr(w.sbt_x0); ga.xstride = h->XS;
         ga.num_slots = num_slots; ga.Tp = d.Tp; ga.FP = d.FP; ga.F = d.F; ga.NSBN = h->cfg.sb_num_neighbors; ga.NIN = h->NIN;
+        ga.NFBN = h->cfg.fb_num_neighbors;
         launch_sb_gather(ga, s);
         Dims ds = d;
         ds.B = num_slots; ds.F = h->NIN; ds.FP = h->XS;
@@ -984,6 +990,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     a.out = out;
     a.out_stride_o = (long)rows_per_utt(h, mode) * frames;
     a.num_rows = num_rows; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
+    a.NFBN = h->cfg.fb_num_neighbors;
     a.act = h->cfg.sb_act;
     launch_sb_lstm(h, plan, a, fptr(w.coop_hx), reinterpret_cast<unsigned*>(base + w.coop_bar), s, h->timing ? rec.e[3] : nullptr);
     if (h->timing) {

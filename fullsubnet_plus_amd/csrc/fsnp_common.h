@@ -115,7 +115,9 @@ void stft_build_matrices(int n_fft, float* fwd /*[N2 pad 384][n_fft]*/, float* i
 struct SubbandBuffers {
     const float* att_mag;  // [B][Tp][FP]
     const float* fb;       // [NFB][B][Tp][FP]  NFB = NIN - NSB full-band branches (3: FullSubNet+, 1: FullSubNet)
-    const float* refl_w;   // [F] multiplicity of each frequency row inside the unfold
+    const float* refl_w;   // [F] multiplicity of each frequency row inside the unfold of the magnitude (sb_num_neighbors)
+    const float* refl_wfb; // [F] the same for the unfold of the full-band outputs (fb_num_neighbors; all ones for 0)
+    int NFBN;
     double* acc;           // [B][2]  (sum, sumsq) over the whole [F,NIN,Tp] tensor, zeroed per forward
     NormMD* md_utt;        // [B]
     NormMD* md_row;        // [Nrows][Tp] (cumulative norms only)
@@ -131,7 +133,7 @@ struct SbGatherArgs {
     const float* att_mag; int fb_rel, fb_branch_stride;
     const RowDesc* rows; const NormMD* md_utt; const NormMD* md_row;
     float* x; int xstride;
-    int num_slots, Tp, FP, F, NSBN, NIN;
+    int num_slots, Tp, FP, F, NSBN, NFBN, NIN;
 };
 void launch_sb_gather(const SbGatherArgs& a, hipStream_t s);
 void launch_sb_scatter(const float* y, int ystride, const RowDesc* rows, float* out, long out_stride_o, int num_slots,
@@ -173,6 +175,7 @@ struct LstmArgs {
     int num_tiles;         // workgroups; rows[] holds num_tiles * (32 + ex) slots
     int ex;                // VALU rows per tile: 0, 1, 2 or 4
     int Tp, LA, FP, F, NSBN;  // NSBN = sb_num_neighbors
+    int NFBN;                 // fb_num_neighbors
     int act;               // FSNP_ACT_* on the Linear output
     unsigned long long* prof;  // optional [Tp][8] s_memtime stamps of workgroup 0 (debug)
     // column-split (cooperative) kernel only
@@ -228,6 +231,16 @@ __host__ __device__ inline int reflect_index(int i, int F) {
     if (i < 0) i = -i;
     if (i >= F) i = 2 * (F - 1) - i;
     return i;
+}
+
+// Float offset (from att_mag) of feature j of the sub-band input of frequency f, frame 0 of utterance base
+// (fullsubnet_plus.py:167-188 / fullsubnet.py:91-100): the 2 nsbn + 1 reflect-padded neighbours of the (attention)
+// magnitude, then for every full-band branch its 2 nfbn + 1 reflect-padded neighbours (BaseModel.unfold, base_model.py:15-47).
+__host__ __device__ inline int sb_feature_offset(int j, int f, int base, int F, int nsbn, int nfbn, int fb_rel, int fb_branch_stride) {
+    const int nsb = 2 * nsbn + 1;
+    if (j < nsb) return base + reflect_index(f - nsbn + j, F);
+    const int nfb = 2 * nfbn + 1, jj = j - nsb;
+    return fb_rel + (jj / nfb) * fb_branch_stride + base + reflect_index(f - nfbn + jj % nfb, F);
 }
 
 }  // namespace fsnp

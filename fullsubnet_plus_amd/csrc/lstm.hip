@@ -286,10 +286,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     auto plan = [&](const RowDesc& rd, int j) -> int {
         if (!rd.valid || j >= w.NIN) return -1;
         if (dense) return rd.b * Tp * w.NIN + j;           // rd.b = sequence index in dense mode
-        const int base = rd.b * Tp * a.FP;
-        const int nsb = 2 * a.NSBN + 1;
-        return (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
-                         : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
+        return sb_feature_offset(j, rd.f, rd.b * Tp * a.FP, a.F, a.NSBN, a.NFBN, a.fb_rel, a.fb_branch_stride);
     };
     auto row_md = [&](const RowDesc& rd, int slot, NormMD& md, const NormMD*& md_row) {
         md.m = 0.0f; md.d = 1.0f; md_row = nullptr;

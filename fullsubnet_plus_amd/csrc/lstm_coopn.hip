@@ -159,12 +159,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             int off = -1;
             if (rd.valid && j < w.NIN) {
                 if (dense) off = rd.b * Tp * gstep + j;
-                else {
-                    const int base = rd.b * Tp * a.FP;
-                    const int nsb = 2 * a.NSBN + 1;
-                    off = (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
-                                    : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
-                }
+                else off = sb_feature_offset(j, rd.f, rd.b * Tp * a.FP, a.F, a.NSBN, a.NFBN, a.fb_rel, a.fb_branch_stride);
             }
             goff[r][i] = off;
         }

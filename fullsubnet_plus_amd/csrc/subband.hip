@@ -36,12 +36,13 @@ constexpr int SB_ROWS = 16;
 __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
                                                                const float* __restrict__ fb, long fb_bs, int nfb,
                                                                const float* __restrict__ refl_w,
+                                                               const float* __restrict__ refl_wfb,
                                                                double* __restrict__ acc, int Tp, int F, int FP) {
     __shared__ double red[8];
     const int b = blockIdx.y, t0 = blockIdx.x * SB_ROWS, t1 = min(t0 + SB_ROWS, Tp);
     double s = 0.0, q = 0.0;
     for (int f = threadIdx.x; f < F; f += 256) {
-        const double wr = refl_w[f];
+        const double wr = refl_w[f], wfb = refl_wfb[f];
         for (int t = t0; t < t1; ++t) {
             const long i = ((long)b * Tp + t) * FP + f;
             const double a = att_mag[i];
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __re
             q += wr * a * a;
             for (int k = 0; k < nfb; ++k) {
                 const double v = fb[k * fb_bs + i];
-                s += v;
-                q += v * v;
+                s += wfb * v;
+                q += wfb * v * v;
             }
         }
     }
@@ -75,7 +76,7 @@ __global__ void sb_offline_final_kernel(const double* __restrict__ acc, NormMD* 
 __global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restrict__ att_mag,
                                                            const float* __restrict__ fb, long fb_bs,
                                                            const RowDesc* __restrict__ rows, NormMD* __restrict__ md_row,
-                                                           int num_slots, int Tp, int F, int FP, int nsbn, int nin,
+                                                           int num_slots, int Tp, int F, int FP, int nsbn, int nfbn, int nin,
                                                            int norm_type) {
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= num_slots) return;
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restri
             const double v = att_mag[base + reflect_index(rd.f - nsbn + j, F)];
             s += v; q += v * v;
         }
-        for (int k = 0; k < nin - nsb; ++k) {
-            const double v = fb[k * fb_bs + base + rd.f];
+        for (int j = nsb; j < nin; ++j) {
+            const double v = att_mag[sb_feature_offset(j, rd.f, 0, F, nsbn, nfbn, (int)(fb - att_mag), (int)fb_bs) + base];
             s += v; q += v * v;
         }
         cs += s; cq += q;
@@ -104,12 +105,12 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
     const long fb_bs = (long)d.B * d.Tp * d.FP;
     if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
         hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, SB_ROWS), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
-                           fb_bs, d.NIN - d.NSB, buf.refl_w, buf.acc, d.Tp, d.F, d.FP);
+                           fb_bs, (d.NIN - d.NSB) / (2 * buf.NFBN + 1), buf.refl_w, buf.refl_wfb, buf.acc, d.Tp, d.F, d.FP);
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);
     } else {
         hipLaunchKernelGGL(sb_cumulative_kernel, dim3(cdiv(num_slots, 64)), dim3(64), 0, s, buf.att_mag, buf.fb, fb_bs,
-                           rows, buf.md_row, num_slots, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, d.NIN, norm_type);
+                           rows, buf.md_row, num_slots, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, buf.NFBN, d.NIN, norm_type);
     }
 }
 
@@ -118,14 +119,11 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
 __global__ __launch_bounds__(256) void sb_gather_kernel(SbGatherArgs a) {
     const int slot = blockIdx.x;
     const RowDesc rd = a.rows[slot];
-    const int nsb = 2 * a.NSBN + 1;
     for (int i = threadIdx.x; i < a.Tp * a.xstride; i += 256) {
         const int t = i / a.xstride, j = i % a.xstride;
         float v = 0.0f;
         if (rd.valid && j < a.NIN) {
-            const int base = (rd.b * a.Tp + t) * a.FP;
-            const int off = (j < nsb) ? base + reflect_index(rd.f - a.NSBN + j, a.F)
-                                      : a.fb_rel + (j - nsb) * a.fb_branch_stride + base + rd.f;
+            const int off = sb_feature_offset(j, rd.f, (rd.b * a.Tp + t) * a.FP, a.F, a.NSBN, a.NFBN, a.fb_rel, a.fb_branch_stride);
             const NormMD m = a.md_row ? a.md_row[(size_t)slot * a.Tp + t] : a.md_utt[rd.b];
             v = (a.att_mag[off] - m.m) / m.d;
         }

@@ -439,8 +439,8 @@ class FullSubNet_Plus(_HipModel):
             raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
         if subband_num != 1:
             raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
-        if fb_num_neighbors != 0:
-            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
+        if (sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1) > 40:
+            raise NotImplementedError("HIP path: more than 40 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
@@ -552,8 +552,8 @@ class FullSubNet(_HipModel):
                  ):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if fb_num_neighbors != 0:
-            raise NotImplementedError("HIP path: fb_num_neighbors != 0 is not built yet")
+        if (sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1) > 40:
+            raise NotImplementedError("HIP path: more than 40 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")

@@ -78,7 +78,7 @@ typedef struct fsnp_config {
     int32_t num_freqs;          /* 257 */
     int32_t look_ahead;         /* 2   */
     int32_t sb_num_neighbors;   /* 15  */
-    int32_t fb_num_neighbors;   /* 0 (only 0 is supported by the HIP path) */
+    int32_t fb_num_neighbors;   /* 0; > 0 as long as the sub-band input (2 sb + 1) + branches (2 fb + 1) has <= 40 features */
     int32_t tcn_hidden;         /* 512: TCNBlock hidden_channel (causal_conv.py:68) */
     int32_t num_tcn_blocks;     /* 8, dilations 1,2,5,9,1,2,5,9 (sequence_model.py:48-57) */
     int32_t sb_hidden;          /* 384: sb_model_hidden_size */

@@ -78,6 +78,10 @@ CASES = [
          inp=("spec", 3, 20, 19), stages=False),
     dict(name="b5_t16_groups3", wseed=20, profile="harsh", args={"num_groups_in_drop_band": 3},
          inp=("spec", 5, 16, 20), stages=False),
+    # fb_num_neighbors > 0: the full-band outputs are unfolded too (fullsubnet_plus.py:170-184); 31 + 3 x 3 = 40 features
+    dict(name="b3_t16_fbn1", wseed=21, profile="harsh", args={"fb_num_neighbors": 1}, inp=("spec", 3, 16, 21), stages=False),
+    dict(name="b1_t30_fbn1_cum_layer", wseed=22, profile="default", args={"fb_num_neighbors": 1, "norm_type": "cumulative_layer_norm"},
+         inp=("spec", 1, 30, 22), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -98,6 +102,7 @@ FSN_CASES = [
     dict(name="fsn_b1_2s_default", wseed=8, profile="default", args={}, inp=("stft", 1, 2.0, 28), stages=False),
     dict(name="fsn_gru_b1_t24_harsh_stages", wseed=9, profile="harsh", args={"sequence_model": "GRU"},
          inp=("spec", 1, 24, 29), stages=True),
+    dict(name="fsn_b3_t16_fbn2", wseed=11, profile="harsh", args={"fb_num_neighbors": 2}, inp=("spec", 3, 16, 31), stages=False),
     dict(name="fsn_gru_b3_t20_default", wseed=10, profile="default", args={"sequence_model": "GRU"},
          inp=("spec", 3, 20, 30), stages=False),
 ]
@@ -117,7 +122,7 @@ def run_case(case, FullSubNet_Plus):
     torch.manual_seed(0)
     model = FullSubNet_Plus(**args).eval()
     sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"],
-                         sequence_model=args["sequence_model"])
+                         sequence_model=args["sequence_model"], fb_num_neighbors=args["fb_num_neighbors"])
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]
@@ -179,7 +184,8 @@ def run_case_fsn(case, Model):
     args.update(case["args"])
     torch.manual_seed(0)
     model = Model(**args).eval()
-    sd = make_state_dict_fullsubnet(case["wseed"], case["profile"], sequence_model=args["sequence_model"])
+    sd = make_state_dict_fullsubnet(case["wseed"], case["profile"], sequence_model=args["sequence_model"],
+                                    fb_num_neighbors=args["fb_num_neighbors"])
     res = model.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     kind, B, t, iseed = case["inp"]

@@ -33,10 +33,12 @@ class Golden:
     def state_dict(self):
         if self.is_fullsubnet:
             return make_state_dict_fullsubnet(self.meta["wseed"], self.meta["profile"],
-                                              sequence_model=self.args.get("sequence_model", "LSTM"))
+                                              sequence_model=self.args.get("sequence_model", "LSTM"),
+                                              fb_num_neighbors=self.args.get("fb_num_neighbors", 0))
         return make_state_dict(self.meta["wseed"], self.meta["profile"],
                                attention=self.args.get("channel_attention_model", "TSSE"),
-                               sequence_model=self.args.get("sequence_model", "LSTM"))
+                               sequence_model=self.args.get("sequence_model", "LSTM"),
+                               fb_num_neighbors=self.args.get("fb_num_neighbors", 0))
 
     def inputs(self):
         inp = self.meta["inp"]
