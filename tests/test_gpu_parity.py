@@ -660,3 +660,17 @@ def test_c_abi_argument_errors_are_loud():
     with pytest.raises(AssertionError):
         m(*[t[:, :, :200] for t in ins])
     assert np.array_equal(m(*ins).cpu().numpy(), ok)
+
+
+def test_subband_tcn_with_cumulative_norm_vs_oracle():
+    """sequence_model="TCN" + cumulative_layer_norm: the materialised sub-band input uses the per-sequence (m_t, d_t)
+    tables (sb_cumulative_kernel -> sb_gather_kernel)."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": "TCN", "norm_type": "cumulative_layer_norm"}
+    sd = make_state_dict(34, "harsh", sequence_model="TCN")
+    cpu_in = make_spec(3, 18, 303)
+    m = _model(args, sd, "parity")
+    out = m(*_cuda(cpu_in)).cpu().numpy()
+    want = fsnp_torch.forward(sd, *cpu_in, norm_type="cumulative_layer_norm").numpy()
+    err = rel_err(out, want)
+    _record("subband_tcn_cumulative_layer", rel=err)
+    assert out.shape == want.shape and err < TOL, err
