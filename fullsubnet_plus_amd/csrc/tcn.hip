@@ -13,6 +13,8 @@
 // fp64 slot with one atomic pair per workgroup (row tiles never straddle utterances); the consuming
 // kernel applies the per-utterance scalars + per-channel affine while it loads its operand, so no
 // normalised tensor is ever written.
+#include <cstdlib>
+
 #include "fsnp_common.h"
 
 namespace fsnp {
@@ -237,6 +239,8 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
 // ceil(blocks / CUs) * BN; pick the BN in {64, 96, 128} that minimises it (ties -> the narrower tile: more,
 // smaller workgroups balance better).  Weights are zero-padded to a multiple of 384 rows so any choice is valid.
 static int pick_bn(int n, int row_tiles, int num_cus, int branches) {
+    static const int forced = [] { const char* e = getenv("FSNP_GEMM_BN"); return e ? atoi(e) : 0; }();   // tuning override
+    if (forced == 64 || forced == 96 || forced == 128) return forced;
     int best = 64;
     long best_cost = -1;
     const int cand[3] = {64, 96, 128};
