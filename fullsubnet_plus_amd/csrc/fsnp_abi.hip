@@ -1234,6 +1234,23 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
     return 0;
 }
 
+int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
+                         int32_t* out, int32_t max_chunks) {
+    if (!out || num_rows <= 0 || num_cus <= 0 || hidden % 128 != 0 || max_chunks <= 0) { set_error("fsnp_debug_plan_rows: bad argument"); return -1; }
+    fsnp_handle h;                      // host-only: the planner never touches the device
+    h.H = hidden; h.num_cus = num_cus; h.num_cus_real = num_cus; h.gru = gru; h.lstm_coop = coop; h.composite_gain = composite_gain;
+    const SbPlan plan = plan_sb(&h, num_rows);
+    int n = 0;
+    for (const SbChunk& c : plan.chunks) {
+        if (n >= max_chunks) break;
+        int32_t* o = out + 8 * n;
+        o[0] = c.kind; o[1] = c.row0; o[2] = c.nrows; o[3] = c.num_tiles; o[4] = c.ex; o[5] = c.kind == 1 ? c.units : c.groups;
+        o[6] = c.rpg; o[7] = c.slot0;
+        ++n;
+    }
+    return n;
+}
+
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks) {
     if (!h || !out || batch <= 0 || max_chunks <= 0) { set_error("fsnp_describe_plan: bad argument"); return -1; }
     const SbPlan plan = plan_sb(h, batch * rows_per_utt(h, mode));

@@ -306,3 +306,53 @@ def test_column_split_kernels_keep_their_asm_invariants():
         assert r["mfma"] >= 48, (name, r)
         assert r["scratch_in_loop"] == 0 and r["cache_maint"] == 0, (name, r)
         assert r["sc1_loads"] > 0 and r["sc1_stores"] > 0, (name, r)
+
+
+# ---------------------------------------------------------------- sub-band planner (fsnp_abi.hip plan_sb), host only
+def _plan(rows, cus=256, gru=0, coop=1, gain=0.97):
+    import ctypes as ct
+    lib = _lib.load()
+    buf = (ct.c_int32 * (8 * 64))()
+    n = lib.fsnp_debug_plan_rows(rows, cus, 384, gru, coop, gain, buf, 64)
+    assert n > 0, lib.fsnp_last_error()
+    keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
+    return [dict(zip(keys, buf[8 * i:8 * i + 8])) for i in range(n)]
+
+
+@pytest.mark.parametrize("gru", [0, 1])
+@pytest.mark.parametrize("rows", [1, 31, 257, 514, 1285, 1344, 1345, 1542, 2056, 4112, 5440, 5441, 5654, 8192, 8224, 8481,
+                                  9252, 10280, 12336, 16448, 24672, 65792])
+def test_subband_plans_cover_every_sequence_and_fit_the_chip(rows, gru):
+    """Every plan: chunks are consecutive, cover [0, rows), their slots do not overlap, every tile holds <= 32 + ex
+    sequences, and the column-split chunks are co-resident by construction (workgroups <= CUs)."""
+    chunks = _plan(rows, gru=gru)
+    nxt, slot = 0, 0
+    for c in chunks:
+        assert c["row0"] == nxt and c["slot0"] == slot and c["rows"] > 0
+        nxt += c["rows"]
+        slot += c["tiles"] * (32 + c["ex"])
+        assert c["tiles"] * (32 + c["ex"]) >= c["rows"]
+        if c["kind"] == 1:
+            assert c["par"] in (8, 16, 32, 64) and c["tiles"] * (384 // c["par"]) <= 256
+        elif c["kind"] == 2:
+            assert c["rpg"] in (1, 2) and c["par"] * 3 <= 256 and c["par"] * c["rpg"] >= c["tiles"]
+        else:
+            assert not gru, "there is no row-tile GRU kernel"
+    assert nxt == rows
+
+
+def test_subband_plan_choices_match_the_design():
+    """The cuts DESIGN.md 4.1 / 4.1b describe, for the batch sizes of BASELINE.json and of the tables in profiles/."""
+    kinds = lambda rows, **kw: [(c["kind"], c["rows"]) for c in _plan(rows, **kw)]
+    assert kinds(257) == [(1, 257)] and _plan(257)[0]["par"] == 16                 # B = 1: K split, 16 units
+    assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
+    assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
+    assert kinds(4096) == [(2, 4096)] and _plan(4096)[0]["rpg"] == 2                # parity-mode B = 32: 128 tiles
+    assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
+    assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
+    assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
+    assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
+    assert kinds(8224, coop=0) == [(0, 8224)] and _plan(8224, coop=0)[0]["ex"] == 1  # column-split kernels off: VALU rows
+    assert kinds(8224, gain=0.0) == [(0, 8224)]                                     # composite plans off
+    g = kinds(65792, gru=1)                                                         # GRU, B = 256: chunks of <= 170 tiles,
+    assert [k for k, _ in g[:-1]] == [2] * 12 and g[-1] == (1, 65792 - 12 * 5440)   # the short last one K split
