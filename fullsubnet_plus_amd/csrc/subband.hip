@@ -72,31 +72,52 @@ __global__ void sb_offline_final_kernel(const double* __restrict__ acc, NormMD* 
     if (b < B) md_utt[b] = sb_norm_md(norm_type, acc[b * 2], acc[b * 2 + 1], count);
 }
 
-// one thread per sub-band sequence, serial in t (cumulative norms only)
-__global__ __launch_bounds__(64) void sb_cumulative_kernel(const float* __restrict__ att_mag,
-                                                           const float* __restrict__ fb, long fb_bs,
-                                                           const RowDesc* __restrict__ rows, NormMD* __restrict__ md_row,
-                                                           int num_slots, int Tp, int F, int FP, int nsbn, int nfbn, int nin,
-                                                           int norm_type) {
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= num_slots) return;
+// cumulative norms: one workgroup per sub-band sequence.  Every thread sums the NIN features of its frames
+// (t = tid, tid + 256, ...) in fp64, then a workgroup-wide inclusive scan over t turns the per-frame (sum, sumsq) into the
+// running statistics of base_model.py:237-258 / 288-316.  (A thread per sequence, serial in t, took 2.8 ms for 10 s clips.)
+__global__ __launch_bounds__(256) void sb_cumulative_kernel(const float* __restrict__ att_mag,
+                                                            const float* __restrict__ fb, long fb_bs,
+                                                            const RowDesc* __restrict__ rows, NormMD* __restrict__ md_row,
+                                                            int num_slots, int Tp, int F, int FP, int nsbn, int nfbn, int nin,
+                                                            int norm_type) {
+    __shared__ double wsum[4][2];
+    __shared__ double carry[2];
+    const int row = blockIdx.x;
     const RowDesc rd = rows[row];
-    if (!rd.valid) return;
-    double cs = 0.0, cq = 0.0;
+    if (!rd.valid) return;                               // uniform per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsb = 2 * nsbn + 1;
-    for (int t = 0; t < Tp; ++t) {
-        const long base = ((long)rd.b * Tp + t) * FP;
+    if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
+    __syncthreads();
+    for (int t0 = 0; t0 < Tp; t0 += 256) {
+        const int t = t0 + tid;
         double s = 0.0, q = 0.0;
-        for (int j = 0; j < nsb; ++j) {
-            const double v = att_mag[base + reflect_index(rd.f - nsbn + j, F)];
-            s += v; q += v * v;
+        if (t < Tp) {
+            const long base = ((long)rd.b * Tp + t) * FP;
+            for (int j = 0; j < nsb; ++j) {
+                const double v = att_mag[base + reflect_index(rd.f - nsbn + j, F)];
+                s += v; q += v * v;
+            }
+            for (int j = nsb; j < nin; ++j) {
+                const double v = att_mag[sb_feature_offset(j, rd.f, 0, F, nsbn, nfbn, (int)(fb - att_mag), (int)fb_bs) + base];
+                s += v; q += v * v;
+            }
         }
-        for (int j = nsb; j < nin; ++j) {
-            const double v = att_mag[sb_feature_offset(j, rd.f, 0, F, nsbn, nfbn, (int)(fb - att_mag), (int)fb_bs) + base];
-            s += v; q += v * v;
+        // inclusive scan over the 256 frames of this chunk: within the wave, then across the 4 waves, plus the carry
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double us = __shfl_up(s, o), uq = __shfl_up(q, o);
+            if (lane >= o) { s += us; q += uq; }
         }
-        cs += s; cq += q;
-        md_row[(long)row * Tp + t] = sb_norm_md(norm_type, cs, cq, (double)nin * (t + 1));
+        if (lane == 63) { wsum[wave][0] = s; wsum[wave][1] = q; }
+        __syncthreads();
+        double cs = carry[0], cq = carry[1];
+        for (int wv = 0; wv < wave; ++wv) { cs += wsum[wv][0]; cq += wsum[wv][1]; }
+        s += cs; q += cq;
+        if (t < Tp) md_row[(long)row * Tp + t] = sb_norm_md(norm_type, s, q, (double)nin * (t + 1));
+        __syncthreads();
+        if (tid == 255) { carry[0] = s; carry[1] = q; }
+        __syncthreads();
     }
 }
 
@@ -109,7 +130,7 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);
     } else {
-        hipLaunchKernelGGL(sb_cumulative_kernel, dim3(cdiv(num_slots, 64)), dim3(64), 0, s, buf.att_mag, buf.fb, fb_bs,
+        hipLaunchKernelGGL(sb_cumulative_kernel, dim3(num_slots), dim3(256), 0, s, buf.att_mag, buf.fb, fb_bs,
                            rows, buf.md_row, num_slots, d.Tp, d.F, d.FP, (d.NSB - 1) / 2, buf.NFBN, d.NIN, norm_type);
     }
 }
