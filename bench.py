@@ -119,8 +119,8 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fullsubnet_plus_amd import FullSubNet, FullSubNet_Plus
-    from oracle.ref_loader import DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS
-    from oracle.weights import make_inputs, make_state_dict, make_state_dict_fullsubnet
+    from fullsubnet_plus_amd.synthetic import (DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS, make_inputs, make_state_dict,
+                                               make_state_dict_fullsubnet)
 
     fsn = args.model == "fullsubnet"
     if fsn:
@@ -152,7 +152,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     if args.wave:
-        from oracle.weights import make_wave
+        from fullsubnet_plus_amd.synthetic import make_wave
         wav = torch.from_numpy(make_wave(B, args.seconds, 1000 + rank)).to(dev)
 
     def run_once():

@@ -56,41 +56,6 @@ def reference_model_args():
         return tomli.load(f)["model"]["args"]
 
 
-# A frozen copy of config/inference.toml [model.args] so the GPU box (which has no
-# /root/reference) builds the same network.  tests/test_oracle.py asserts it equals
-# reference_model_args() whenever the reference is present.
-DEFAULT_MODEL_ARGS = dict(
-    sb_num_neighbors=15,
-    fb_num_neighbors=0,
-    num_freqs=257,
-    look_ahead=2,
-    sequence_model="LSTM",
-    fb_output_activate_function="ReLU",
-    sb_output_activate_function=False,
-    channel_attention_model="TSSE",
-    fb_model_hidden_size=512,
-    sb_model_hidden_size=384,
-    weight_init=False,
-    norm_type="offline_laplace_norm",
-    num_groups_in_drop_band=2,
-    kersize=[3, 5, 10],
-    subband_num=1,
-)
-
-
-# [model.args] of the original FullSubNet as the reference ships them (commented alternative of
-# config/inference.toml:11,28 -> recipes' fullsubnet config): same values as above minus the FullSubNet+-only keys.
-FULLSUBNET_MODEL_ARGS = dict(
-    sb_num_neighbors=15,
-    fb_num_neighbors=0,
-    num_freqs=257,
-    look_ahead=2,
-    sequence_model="LSTM",
-    fb_output_activate_function="ReLU",
-    sb_output_activate_function=False,
-    fb_model_hidden_size=512,
-    sb_model_hidden_size=384,
-    weight_init=False,
-    norm_type="offline_laplace_norm",
-    num_groups_in_drop_band=2,
-)
+# Frozen copies of the reference's [model.args] live with the synthetic generators (bench.py needs them without importing
+# the test infrastructure); tests/test_oracle.py asserts DEFAULT_MODEL_ARGS == reference_model_args() when the reference is here.
+from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS  # noqa: E402,F401
