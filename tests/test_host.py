@@ -356,3 +356,28 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(8224, gain=0.0) == [(0, 8224)]                                     # composite plans off
     g = kinds(65792, gru=1)                                                         # GRU, B = 256: chunks of <= 170 tiles,
     assert [k for k, _ in g[:-1]] == [2] * 12 and g[-1] == (1, 65792 - 12 * 5440)   # the short last one K split
+
+
+def test_oracle_is_only_reachable_from_the_allowed_places():
+    """The oracle is test infrastructure: the product package never imports it, bench.py only inside its cpu_baseline
+    leg, __graft_entry__ only inside build() (import check of the checker) and smoke()."""
+    import ast
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        found = []
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            for node in ast.iter_child_nodes(fn) if isinstance(fn, ast.Module) else ast.walk(fn):
+                mod = node.module if isinstance(node, ast.ImportFrom) else None
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else []
+                if (mod and mod.split(".")[0] == "oracle") or any(n.split(".")[0] == "oracle" for n in names):
+                    found.append(fn.name if isinstance(fn, ast.FunctionDef) else "<module>")
+        return set(found)
+
+    pkg = os.path.join(ROOT, "fullsubnet_plus_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert oracle_imports(os.path.join(pkg, f)) == set(), f
+    assert oracle_imports(os.path.join(ROOT, "bench.py")) <= {"cpu_baseline"}
+    # build() may BUILD the checker (here: import-check the pure-Python restatements), smoke() uses it
+    assert oracle_imports(os.path.join(ROOT, "__graft_entry__.py")) <= {"build", "smoke"}
