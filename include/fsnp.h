@@ -218,9 +218,11 @@ int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
  * as the failed launch has completed - a wrong result is never silent for long. */
 int fsnp_check_errors(fsnp_handle* h);
 
-/* Tuning hook: 1 (default) = use the column-split cooperative LSTM kernel (csrc/lstm_coop.hip) whenever
- * row_tiles * H/32 workgroups fit the chip (small batches, e.g. the reference CLI's batch of one); 0 = never
- * (also FSNP_LSTM_COOP=0 at fsnp_create time). */
+/* Tuning hook: 1 (default) = the sub-band sequences are planned over all three kernels - the column-split kernels
+ * (csrc/lstm_coop.hip <= 42 row tiles, csrc/lstm_coopn.hip 43..170; all their workgroups must be co-resident) for small
+ * batches and for the remainder of larger ones, the one-tile-per-CU kernel for full rounds (fsnp_describe_plan shows the
+ * cut); 0 = the one-tile-per-CU kernel only (also FSNP_LSTM_COOP=0 at fsnp_create time; use it when the GPU is shared
+ * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
 /* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
  * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph
