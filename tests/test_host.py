@@ -381,3 +381,24 @@ def test_oracle_is_only_reachable_from_the_allowed_places():
     assert oracle_imports(os.path.join(ROOT, "bench.py")) <= {"cpu_baseline"}
     # build() may BUILD the checker (here: import-check the pure-Python restatements), smoke() uses it
     assert oracle_imports(os.path.join(ROOT, "__graft_entry__.py")) <= {"build", "smoke"}
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """include/fsnp.h compiles as C99 with -Wall -Werror -pedantic, libfsnp_hip.so links from a plain C program, and the
+    error paths reachable without a GPU return codes + messages (tests/c_abi/abi_check.c)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    _lib.load()
+    from fullsubnet_plus_amd import _build
+    exe = tmp_path / "abi_check"
+    libdir = os.path.dirname(_build.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-o", str(exe), "-L", libdir, "-lfsnp_hip",
+           "-Wl,-rpath," + libdir]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "gfx950" in run.stdout and "bad config rc=2" in run.stdout and "plan chunks=2" in run.stdout
