@@ -685,3 +685,43 @@ def test_subband_tcn_with_cumulative_norm_vs_oracle():
     err = rel_err(out, want)
     _record("subband_tcn_cumulative_layer", rel=err)
     assert out.shape == want.shape and err < TOL, err
+
+
+def test_forward_from_plain_c(tmp_path):
+    """The C ABI is self-sufficient: a plain C program (tests/c_abi/abi_forward.c: fsnp.h + the HIP runtime C API, no
+    Python, no torch) loads the named weights, runs fsnp_forward on its own hipMalloc'ed buffers and reproduces the
+    golden vector of the reference."""
+    import ctypes
+    import shutil
+    import struct
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    from fullsubnet_plus_amd import _build, _lib
+    g = Golden("b3_t20_harsh")
+    m = FullSubNet_Plus(**g.args)
+    sd = g.state_dict()
+    cfg = m._config()
+    (tmp_path / "config.bin").write_bytes(bytes(ctypes.string_at(ctypes.byref(cfg), ctypes.sizeof(cfg))))
+    with open(tmp_path / "weights.bin", "wb") as f:
+        for name, t in sd.items():
+            arr = t.numpy().astype(np.float32).ravel()
+            f.write(struct.pack("<i", len(name)) + name.encode() + struct.pack("<q", arr.size) + arr.tobytes())
+    mag, real, imag = g.inputs()
+    B, _, F, T = mag.shape
+    for nm, t in (("mag", mag), ("real", real), ("imag", imag)):
+        (tmp_path / f"{nm}.bin").write_bytes(t.contiguous().numpy().tobytes())
+    (tmp_path / "dims.bin").write_bytes(struct.pack("<4i", B, F, T, _lib.MODE_PARITY))
+    libdir = os.path.dirname(_build.LIB_PATH)
+    exe = tmp_path / "abi_forward"
+    cmd = ["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", "abi_forward.c"), "-o", str(exe), "-L", libdir, "-lfsnp_hip",
+           "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float32).reshape(g.arrays["out"].shape)
+    err = rel_err(out, g.arrays["out"])
+    _record("forward_from_plain_c", rel=err)
+    assert err < TOL, err
