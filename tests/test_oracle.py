@@ -104,3 +104,19 @@ def test_fullsubnet_state_dict_matches_reference_parameter_tree():
     assert list(sd.keys()) == list(rsd.keys())
     for k in sd:
         assert tuple(sd[k].shape) == tuple(rsd[k].shape), k
+
+
+def test_committed_golden_is_what_the_generator_produces():
+    """tests/golden/*.npz are outputs of the REAL reference produced by oracle/make_golden.py: re-running the generator
+    for one small case here (reference mounted) reproduces the committed arrays (up to thread-count rounding)."""
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted")
+    from oracle import make_golden
+    case = next(c for c in make_golden.CASES if c["name"] == "b1_t8_min")
+    payload, _ = make_golden.run_case(case, ref_loader.load_reference())
+    g = Golden("b1_t8_min")
+    for key in ("out", "out64"):
+        assert rel_err(payload[key], g.arrays[key]) < 1e-6, key
+    fcase = next(c for c in make_golden.FSN_CASES if c["name"] == "fsn_b1_t20_gaussian")
+    fpayload, _ = make_golden.run_case_fsn(fcase, ref_loader.load_reference_fullsubnet())
+    assert rel_err(fpayload["out"], Golden("fsn_b1_t20_gaussian").arrays["out"]) < 1e-6
