@@ -46,6 +46,8 @@ def parse():
                     help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
     ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
                     help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
+    ap.add_argument("--sequence-model", default="LSTM", choices=["LSTM", "GRU", "TCN"],
+                    help="sub-band sequence model (SURVEY.md 8f-4 variants; the headline is LSTM; TCN: FullSubNet+ only)")
     ap.add_argument("--wave", action="store_true",
                     help="time waveform -> waveform (HIP STFT + forward + cIRM + iSTFT, model.enhance_wave) instead of the "
                          "headline forward; extra information, not BASELINE.json's metric")
@@ -125,11 +127,13 @@ def main():
     fsn = args.model == "fullsubnet"
     if fsn:
         assert args.precision == "fp32", "the bf16 ih-GEMM variant is defined for FullSubNet+ only"
-        sd = make_state_dict_fullsubnet(0, "default")
-        model = FullSubNet(**{**FULLSUBNET_MODEL_ARGS, "norm_type": args.norm})
+        sd = make_state_dict_fullsubnet(0, "default", sequence_model=args.sequence_model)
+        model = FullSubNet(**{**FULLSUBNET_MODEL_ARGS, "norm_type": args.norm, "sequence_model": args.sequence_model})
     else:
-        sd = make_state_dict(0, "default")
-        model = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": args.norm})
+        sd = make_state_dict(0, "default", sequence_model=args.sequence_model)
+        model = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": args.norm, "sequence_model": args.sequence_model})
+    if args.sequence_model != "LSTM":
+        assert args.precision == "fp32", "the bf16 ih-GEMM variant exists for the LSTM sub-band model only"
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.batch_mode = args.mode
@@ -220,7 +224,8 @@ def main():
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 + bf16 ih-GEMM (configs[4])",
         "data": "synthetic",
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
-                               f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)",
+                               f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)" +
+                               ("" if args.sequence_model == "LSTM" else f", sequence_model={args.sequence_model}"),
                    "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)"},
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
