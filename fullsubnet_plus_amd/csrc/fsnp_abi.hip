@@ -336,9 +336,9 @@ struct SbPlan {
     std::vector<SbChunk> chunks;
     int total_slots = 0, coop_tiles = 0;
 };
-static double est_step_us(const fsnp_handle* h, const SbChunk& c) {      // measured per-step costs
-    if (c.kind == 1) return 191.0 * c.units / h->H + 11.0;
-    if (c.kind == 2) return c.rpg == 1 ? 79.0 : 153.0;
+static double est_step_us(const fsnp_handle* h, const SbChunk& c) {      // measured per-step costs (profiles/r01_column_split.md)
+    if (c.kind == 1) return c.units <= 8 ? 9.0 : c.units <= 16 ? 19.0 : c.units <= 32 ? 29.0 : 55.0;
+    if (c.kind == 2) return c.rpg == 1 ? 76.0 : 151.0;
     return cdiv(c.num_tiles, h->num_cus) * 208.0 * (1.0 + 0.11 * c.ex);
 }
 static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
@@ -353,6 +353,24 @@ static SbChunk column_chunk(const fsnp_handle* h, int row0, int nrows) {   // ki
     if (c.rpg != 0) c.kind = 2;
     return c;
 }
+// Column-split launches for `nrows` sequences (any count).  A launch costs the same per step whether its kernel is full or
+// not (K split 9..55 us, one row tile per group 76 us, two 151 us), so with G = 85 groups on 256 CUs:
+//   <= 42 tiles: one K-split launch;   43..G: one tile per group;   G+1..G+42: G tiles one per group + the rest K split
+//   (97 tiles: 76 + 29 us instead of 151);   G+43..2G: two tiles per group;   more (GRU only): full 2G launches first.
+static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nrows) {
+    std::vector<SbChunk> out;
+    const int G = h->num_cus_real / (h->H / 128);
+    int r0 = row0, left = nrows;
+    while (cdiv(left, 32) > 2 * G) { out.push_back(column_chunk(h, r0, 2 * G * 32)); r0 += 2 * G * 32; left -= 2 * G * 32; }
+    const int tiles = cdiv(left, 32);
+    if (tiles > G && tiles <= 2 * G && lstm_coop_pick_units(h->H, tiles - G, h->num_cus_real, 8) != 0) {
+        out.push_back(column_chunk(h, r0, G * 32));
+        r0 += G * 32; left -= G * 32;
+    }
+    if (left > 0) out.push_back(column_chunk(h, r0, left));
+    return out;
+}
+
 static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
@@ -362,12 +380,8 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
     const int col_max_rows = 2 * (h->num_cus_real / (h->H / 128)) * 32;      // one lstm_coopn launch: 170 tiles on 256 CUs
-    if (h->gru) {
-        // no row-tile GRU kernel: full chunks of ONE row tile per group (85 tiles on 255 workgroups, 76 us per step - the same
-        // cost per tile as 170-tile chunks, but a short last chunk then costs 76 / 9 us instead of 151), remainder on
-        // whatever column split fits it
-        const int chunk_rows = col_max_rows / 2;
-        for (int r0 = 0; r0 < num_rows; r0 += chunk_rows) push(column_chunk(h, r0, num_rows - r0 < chunk_rows ? num_rows - r0 : chunk_rows));
+    if (h->gru) {                                                             // no row-tile GRU kernel: column-split launches only
+        for (const SbChunk& c : plan_columns(h, 0, num_rows)) push(c);
         return p;
     }
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
@@ -375,17 +389,21 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     // batches, remainder tiles) stay fp32 - more accurate and, there, faster
     if (h->lstm_coop == 0) { push(whole); return p; }
     if (num_rows <= col_max_rows) {
-        const SbChunk c = column_chunk(h, 0, num_rows);
-        push(c.kind != 0 ? c : whole);
+        for (const SbChunk& c : plan_columns(h, 0, num_rows)) push(c);
         return p;
     }
     // full rounds on the row-tile kernel + the remainder on whatever runs it fastest, if that beats VALU rows / one more round
     const int full = h->num_cus * 32, q = num_rows / full, rem = num_rows - q * full;
     if (q >= 1 && rem > 0) {
-        SbChunk rc = rem <= col_max_rows ? column_chunk(h, q * full, rem) : rowtile_chunk(h, q * full, rem);
-        if (rc.kind == 0 && rem <= col_max_rows) rc = rowtile_chunk(h, q * full, rem);
+        std::vector<SbChunk> rc = rem <= col_max_rows ? plan_columns(h, q * full, rem) : std::vector<SbChunk>{rowtile_chunk(h, q * full, rem)};
         const SbChunk main_c{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0};
-        if (est_step_us(h, main_c) + est_step_us(h, rc) < h->composite_gain * est_step_us(h, whole)) { push(main_c); push(rc); return p; }
+        double cost = est_step_us(h, main_c);
+        for (const SbChunk& c : rc) cost += est_step_us(h, c);
+        if (cost < h->composite_gain * est_step_us(h, whole)) {
+            push(main_c);
+            for (const SbChunk& c : rc) push(c);
+            return p;
+        }
     }
     push(whole);
     return p;

@@ -354,9 +354,11 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
     assert kinds(8224, coop=0) == [(0, 8224)] and _plan(8224, coop=0)[0]["ex"] == 1  # column-split kernels off: VALU rows
     assert kinds(8224, gain=0.0) == [(0, 8224)]                                     # composite plans off
-    g = kinds(65792, gru=1)                                                         # GRU, B = 256: chunks of 85 tiles (one per
-    assert [k for k, _ in g[:-1]] == [2] * 24 and g[-1] == (1, 65792 - 24 * 2720)   # group), the short last one K split
-    assert kinds(8224, gru=1) == [(2, 2720)] * 3 + [(1, 64)]                        # GRU, B = 32
+    g = kinds(65792, gru=1)                                                         # GRU, B = 256: full 170-tile launches,
+    assert [k for k, _ in g[:-1]] == [2] * 12 and g[-1] == (1, 65792 - 12 * 5440)   # the short last one K split
+    assert kinds(8224, gru=1) == [(2, 5440), (2, 2720), (1, 64)]                    # GRU, B = 32: 170 + 85 + 2 tiles
+    assert kinds(3084) == [(2, 2720), (1, 364)]                                     # B = 12: 85 tiles one per group + 12 K split
+    assert kinds(4112) == [(2, 4112)] and _plan(4112)[0]["rpg"] == 2                # B = 16: 129 tiles, two per group
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():
