@@ -405,3 +405,17 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "gfx950" in run.stdout and "bad config rc=2" in run.stdout and "plan chunks=2" in run.stdout
+
+
+def test_synthetic_generators_are_frozen():
+    """The seeded weight / waveform generators (fullsubnet_plus_amd/synthetic.py, numpy PCG64) are what the golden fixtures
+    were generated with: known-answer checksums, so a change of generator or numpy stream shows up here and not as a
+    mysterious parity failure."""
+    from fullsubnet_plus_amd.synthetic import make_wave
+    f64 = lambda a: float(np.asarray(a, dtype=np.float64).sum())
+    sd = make_state_dict(0, "default", as_torch=False)
+    assert abs(f64(sd["sb_model.sequence_model.weight_hh_l0"]) - 14.657252892301898) < 1e-6
+    assert abs(f64(sd["fb_model.sequence_model.3.sconv.weight"]) - 1.1025237809649013) < 1e-6
+    assert abs(f64(make_state_dict(4, "harsh", as_torch=False)["sb_model.sequence_model.weight_ih_l1"]) - 19.92727242918871) < 1e-5
+    assert abs(f64(make_state_dict_fullsubnet(3, "harsh", as_torch=False)["fb_model.sequence_model.weight_hh_l1"]) + 15.92294563049542) < 1e-5
+    assert abs(f64(make_wave(2, 0.5, 7)) + 3.7271236432115984) < 1e-6
