@@ -356,16 +356,24 @@ static SbChunk column_chunk(const fsnp_handle* h, int row0, int nrows) {   // ki
 // Column-split launches for `nrows` sequences (any count).  A launch costs the same per step whether its kernel is full or
 // not (K split 9..55 us, one row tile per group 76 us, two 151 us), so with G = 85 groups on 256 CUs:
 //   <= 42 tiles: one K-split launch;   43..G: one tile per group;   G+1..G+42: G tiles one per group + the rest K split
-//   (97 tiles: 76 + 29 us instead of 151);   G+43..2G: two tiles per group;   more (GRU only): full 2G launches first.
+//   (97 tiles: 76 + 29 us instead of 151; up to 5 tiles more: a full K-split launch + a tiny one, 128 tiles = 85 + 42 + 1:
+//   76 + 55 + 9 us);   otherwise up to 2G: two tiles per group;   more (GRU only): full 2G launches first.
 static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nrows) {
     std::vector<SbChunk> out;
     const int G = h->num_cus_real / (h->H / 128);
     int r0 = row0, left = nrows;
     while (cdiv(left, 32) > 2 * G) { out.push_back(column_chunk(h, r0, 2 * G * 32)); r0 += 2 * G * 32; left -= 2 * G * 32; }
-    const int tiles = cdiv(left, 32);
-    if (tiles > G && tiles <= 2 * G && lstm_coop_pick_units(h->H, tiles - G, h->num_cus_real, 8) != 0) {
+    // K-split capacity at the coarsest (64-unit) split and at the finest (8-unit) one: 42 and 5 tiles on 256 CUs
+    const int k64 = h->num_cus_real / (h->H / 64), k8 = h->num_cus_real / (h->H / 8);
+    auto small = [&](int t) { return t <= k64 || t <= k64 + k8; };      // one K-split launch, or a full one + a tiny one (55 + 9 us)
+    int tiles = cdiv(left, 32);
+    if (tiles > G && tiles <= 2 * G && small(tiles - G)) {              // G tiles one per group first
         out.push_back(column_chunk(h, r0, G * 32));
-        r0 += G * 32; left -= G * 32;
+        r0 += G * 32; left -= G * 32; tiles -= G;
+    }
+    if (tiles > k64 && tiles <= k64 + k8) {                             // e.g. the 43 tiles left of parity-mode B = 32 (128 tiles)
+        out.push_back(column_chunk(h, r0, k64 * 32));
+        r0 += k64 * 32; left -= k64 * 32;
     }
     if (left > 0) out.push_back(column_chunk(h, r0, left));
     return out;

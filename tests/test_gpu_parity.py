@@ -90,12 +90,12 @@ def test_lstm2_fc_valu_rows_and_rounds(n, cus, steps):
     assert per_row.max() < 2e-5, (per_row.max(), np.argsort(-per_row)[:8])
 
 
-@pytest.mark.parametrize("n,steps", [(20, 5), (70, 33), (257, 128), (672, 9), (1000, 17), (1300, 12),
-                                     (1400, 9), (2700, 21), (2750, 8), (4112, 14), (5440, 6)])
+@pytest.mark.parametrize("n,steps", [(20, 5), (70, 33), (257, 128), (672, 9), (1000, 17), (1300, 12), (1376, 7),
+                                     (1400, 9), (2700, 21), (2750, 8), (4096, 5), (4112, 14), (5440, 6)])
 def test_lstm2_fc_cooperative_kernel(n, steps):
     """Column-split kernels: csrc/lstm_coop.hip (<= 42 row tiles: 6..48 workgroups share each 32-row tile, K split over
     the waves) and csrc/lstm_coopn.hip (43..170 row tiles: n = 1400..5440 here - 3 workgroups share 1 or 2 row tiles,
-    incl. an odd tile count whose last group owns one tile).  h is exchanged through global memory with one agent-scope
+    incl. an odd tile count whose last group owns one tile; 1376 / 4096 / 4112: a full K-split launch plus a tiny one).  h is exchanged through global memory with one agent-scope
     barrier per step; results must match the oracle and the row-tile kernel."""
     sd = make_state_dict(9, "harsh")
     m = _model(DEFAULT_MODEL_ARGS, sd)

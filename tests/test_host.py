@@ -347,7 +347,8 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(257) == [(1, 257)] and _plan(257)[0]["par"] == 16                 # B = 1: K split, 16 units
     assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
     assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
-    assert kinds(4096) == [(2, 4096)] and _plan(4096)[0]["rpg"] == 2                # parity-mode B = 32: 128 tiles
+    assert kinds(4096) == [(2, 2720), (1, 1344), (1, 32)]                           # parity-mode B = 32: 128 tiles = 85 + 42 + 1
+    assert kinds(4256) == [(2, 4256)] and _plan(4256)[0]["rpg"] == 2                # 133 tiles: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
@@ -358,7 +359,8 @@ def test_subband_plan_choices_match_the_design():
     assert [k for k, _ in g[:-1]] == [2] * 12 and g[-1] == (1, 65792 - 12 * 5440)   # the short last one K split
     assert kinds(8224, gru=1) == [(2, 5440), (2, 2720), (1, 64)]                    # GRU, B = 32: 170 + 85 + 2 tiles
     assert kinds(3084) == [(2, 2720), (1, 364)]                                     # B = 12: 85 tiles one per group + 12 K split
-    assert kinds(4112) == [(2, 4112)] and _plan(4112)[0]["rpg"] == 2                # B = 16: 129 tiles, two per group
+    assert kinds(4112) == [(2, 2720), (1, 1344), (1, 48)]                           # B = 16: 129 tiles = 85 + 42 + 2
+    assert kinds(1376) == [(1, 1344), (1, 32)]                                      # 43 tiles: a full K-split launch + a tiny one
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():
