@@ -365,7 +365,7 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
     while (cdiv(left, 32) > 2 * G) { out.push_back(column_chunk(h, r0, 2 * G * 32)); r0 += 2 * G * 32; left -= 2 * G * 32; }
     // K-split capacity at the coarsest (64-unit) split and at the finest (8-unit) one: 42 and 5 tiles on 256 CUs
     const int k64 = h->num_cus_real / (h->H / 64), k8 = h->num_cus_real / (h->H / 8);
-    auto small = [&](int t) { return t <= k64 || t <= k64 + k8; };      // one K-split launch, or a full one + a tiny one (55 + 9 us)
+    auto small = [&](int t) { return t <= k64 + k8; };                  // one K-split launch, or a full one + a tiny one (55 + 9 us)
     int tiles = cdiv(left, 32);
     if (tiles > G && tiles <= 2 * G && small(tiles - G)) {              // G tiles one per group first
         out.push_back(column_chunk(h, r0, G * 32));
@@ -531,7 +531,10 @@ const char* fsnp_version(void) { return "fsnp-hip 0.1 (gfx950)"; }
 int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (!cfg || !out) { set_error("fsnp_create: null argument"); return 1; }
     *out = nullptr;
-    if (cfg->fb_num_neighbors < 0) { set_error("fb_num_neighbors must be >= 0"); return 2; }
+    if (cfg->num_freqs < 2) { set_error("num_freqs must be >= 2"); return 2; }
+    if (cfg->look_ahead < 0) { set_error("look_ahead must be >= 0"); return 2; }
+    if (cfg->sb_num_neighbors < 0 || cfg->fb_num_neighbors < 0) { set_error("sb_num_neighbors / fb_num_neighbors must be >= 0"); return 2; }
+    if (cfg->num_groups_in_drop_band < 1) { set_error("num_groups_in_drop_band must be >= 1"); return 2; }
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
     if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
@@ -890,7 +893,6 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
                   "(its workgroups were not co-resident - is the GPU shared?); that result was invalid - set FSNP_LSTM_COOP=0");
         return 5;
     }
-    if (batch <= 0 || frames <= 0) { set_error("fsnp_forward: empty input (B=%d, T=%d)", batch, frames); return 2; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
     if (mode == FSNP_MODE_PARITY && (h->cfg.num_groups_in_drop_band < 2 || global_batch <= h->cfg.num_groups_in_drop_band)) {
         set_error("PARITY mode needs num_groups_in_drop_band >= 2 and a global batch larger than it (feature.py:263)");
@@ -1166,7 +1168,8 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
     // inferencer.py:142-158: stft -> (mag, real, imag) -> model -> decompress_cIRM, complex multiply -> istft(length)
     stft_into(h, p, wav, wav_stride, xp, xs, noisy, p.sp, batch, samples, s);
     const int64_t cst[3] = {(int64_t)T * (p.sp / 2), 1, p.sp / 2};       // complex-element strides of [B][T][sp/2] as (b, f, t)
-    if (fsnp_forward_complex(h, noisy, cst, mask, batch, T, FSNP_MODE_FULL, 0, batch, hip_stream)) return 4;
+    const int rc = fsnp_forward_complex(h, noisy, cst, mask, batch, T, FSNP_MODE_FULL, 0, batch, hip_stream);
+    if (rc) return rc;
     // the pad column of every row of `enh` is never written by apply_cirm and multiplies zero weights: clear it once
     FSNP_HIP_CHECK(hipMemsetAsync(enh, 0, spec_b, s));
     launch_apply_cirm(mask, noisy, cst, enh, cst, batch, p.F, T, s);

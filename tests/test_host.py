@@ -39,6 +39,22 @@ def test_create_fails_loudly_without_gpu():
     assert b"no CPU fallback" in lib.fsnp_last_error() or b"HIP" in lib.fsnp_last_error()
 
 
+@pytest.mark.parametrize("field,value,msg", [("num_freqs", 1, b"num_freqs"), ("look_ahead", -1, b"look_ahead"),
+                                             ("sb_num_neighbors", -1, b"neighbors"), ("fb_num_neighbors", 4, b"40"),
+                                             ("num_groups_in_drop_band", 0, b"num_groups_in_drop_band"),
+                                             ("output_size", 3, b"output_size"), ("sb_hidden", 256, b"384"),
+                                             ("norm_type", 7, b"norm_type"), ("attention", 9, b"attention"),
+                                             ("model", 5, b"model"), ("sequence_model", 3, b"sequence_model")])
+def test_create_validates_the_config_before_touching_the_device(field, value, msg):
+    """Bad configurations are rejected with rc 2 and a message naming the field - with or without a GPU."""
+    lib = _lib.load()
+    cfg = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)._config()
+    setattr(cfg, field, value)
+    hp = ctypes.c_void_p()
+    assert lib.fsnp_create(ctypes.byref(cfg), ctypes.byref(hp)) == 2 and not hp.value
+    assert msg in lib.fsnp_last_error(), lib.fsnp_last_error()
+
+
 def test_module_has_reference_parameter_tree_and_strict_load():
     m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
     sd = make_state_dict(0)
