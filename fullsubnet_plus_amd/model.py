@@ -134,6 +134,14 @@ def _reference_style_init(m):
             (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p)
 
 
+def _resolve_device(device):
+    """"cuda" -> the current device with its index (a handle is bound to one device)."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 class _HipModel(nn.Module):
     """Everything the two reference models share on the HIP side: the fsnp_handle, lazy strict weight packing,
     the fsnp_forward call and the test / bench hooks.  Subclasses hold the reference's parameter tree and
@@ -338,43 +346,28 @@ class _HipModel(nn.Module):
 
     def debug_set_num_cus(self, num_cus, device="cuda"):
         """Test hook: plan LSTM tiles as if the chip had `num_cus` CUs (exercises multi-round / VALU-row tiles)."""
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
+        lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_num_cus(self._handle, int(num_cus)), "fsnp_debug_set_num_cus")
 
     def debug_set_lstm_waves(self, waves, device="cuda"):
         """Tuning hook: waves per workgroup of the fused LSTM kernel (12 = three per SIMD, or 4)."""
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
+        lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_waves(self._handle, int(waves)), "fsnp_debug_set_lstm_waves")
 
     def debug_set_lstm_coop(self, mode, device="cuda"):
         """Tuning hook: 1 = use the cooperative column-split LSTM kernel for small batches (default), 0 = never."""
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
+        lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
     def debug_set_graph(self, mode, device="cuda"):
         """Tuning hook: 1 / 2 = replay the full-band stages from a hipGraph, 0 = launch kernel by kernel (default)."""
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
+        lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_graph(self._handle, int(mode)), "fsnp_debug_set_graph")
 
     def set_precision(self, mode, device="cuda"):
         """"fp32" (default) or "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16)."""
         assert mode in ("fp32", "bf16_ih")
-        dev = torch.device(device)
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
-        lib = self._ensure_handle(dev)
+        lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_set_precision(self._handle, int(mode == "bf16_ih")), "fsnp_set_precision")
 
     def debug_inject_error(self):
