@@ -82,6 +82,14 @@ CASES = [
     dict(name="b3_t16_fbn1", wseed=21, profile="harsh", args={"fb_num_neighbors": 1}, inp=("spec", 3, 16, 21), stages=False),
     dict(name="b1_t30_fbn1_cum_layer", wseed=22, profile="default", args={"fb_num_neighbors": 1, "norm_type": "cumulative_layer_norm"},
          inp=("spec", 1, 30, 22), stages=False),
+    # constructor options the default config never moves: look_ahead, sb_num_neighbors, kersize, activations, num_freqs
+    dict(name="b1_t20_la0", wseed=23, profile="harsh", args={"look_ahead": 0}, inp=("spec", 1, 20, 23), stages=False),
+    dict(name="b3_t18_la4", wseed=24, profile="default", args={"look_ahead": 4}, inp=("spec", 3, 18, 24), stages=False),
+    dict(name="b1_t20_nb10_k247", wseed=25, profile="harsh", args={"sb_num_neighbors": 10, "kersize": [2, 4, 7]},
+         inp=("spec", 1, 20, 25), stages=False),
+    dict(name="b1_t20_tanh_relu6", wseed=26, profile="default",
+         args={"fb_output_activate_function": "Tanh", "sb_output_activate_function": "ReLU6"}, inp=("spec", 1, 20, 26), stages=False),
+    dict(name="b3_t16_f161", wseed=27, profile="harsh", args={"num_freqs": 161}, inp=("spec", 3, 16, 27), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -103,6 +111,9 @@ FSN_CASES = [
     dict(name="fsn_gru_b1_t24_harsh_stages", wseed=9, profile="harsh", args={"sequence_model": "GRU"},
          inp=("spec", 1, 24, 29), stages=True),
     dict(name="fsn_b3_t16_fbn2", wseed=11, profile="harsh", args={"fb_num_neighbors": 2}, inp=("spec", 3, 16, 31), stages=False),
+    dict(name="fsn_b3_t18_la1_nb10_f161_tanh", wseed=12, profile="harsh",
+         args={"look_ahead": 1, "sb_num_neighbors": 10, "num_freqs": 161, "sb_output_activate_function": "Tanh"},
+         inp=("spec", 3, 18, 32), stages=False),
     dict(name="fsn_gru_b3_t20_default", wseed=10, profile="default", args={"sequence_model": "GRU"},
          inp=("spec", 3, 20, 30), stages=False),
 ]
@@ -110,10 +121,11 @@ FSN_CASES = [
 SB_ROWS = [0, 1, 14, 15, 16, 128, 240, 241, 242, 255, 256]   # sub-bands kept from stage sb_input (B=1)
 
 
-def build_inputs(kind, B, t, seed):
+def build_inputs(kind, B, t, seed, num_freqs=257):
     if kind == "stft":
+        assert num_freqs == 257
         return make_inputs(B, t, seed)
-    return make_spec(B, t, seed)
+    return make_spec(B, t, seed, num_freqs)
 
 
 def run_case(case, FullSubNet_Plus):
@@ -122,11 +134,12 @@ def run_case(case, FullSubNet_Plus):
     torch.manual_seed(0)
     model = FullSubNet_Plus(**args).eval()
     sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"],
-                         sequence_model=args["sequence_model"], fb_num_neighbors=args["fb_num_neighbors"])
+                         sequence_model=args["sequence_model"], fb_num_neighbors=args["fb_num_neighbors"],
+                         num_freqs=args["num_freqs"], sb_num_neighbors=args["sb_num_neighbors"], kersize=tuple(args["kersize"]))
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]
-    mag, real, imag = build_inputs(kind, B, t, iseed)
+    mag, real, imag = build_inputs(kind, B, t, iseed, args["num_freqs"])
 
     stages = {}
     hooks = []
@@ -185,11 +198,12 @@ def run_case_fsn(case, Model):
     torch.manual_seed(0)
     model = Model(**args).eval()
     sd = make_state_dict_fullsubnet(case["wseed"], case["profile"], sequence_model=args["sequence_model"],
-                                    fb_num_neighbors=args["fb_num_neighbors"])
+                                    fb_num_neighbors=args["fb_num_neighbors"], num_freqs=args["num_freqs"],
+                                    sb_num_neighbors=args["sb_num_neighbors"])
     res = model.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     kind, B, t, iseed = case["inp"]
-    mag, _, _ = build_inputs(kind, B, t, iseed)
+    mag, _, _ = build_inputs(kind, B, t, iseed, args["num_freqs"])
     stages = {}
     hooks = []
     if case["stages"]:
@@ -258,7 +272,9 @@ def main():
         kw = dict(look_ahead=args["look_ahead"], sb_num_neighbors=args["sb_num_neighbors"],
                   fb_num_neighbors=args["fb_num_neighbors"], norm_type=args["norm_type"],
                   num_groups_in_drop_band=args["num_groups_in_drop_band"],
-                  channel_attention_model=args["channel_attention_model"])
+                  channel_attention_model=args["channel_attention_model"],
+                  fb_output_activate_function=args["fb_output_activate_function"],
+                  sb_output_activate_function=args["sb_output_activate_function"])
         sub = case.get("subsample_f") or 1
         ot = fsnp_torch.forward(sd, mag, real, imag, **kw).numpy()[:, :, ::sub, :]
         scale = np.abs(payload["out"]).max()

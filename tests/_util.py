@@ -34,11 +34,16 @@ class Golden:
         if self.is_fullsubnet:
             return make_state_dict_fullsubnet(self.meta["wseed"], self.meta["profile"],
                                               sequence_model=self.args.get("sequence_model", "LSTM"),
-                                              fb_num_neighbors=self.args.get("fb_num_neighbors", 0))
+                                              fb_num_neighbors=self.args.get("fb_num_neighbors", 0),
+                                              num_freqs=self.args.get("num_freqs", 257),
+                                              sb_num_neighbors=self.args.get("sb_num_neighbors", 15))
         return make_state_dict(self.meta["wseed"], self.meta["profile"],
                                attention=self.args.get("channel_attention_model", "TSSE"),
                                sequence_model=self.args.get("sequence_model", "LSTM"),
-                               fb_num_neighbors=self.args.get("fb_num_neighbors", 0))
+                               fb_num_neighbors=self.args.get("fb_num_neighbors", 0),
+                               num_freqs=self.args.get("num_freqs", 257),
+                               sb_num_neighbors=self.args.get("sb_num_neighbors", 15),
+                               kersize=tuple(self.args.get("kersize", (3, 5, 10))))
 
     def inputs(self):
         inp = self.meta["inp"]
@@ -50,7 +55,7 @@ class Golden:
             return X.abs().unsqueeze(1), X.real.unsqueeze(1), X.imag.unsqueeze(1)
         if inp["kind"] == "stft":
             return make_inputs(inp["B"], inp["t"], inp["seed"])
-        return make_spec(inp["B"], inp["t"], inp["seed"])
+        return make_spec(inp["B"], inp["t"], inp["seed"], self.args.get("num_freqs", 257))
 
     def fwd_kwargs(self):
         a = self.args
@@ -61,7 +66,9 @@ class Golden:
         return dict(look_ahead=a["look_ahead"], sb_num_neighbors=a["sb_num_neighbors"],
                     fb_num_neighbors=a["fb_num_neighbors"], norm_type=a["norm_type"],
                     num_groups_in_drop_band=a["num_groups_in_drop_band"],
-                    channel_attention_model=a.get("channel_attention_model", "TSSE"))
+                    channel_attention_model=a.get("channel_attention_model", "TSSE"),
+                    fb_output_activate_function=a.get("fb_output_activate_function", "ReLU"),
+                    sb_output_activate_function=a.get("sb_output_activate_function", False))
 
 
 def rel_err(a, b):
