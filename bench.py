@@ -22,6 +22,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,6 +56,11 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help='"nccl" (= RCCL; the real launch) or "gloo" (plumbing tests)')
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (checks the N>1 plumbing on a 1-GPU box with --dist-backend gloo)")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
+                    help="1 (default) = the serving loop: fsnp_set_pipeline, the remainder chunk of forward i (the 32 of 8224 "
+                         "sequences that do not fit the chip-filling launch) overlaps the full-band stages of forward i+1; all "
+                         "K forwards are complete (fsnp_flush + synchronize) inside the timed region.  0 = every forward runs "
+                         "strictly back to back.  The other mode is timed too and reported as `alt_ms_per_step`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -93,13 +100,33 @@ def cpu_baseline(sd, inputs, budget_s, norm, fullsubnet=False):
             out0 = o
         done += 1
     dt = time.perf_counter() - t0
+    last = mag.shape[0] - 1                                   # untimed: the LAST utterance too (B = 32: its upper bins are the
+    out_last = fwd(mag[last:], real[last:], imag[last:], norm)   # 32 sequences that run on the remainder kernel)
     return {"value": done * T / dt, "unit": "frames/s", "cores": best_threads, "kind": "port",
             "sample": f"{done} x 1-utterance forwards of the {T}-frame clips (oracle/fsnp_torch.py, "
-                      f"torch {torch.__version__} CPU, {best_threads} of {ncpu} host threads), {dt:.1f} s"}, out0
+                      f"torch {torch.__version__} CPU, {best_threads} of {ncpu} host threads), {dt:.1f} s"}, out0, out_last
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves (one process per
+    GPU, rendezvous on 127.0.0.1) and exit with their status.  Fails loudly when fewer than N GPUs are visible."""
+    visible = torch.cuda.device_count()
+    if not args.same_device and visible < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / cross-process tensors)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,7 +144,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(args.dist_backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
 
     from fullsubnet_plus_amd import FullSubNet, FullSubNet_Plus
     from fullsubnet_plus_amd.synthetic import (DEFAULT_MODEL_ARGS, FULLSUBNET_MODEL_ARGS, make_inputs, make_state_dict,
@@ -136,6 +164,7 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.batch_mode = args.mode
+    model.error_check = "deferred"       # no host wait per forward; poll_errors() below, after the final synchronisation
 
     B = args.batch
     cpu_in = make_inputs(B, args.seconds, 1000 + rank)           # synthetic, per-rank seed
@@ -164,26 +193,38 @@ def main():
     with torch.no_grad():
         out = model.enhance_wave(wav[:1]) if args.wave else model(*[t[:1] for t in gpu_in])   # creates the handle
         model.set_precision(args.precision)
-        out = None
-        for _ in range(args.warmup):
-            out = run_once()
-        if out is None:
-            out = run_once()
-        sync_all()
-        model.set_timing(True)
-        model.get_timing(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = run_once()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        timing = model.get_timing(reset=True)
-        model.set_timing(False)
 
+        def timed_loop(pipeline):
+            model.set_pipeline(bool(pipeline), dev)
+            o = None
+            for _ in range(max(args.warmup, 1)):                 # also re-grows the (re-shaped) workspace outside the timing
+                o = run_once()
+            model.flush()
+            sync_all()
+            model.set_timing(True)
+            model.get_timing(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                o = run_once()
+            model.flush()                                        # deferred remainder chunks: ordered before the sync below
+            sync_all()
+            dt = time.perf_counter() - t0
+            tm = model.get_timing(reset=True)
+            model.set_timing(False)
+            model.poll_errors()                                  # a column-split launch that gave up would have flagged the handle
+            return dt, tm, o
+
+        pipelined = bool(args.pipeline) and not args.wave
+        alt_elapsed, _, _ = timed_loop(not pipelined) if not args.wave else (None, None, None)
+        elapsed, timing, out = timed_loop(pipelined)
+
+    rank_ms = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)          # the job is as slow as its slowest rank
         # batch-split plumbing: gather every rank's masks once (outside the timed region)
         g0 = time.perf_counter()
         gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=dev)
@@ -219,29 +260,43 @@ def main():
         "metric": "STFT frames/sec (257-bin, 2 s clips), " + ("FullSubNet" if fsn else "FullSubNet+") +
                   (" waveform -> waveform (HIP STFT + forward + cIRM + iSTFT)" if args.wave else " forward"),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "alt_ms_per_step": None if alt_elapsed is None else alt_elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 + bf16 ih-GEMM (configs[4])",
         "data": "synthetic",
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
                                f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)" +
                                ("" if args.sequence_model == "LSTM" else f", sequence_model={args.sequence_model}"),
-                   "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)"},
+                   "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)",
+                   "loop": ("pipelined serving loop: the column-split remainder chunk of forward i overlaps the full-band stages "
+                            "of forward i+1 (fsnp_set_pipeline); every forward is complete inside the timed region; "
+                            "alt_ms_per_step = the same K forwards strictly back to back") if pipelined else
+                           "forwards strictly back to back (alt_ms_per_step = the pipelined serving loop)"},
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "traffic": traffic, "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
+                     "traffic": traffic,
+                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, committed; NOT "
+                                       "re-measured by this run)" if traffic is not None else None,
+                     "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
                      "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
     }
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
+        result["dist"] = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""),
+                          "world_size_seen": dist.get_world_size(), "same_device": bool(args.same_device),
+                          "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ref0 = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
+        base, ref0, ref_last = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
         result["cpu_baseline"] = base
-        if args.mode == "full" and not args.wave:
-            got = out[:1].cpu()
-            result["cirm_max_abs_err"] = float((got - ref0).abs().max())
-            result["cirm_rel_err"] = float((got - ref0).abs().max() / ref0.abs().max())
+        if args.mode == "full" and not args.wave:           # first and last utterance of the timed batch vs the oracle
+            got, got_last = out[:1].cpu(), out[-1:].cpu()
+            result["cirm_max_abs_err"] = max(float((got - ref0).abs().max()), float((got_last - ref_last).abs().max()))
+            result["cirm_rel_err"] = max(float((got - ref0).abs().max() / ref0.abs().max()),
+                                         float((got_last - ref_last).abs().max() / ref_last.abs().max()))
+            result["cirm_checked_utterances"] = [0, B - 1]
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

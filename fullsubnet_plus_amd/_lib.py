@@ -53,6 +53,11 @@ SYMBOLS = {
     "fsnp_debug_lstm_profile": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64]),
     "fsnp_set_precision": (c_i32, [c_vp, c_i32]),
     "fsnp_check_errors": (c_i32, [c_vp]),
+    "fsnp_poll_errors": (c_i32, [c_vp]),
+    "fsnp_set_pipeline": (c_i32, [c_vp, c_i32]),
+    "fsnp_flush": (c_i32, [c_vp, c_vp]),
+    "fsnp_abi_version": (c_i32, []),
+    "fsnp_config_size": (c_i32, []),
     "fsnp_debug_set_lstm_coop": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_graph": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_inject_error": (c_i32, [c_vp]),
@@ -64,6 +69,8 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
+ABI_VERSION = 2          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+
 _lib = None
 
 
@@ -74,12 +81,12 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
-    if build_if_missing and (not os.path.exists(path) or (_build.is_stale() and os.access(_build.HERE, os.W_OK))):
-        try:
-            _build.build()
-        except Exception:
-            if not os.path.exists(path):
-                raise
+    if build_if_missing and (not os.path.exists(path) or _build.is_stale()):
+        # a stale library is never bound silently: its entry points may no longer match the signatures above
+        if not os.access(_build.HERE, os.W_OK):
+            raise RuntimeError(f"{path} is {'stale' if os.path.exists(path) else 'missing'} and {_build.HERE} is read-only: "
+                               "rebuild with `python -m fullsubnet_plus_amd._build`")
+        _build.build()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -m fullsubnet_plus_amd._build`")
     lib = ctypes.CDLL(path)
@@ -87,6 +94,9 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.fsnp_abi_version() != ABI_VERSION or lib.fsnp_config_size() != ctypes.sizeof(FsnpConfig):
+        raise RuntimeError(f"{path}: ABI mismatch (library: version {lib.fsnp_abi_version()}, fsnp_config {lib.fsnp_config_size()} "
+                           f"bytes; binding: version {ABI_VERSION}, {ctypes.sizeof(FsnpConfig)} bytes) - rebuild the library")
     _lib = lib
     return lib
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,7 @@ struct WeightSpec {
 struct Workspace {
     // offsets in bytes from the workspace base
     size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, sbt_x0, sbt_x, sbt_fb, sbt_y1, sbt_y2, zero_begin,
-        fsum, gn, sb_acc, coop_hx, coop_bar, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
+        fsum, gn, sb_acc, coop_hx, coop_bar, coop_abort, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
 };
 
 // The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1); it
@@ -53,6 +54,20 @@ struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
 struct TimingRec {
     hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
 };
+
+// Every entry point that touches the device runs on the handle's device and puts the caller's current device back.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define FSNP_ON_DEVICE(h)                                                              \
+    fsnp::DeviceGuard _dev_guard((h)->device);                                         \
+    if (!_dev_guard.ok) { fsnp::set_error("hipSetDevice(%d) failed", (h)->device); return 1; }
 
 }  // namespace fsnp
 
@@ -74,6 +89,7 @@ struct fsnp_handle {
     int model = FSNP_MODEL_FULLSUBNET_PLUS;
     int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
     int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
+    bool rowtile_ok = true;      // a one-tile-per-CU kernel (lstm.hip / lstm_gru.hip) exists for this handle's sub-band model
     int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
     TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
     int XS = 0;                  //     row stride of its [slot][t][NIN] activations
@@ -112,9 +128,20 @@ struct fsnp_handle {
     std::vector<GraphEntry> graphs;
 
     bool timing = false;
-    std::vector<TimingRec> timing_recs;
+    std::vector<TimingRec> timing_recs;   // recorded, not yet read back (drained by fsnp_get_timing, or when 256 pile up)
+    std::vector<hipEvent_t> event_pool;   // events are re-used: a forward with timing on allocates nothing in steady state
     double acc_ms[4] = {0, 0, 0, 0};
     int64_t acc_cnt[4] = {0, 0, 0, 0};
+
+    // pipelined serving mode (fsnp_set_pipeline): the column-split remainder chunks that follow a row-tile chunk run on
+    // `side_stream`, so that they overlap the full-band stages of the NEXT forward (which leave most CUs idle); the
+    // workspace is double buffered because forward i+1 rebuilds att / fb while the remainder of forward i still reads them
+    int pipeline = 0;
+    int ws_slots = 1, ws_slot = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
+    bool side_used[2] = {false, false};
+    unsigned char* last_base = nullptr;   // workspace half of the last forward (fsnp_read_stage)
 };
 
 namespace fsnp {
@@ -316,6 +343,23 @@ static void launch_zero_region(void* p, size_t bytes, hipStream_t s) {      // b
     hipLaunchKernelGGL(zero_region_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16);
 }
 
+// Column-split launches need all their workgroups co-resident.  Two of them running at once (two handles / two streams
+// of one process) could each hold part of the chip and wait for peers that cannot be scheduled, so within a process
+// they are chained per device: each one waits for the previous one's completion event.  Other kernels always finish,
+// so they cannot close a cycle; a foreign PROCESS still can - that case ends in the kernels' wall-clock timeout.
+static std::mutex g_coop_mu;
+static hipEvent_t g_coop_ev[64] = {};
+static bool g_coop_used[64] = {};
+template <typename F>
+static void launch_coop_chained(int dev, hipStream_t s, F launch) {
+    if (dev < 0 || dev >= 64) { launch(); return; }
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    if (g_coop_used[dev]) (void)hipStreamWaitEvent(s, g_coop_ev[dev], 0);
+    launch();
+    if (!g_coop_ev[dev] && hipEventCreateWithFlags(&g_coop_ev[dev], hipEventDisableTiming) != hipSuccess) { g_coop_ev[dev] = nullptr; return; }
+    g_coop_used[dev] = hipEventRecord(g_coop_ev[dev], s) == hipSuccess;
+}
+
 // ---- plan of the sub-band recurrent model: which kernel runs which sequences.
 // The row-tile kernel (lstm.hip) needs >= 256 tiles to fill the chip and costs ~208 us per step however few tiles it
 // gets; the column-split kernels pay one inter-workgroup barrier per step instead:
@@ -360,7 +404,8 @@ static SbChunk column_chunk(const fsnp_handle* h, int row0, int nrows) {   // ki
 //   76 + 55 + 9 us);   otherwise up to 2G: two tiles per group;   more (GRU only): full 2G launches first.
 static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nrows) {
     std::vector<SbChunk> out;
-    const int G = h->num_cus_real / (h->H / 128);
+    const int G = h->H >= 128 ? h->num_cus_real / (h->H / 128) : 0;
+    if (G <= 0) return out;                 // fewer CUs than one group needs: no column-split plan (callers fall back / fail)
     int r0 = row0, left = nrows;
     while (cdiv(left, 32) > 2 * G) { out.push_back(column_chunk(h, r0, 2 * G * 32)); r0 += 2 * G * 32; left -= 2 * G * 32; }
     // K-split capacity at the coarsest (64-unit) split and at the finest (8-unit) one: 42 and 5 tiles on 256 CUs
@@ -387,17 +432,22 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
         p.chunks.push_back(c);
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
-    const int col_max_rows = 2 * (h->num_cus_real / (h->H / 128)) * 32;      // one lstm_coopn launch: 170 tiles on 256 CUs
-    if (h->gru) {                                                             // no row-tile GRU kernel: column-split launches only
-        for (const SbChunk& c : plan_columns(h, 0, num_rows)) push(c);
-        return p;
-    }
+    const int col_max_rows = h->H >= 128 ? 2 * (h->num_cus_real / (h->H / 128)) * 32 : 0;   // one lstm_coopn launch: 170 tiles on 256 CUs
+    auto usable = [](const std::vector<SbChunk>& v) {          // a column-split plan exists and every chunk found a kernel
+        if (v.empty()) return false;
+        for (const SbChunk& c : v) if (c.kind == 0) return false;
+        return true;
+    };
+    const bool rowtile_ok = h->rowtile_ok;                     // a one-tile-per-CU kernel exists for this cell / size
+    const bool coop_on = h->lstm_coop != 0 || !rowtile_ok;     // (without one the column-split kernels are the only path)
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
     // bf16-ih mode (configs[4]) only changes the row-tile kernel: sequences that run on a column-split kernel (small
     // batches, remainder tiles) stay fp32 - more accurate and, there, faster
-    if (h->lstm_coop == 0) { push(whole); return p; }
-    if (num_rows <= col_max_rows) {
-        for (const SbChunk& c : plan_columns(h, 0, num_rows)) push(c);
+    if (!coop_on) { push(whole); return p; }
+    if (num_rows <= col_max_rows || !rowtile_ok) {
+        const std::vector<SbChunk> cols = plan_columns(h, 0, num_rows);
+        if (usable(cols)) { for (const SbChunk& c : cols) push(c); return p; }
+        if (rowtile_ok) push(whole);                           // else: empty plan = "this device cannot run the model"
         return p;
     }
     // full rounds on the row-tile kernel + the remainder on whatever runs it fastest, if that beats VALU rows / one more round
@@ -407,7 +457,8 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
         const SbChunk main_c{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0};
         double cost = est_step_us(h, main_c);
         for (const SbChunk& c : rc) cost += est_step_us(h, c);
-        if (cost < h->composite_gain * est_step_us(h, whole)) {
+        const bool rc_ok = rem > col_max_rows || usable(rc);
+        if (rc_ok && cost < h->composite_gain * est_step_us(h, whole)) {
             push(main_c);
             for (const SbChunk& c : rc) push(c);
             return p;
@@ -416,13 +467,16 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     push(whole);
     return p;
 }
-static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmArgs& a, float* hx, unsigned* bar, hipStream_t s,
-                           hipEvent_t after_first = nullptr) {
+// Launches chunks [first, last) of the plan on stream s.  `bar` = per-tile arrival counters followed (at bar +
+// plan.coop_tiles, 64-byte aligned by the caller) by the launch-abort word.
+static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmArgs& a, float* hx, unsigned* bar, unsigned* abort_word,
+                           hipStream_t s, hipEvent_t after_first = nullptr, int first_chunk = 0, int last_chunk = -1) {
     const size_t hx_floats_per_tile = lstm_coop_exchange_bytes(h->H, 1) / 4;
-    bool first = true;
-    for (const SbChunk& c : plan.chunks) {
-        if (!first && after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
-        first = false;
+    const int nchunks = (int)plan.chunks.size();
+    if (last_chunk < 0 || last_chunk > nchunks) last_chunk = nchunks;
+    for (int ci = first_chunk; ci < last_chunk; ++ci) {
+        const SbChunk& c = plan.chunks[ci];
+        if (ci == 1 && after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
         LstmArgs ca = a;
         ca.rows = a.rows + c.slot0;
         ca.num_rows = c.nrows; ca.num_tiles = c.num_tiles; ca.ex = c.ex;
@@ -431,11 +485,14 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_err = h->d_err;
+        ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
-        if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
-        else launch_lstm_coopn(h->lw, ca, s);
+        launch_coop_chained(h->device, s, [&] {
+            if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
+            else launch_lstm_coopn(h->lw, ca, s);
+        });
     }
-    if (after_first) (void)hipEventRecord(after_first, s);
+    if (after_first && last_chunk == nchunks) (void)hipEventRecord(after_first, s);
 }
 static void launch_build_rows(const SbPlan& plan, RowDesc* rows, int F, int T, int mode, int batch_offset, int global_batch,
                               int dense_out, int groups, hipStream_t s) {
@@ -489,6 +546,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.sb_acc = take((size_t)B * 2 * 8);
     w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
     w.coop_bar = take((size_t)plan.coop_tiles * 4);
+    w.coop_abort = take(256);             // [0] sub-band launches, [16] full-band LSTM (FullSubNet)
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
     w.sbt_gn = take(h->sb_tcn ? (size_t)8 * 2 * nrows_pad * 2 * 8 : 0);
@@ -498,14 +556,47 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     return w;
 }
 
+// h->ws holds h->ws_slots (1, or 2 in pipelined mode) halves of h->ws_bytes each
 static int ensure_workspace(fsnp_handle* h, size_t bytes) {
+    bytes = align_up(bytes, 4096);
     if (bytes <= h->ws_bytes) return 0;
     drop_graphs(h);
     if (h->ws) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes));
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes * h->ws_slots));
     h->ws_bytes = bytes;
+    h->side_used[0] = h->side_used[1] = false;     // the synchronise above drained the side stream
     return 0;
 }
+
+// hipEvents for the per-forward timing records come from a pool; records that nobody reads are folded into the
+// accumulators once 256 have piled up (they completed long ago), so timing never grows without bound.
+static int drain_timing(fsnp_handle* h) {
+    for (auto& r : h->timing_recs) {
+        float fb = 0, lstm = 0, all = 0, first = 0;
+        // a forward that failed half way leaves events unrecorded: such a record is dropped, not counted
+        const bool ok = hipEventSynchronize(r.e[2]) == hipSuccess && hipEventSynchronize(r.e[3]) == hipSuccess &&
+                        hipEventElapsedTime(&fb, r.e[0], r.e[1]) == hipSuccess && hipEventElapsedTime(&lstm, r.e[1], r.e[2]) == hipSuccess &&
+                        hipEventElapsedTime(&all, r.e[0], r.e[2]) == hipSuccess && hipEventElapsedTime(&first, r.e[1], r.e[3]) == hipSuccess;
+        if (ok) {
+            h->acc_ms[0] += lstm; h->acc_ms[1] += fb; h->acc_ms[2] += all; h->acc_ms[3] += first;
+            for (int i = 0; i < 4; ++i) h->acc_cnt[i] += 1;
+        } else {
+            (void)hipGetLastError();
+        }
+        for (auto& e : r.e) h->event_pool.push_back(e);
+    }
+    h->timing_recs.clear();
+    return 0;
+}
+static int take_timing_rec(fsnp_handle* h, TimingRec& rec) {
+    if (h->timing_recs.size() >= 256 && drain_timing(h)) return 1;
+    for (auto& e : rec.e) {
+        if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+        else FSNP_HIP_CHECK(hipEventCreate(&e));
+    }
+    return 0;
+}
+
 
 static double lstm_flops_per_step(const fsnp_handle* h) {
     if (h->sb_tcn) return 8 * (2.0 * h->NIN * h->CH + 2.0 * h->CH * 3 + 2.0 * h->CH * h->NIN) + 2.0 * h->NIN * h->cfg.output_size;
@@ -526,7 +617,9 @@ static double fb_lstm_flops_per_frame(const fsnp_handle* h) {   // original Full
 extern "C" {
 
 const char* fsnp_last_error(void) { return g_last_error.c_str(); }
-const char* fsnp_version(void) { return "fsnp-hip 0.1 (gfx950)"; }
+const char* fsnp_version(void) { return "fsnp-hip 0.2 (gfx950)"; }
+int32_t fsnp_abi_version(void) { return FSNP_ABI_VERSION; }
+int32_t fsnp_config_size(void) { return (int32_t)sizeof(fsnp_config); }
 
 int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (!cfg || !out) { set_error("fsnp_create: null argument"); return 1; }
@@ -570,8 +663,15 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->device = dev;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->num_cus_real = h->num_cus;
+    if (cfg->sequence_model != FSNP_SEQ_TCN && h->num_cus_real < cfg->sb_hidden / 8) {
+        // the column-split kernels need at least one group of workgroups resident (GRU has no other kernel)
+        set_error("device %d exposes %d compute units; the sub-band recurrent kernels need at least %d", dev, h->num_cus_real, cfg->sb_hidden / 8);
+        delete h;
+        return 3;
+    }
     h->model = cfg->model;
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
+    h->rowtile_ok = !h->gru;
     h->sb_tcn = cfg->sequence_model == FSNP_SEQ_TCN;
     h->XS = (int)align_up(nin, 4);
     h->NG = h->gru ? 3 : 4;
@@ -610,6 +710,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
 
 void fsnp_destroy(fsnp_handle* h) {
     if (!h) return;
+    fsnp::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     if (h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); }
@@ -620,6 +721,10 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->d_err) (void)hipHostFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
+    for (auto& e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    for (auto& e : h->ev_side) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -840,7 +945,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         for (int j = 0; j < 2 * h->cfg.fb_num_neighbors + 1; ++j) blob[o_reflfb + reflect_index(f - h->cfg.fb_num_neighbors + j, F)] += 1.0f;
     }
 
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     drop_graphs(h);
     if (h->d_weights) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->d_weights)); h->d_weights = nullptr; }
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_weights), blob.size() * sizeof(float)));
@@ -910,19 +1015,32 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     const int fb_units = fsn ? fb_coop_units(h, batch) : 0;
     if (fsn && fb_units == 0) { set_error("FullSubNet: at most %d utterances per call (full-band LSTM residency); split the batch", 32 * (h->num_cus_real / 16)); return 2; }
 
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
+    const int num_rows = batch * rows_per_utt(h, mode);
+    const SbPlan plan = plan_sb(h, num_rows);
+    if (plan.chunks.empty()) {
+        set_error("no kernel plan for %d sub-band sequences on this device (%d CUs): the %s sub-band model needs at least %d",
+                  num_rows, h->num_cus_real, h->gru ? "GRU" : "LSTM", h->H / 128);
+        return 2;
+    }
     const Workspace w = plan_workspace(h, batch, frames, mode);
     if (ensure_workspace(h, w.total)) return 4;
-    unsigned char* base = h->ws;
+    // pipelined mode: alternate between the two workspace halves; the half about to be rebuilt was last read by the
+    // deferred remainder chunks of the forward before the previous one
+    const int slot = h->pipeline ? h->ws_slot : 0;
+    if (h->pipeline) {
+        h->ws_slot ^= 1;
+        if (h->side_used[slot]) FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_side[slot], 0));
+    }
+    unsigned char* base = h->ws + (size_t)slot * h->ws_bytes;
     auto fptr = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
 
     TimingRec rec{};
     if (h->timing) {
-        for (auto& e : rec.e) FSNP_HIP_CHECK(hipEventCreate(&e));
+        if (take_timing_rec(h, rec)) return 4;
+        h->timing_recs.push_back(rec);          // owned by the handle from here on (no leak on an early return)
         FSNP_HIP_CHECK(hipEventRecord(rec.e[0], s));
     }
-    const int num_rows = batch * rows_per_utt(h, mode);
-    const SbPlan plan = plan_sb(h, num_rows);
     const int num_slots = plan.total_slots;
     RowDesc* rows = reinterpret_cast<RowDesc*>(base + w.rows);
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
@@ -958,7 +1076,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         };
         if (h->use_graph) {
             const GraphKey key{batch, frames, mode, batch_offset, global_batch, h->num_cus, h->lstm_coop, h->ih_bf16,
-                               h->debug ? 1 : 0, h->ws, h->d_weights};
+                               h->debug ? 1 : 0, base, h->d_weights};
             if (run_graphed(h, key, s, middle)) return 4;
         } else {
             middle(s);
@@ -979,8 +1097,9 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fa.seq_out = fptr(w.y1);
         fa.num_rows = batch; fa.num_tiles = fb_tiles; fa.Tp = d.Tp; fa.LA = 0; fa.FP = d.FP; fa.F = d.F;
         fa.coop_hx = fptr(w.fb_hx); fa.coop_bar = reinterpret_cast<unsigned*>(base + w.fb_bar); fa.coop_err = h->d_err;
+        fa.coop_abort = reinterpret_cast<unsigned*>(base + w.coop_abort) + 16;
         fa.coop_units = fb_units;
-        launch_lstm_coop_seq(h->fbw, fa, s);
+        launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
         launch_linear_act(fptr(w.y1), d.CH, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
@@ -1008,10 +1127,9 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         if (h->timing) {
             FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
             FSNP_HIP_CHECK(hipEventRecord(rec.e[3], s));
-            h->timing_recs.push_back(rec);
         }
         FSNP_HIP_CHECK(hipGetLastError());
-        h->last_ws = w; h->last_dims = d; h->have_last = true;
+        h->last_ws = w; h->last_dims = d; h->have_last = true; h->last_base = base;
         return 0;
     }
     LstmArgs a{};
@@ -1024,13 +1142,31 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     a.num_rows = num_rows; a.Tp = d.Tp; a.LA = d.LA; a.FP = d.FP; a.F = d.F; a.NSBN = h->cfg.sb_num_neighbors;
     a.NFBN = h->cfg.fb_num_neighbors;
     a.act = h->cfg.sb_act;
-    launch_sb_lstm(h, plan, a, fptr(w.coop_hx), reinterpret_cast<unsigned*>(base + w.coop_bar), s, h->timing ? rec.e[3] : nullptr);
-    if (h->timing) {
-        FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
-        h->timing_recs.push_back(rec);
+    unsigned* bar = reinterpret_cast<unsigned*>(base + w.coop_bar);
+    unsigned* abort_word = reinterpret_cast<unsigned*>(base + w.coop_abort);
+    // pipelined mode: column-split remainder chunks behind a row-tile chunk go to the side stream (after the row-tile
+    // chunk: next to it they would only fight for its CUs), where they overlap the next forward's full-band stages
+    int ndefer = 0;
+    if (h->pipeline && plan.chunks.size() > 1 && plan.chunks[0].kind == 0) {
+        ndefer = 1;
+        while (ndefer < (int)plan.chunks.size() && plan.chunks[ndefer].kind == 0) ++ndefer;
+        if (ndefer == (int)plan.chunks.size()) ndefer = 0;
+    }
+    if (ndefer == 0) {
+        launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, s, h->timing ? rec.e[3] : nullptr);
+        if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
+    } else {
+        launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, s, (h->timing && ndefer > 1) ? rec.e[3] : nullptr, 0, ndefer);
+        if (h->timing && ndefer == 1) FSNP_HIP_CHECK(hipEventRecord(rec.e[3], s));      // "after the first chunk"
+        FSNP_HIP_CHECK(hipEventRecord(h->ev_main, s));
+        FSNP_HIP_CHECK(hipStreamWaitEvent(h->side_stream, h->ev_main, 0));
+        launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, h->side_stream, nullptr, ndefer, -1);
+        if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], h->side_stream));
+        FSNP_HIP_CHECK(hipEventRecord(h->ev_side[slot], h->side_stream));
+        h->side_used[slot] = true;
     }
     FSNP_HIP_CHECK(hipGetLastError());
-    h->last_ws = w; h->last_dims = d; h->have_last = true;
+    h->last_ws = w; h->last_dims = d; h->have_last = true; h->last_base = base;
     return 0;
 }
 
@@ -1073,7 +1209,7 @@ static int ensure_stft(fsnp_handle* h) {
     const StftPlan p = stft_plan(h);
     std::vector<float> host(p.total, 0.0f);
     stft_build_matrices(p.n_fft, host.data() + p.o_fwd, host.data() + p.o_inv, host.data() + p.o_win);
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_stft), p.total * sizeof(float)));
     FSNP_HIP_CHECK(hipMemcpy(h->d_stft, host.data(), p.total * sizeof(float), hipMemcpyHostToDevice));
     return 0;
@@ -1116,7 +1252,7 @@ int fsnp_stft(fsnp_handle* h, const float* wav, int64_t wav_stride, float* spec,
     const StftPlan p = stft_plan(h);
     if (samples <= p.hop) { set_error("fsnp_stft: need more than n_fft/2 = %d samples (reflect padding)", p.hop); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
     if (ensure_io(h, (size_t)batch * xs * 4)) return 4;
     stft_into(h, p, wav, wav_stride, reinterpret_cast<float*>(h->io), xs, spec, p.N2, batch, samples, s);
@@ -1132,7 +1268,7 @@ int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], floa
     const StftPlan p = stft_plan(h);
     if ((long)(frames - 1) * p.hop + p.n_fft < (long)samples + p.hop) { set_error("fsnp_istft: %d frames do not cover %d samples", frames, samples); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     const size_t spec_b = align_up((size_t)batch * frames * p.sp * 4 + 256, 256), fr_b = (size_t)batch * frames * p.n_fft * 4;
     if (ensure_io(h, spec_b + fr_b)) return 4;
     float* sp = reinterpret_cast<float*>(h->io);
@@ -1154,7 +1290,7 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
     const StftPlan p = stft_plan(h);
     if (samples <= p.hop) { set_error("fsnp_enhance_wave: need more than n_fft/2 = %d samples (reflect padding)", p.hop); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     const int T = 1 + samples / p.hop;
     const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
     const size_t xp_b = align_up((size_t)batch * xs * 4, 256), spec_b = align_up((size_t)batch * T * p.sp * 4 + 256, 256);
@@ -1193,15 +1329,18 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     if (h->sb_tcn) { set_error("fsnp_lstm2_fc: the sub-band model of this handle is a TCN (no recurrent kernel)"); return 2; }
     if (num_seq <= 0 || steps <= 0) { set_error("fsnp_lstm2_fc: empty input"); return 2; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
     const SbPlan plan = plan_sb(h, num_seq);
     const int num_slots = plan.total_slots;
     const bool coop = plan.coop_tiles != 0;
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
     const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
-    const size_t coop_bytes = coop ? coop_hx_bytes + align_up((size_t)plan.coop_tiles * 4, 256) : 0;
+    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 4, 256);
+    const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
+    if (plan.chunks.empty()) { set_error("fsnp_lstm2_fc: no kernel plan for %d sequences on this device", num_seq); return 2; }
     if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
+    if (h->pipeline && h->side_stream) FSNP_HIP_CHECK(hipStreamSynchronize(h->side_stream));   // slot 0 may still be read
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
     if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
@@ -1210,7 +1349,8 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
     launch_sb_lstm(h, plan, a, reinterpret_cast<float*>(h->ws + coop_off),
-                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes), s);
+                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes),
+                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes + coop_bar_bytes), s);
     FSNP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1226,17 +1366,18 @@ int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t n
     bool is_gate = false;
     static const char* tags[3] = {"mag", "real", "imag"};
     for (int b = 0; b < h->NFB; ++b) {
-        if (n == std::string("att_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.att) + b * plane;
-        if (n == std::string("fb_") + tags[b]) src = reinterpret_cast<float*>(h->ws + w.fb) + b * plane;
-        if (h->NFB == 3 && n == std::string("gate_") + tags[b]) { src = reinterpret_cast<float*>(h->ws + w.gate) + (size_t)b * d.B * d.FP; is_gate = true; }
+        if (n == std::string("att_") + tags[b]) src = reinterpret_cast<float*>(h->last_base + w.att) + b * plane;
+        if (n == std::string("fb_") + tags[b]) src = reinterpret_cast<float*>(h->last_base + w.fb) + b * plane;
+        if (h->NFB == 3 && n == std::string("gate_") + tags[b]) { src = reinterpret_cast<float*>(h->last_base + w.gate) + (size_t)b * d.B * d.FP; is_gate = true; }
     }
     if (n == "tcn0_mag") {
         if (!h->debug) { set_error("tcn0_mag needs FSNP_DEBUG_STAGES=1 at fsnp_create time"); return 2; }
-        src = reinterpret_cast<float*>(h->ws + w.dbg_tcn0);
+        src = reinterpret_cast<float*>(h->last_base + w.dbg_tcn0);
     }
     if (!src) { set_error("unknown stage %s", name); return 2; }
     const int64_t rows = is_gate ? d.B : (int64_t)d.B * d.Tp;
     if (numel != rows * d.F) { set_error("stage %s has %lld elements, caller asked %lld", name, (long long)(rows * d.F), (long long)numel); return 2; }
+    FSNP_ON_DEVICE(h);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     FSNP_HIP_CHECK(hipMemcpy2D(host_out, (size_t)d.F * 4, src, (size_t)d.FP * 4, (size_t)d.F * 4, (size_t)rows, hipMemcpyDeviceToHost));
     return 0;
@@ -1250,18 +1391,8 @@ int fsnp_set_timing(fsnp_handle* h, int32_t enable) {
 
 int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset) {
     if (!h || !ms || !count) { set_error("fsnp_get_timing: null argument"); return 1; }
-    for (auto& r : h->timing_recs) {
-        FSNP_HIP_CHECK(hipEventSynchronize(r.e[2]));
-        float fb = 0, lstm = 0, all = 0, first = 0;
-        FSNP_HIP_CHECK(hipEventElapsedTime(&fb, r.e[0], r.e[1]));
-        FSNP_HIP_CHECK(hipEventElapsedTime(&lstm, r.e[1], r.e[2]));
-        FSNP_HIP_CHECK(hipEventElapsedTime(&all, r.e[0], r.e[2]));
-        FSNP_HIP_CHECK(hipEventElapsedTime(&first, r.e[1], r.e[3]));
-        h->acc_ms[0] += lstm; h->acc_ms[1] += fb; h->acc_ms[2] += all; h->acc_ms[3] += first;
-        for (int i = 0; i < 4; ++i) h->acc_cnt[i] += 1;
-        for (auto& e : r.e) if (e) (void)hipEventDestroy(e);
-    }
-    h->timing_recs.clear();
+    FSNP_ON_DEVICE(h);
+    if (drain_timing(h)) return 1;
     for (int i = 0; i < 4; ++i) { ms[i] = h->acc_ms[i]; count[i] = h->acc_cnt[i]; }
     if (reset) for (int i = 0; i < 4; ++i) { h->acc_ms[i] = 0; h->acc_cnt[i] = 0; }
     return 0;
@@ -1269,9 +1400,11 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
 
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks) {
-    if (!out || num_rows <= 0 || num_cus <= 0 || hidden % 128 != 0 || max_chunks <= 0) { set_error("fsnp_debug_plan_rows: bad argument"); return -1; }
+    if (!out || num_rows <= 0 || num_cus <= 0 || hidden < 128 || hidden % 128 != 0 || max_chunks <= 0) { set_error("fsnp_debug_plan_rows: bad argument"); return -1; }
     fsnp_handle h;                      // host-only: the planner never touches the device
     h.H = hidden; h.num_cus = num_cus; h.num_cus_real = num_cus; h.gru = gru; h.lstm_coop = coop; h.composite_gain = composite_gain;
+    h.rowtile_ok = gru == 0 || gru == 2;      // gru = 2: plan as a GRU handle WITH its one-tile-per-CU kernel (lstm_gru.hip)
+    h.gru = gru != 0;
     const SbPlan plan = plan_sb(&h, num_rows);
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
@@ -1302,7 +1435,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
     if (h->gru || h->sb_tcn) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
@@ -1330,9 +1463,51 @@ int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     return 0;
 }
 
+int fsnp_poll_errors(fsnp_handle* h) {
+    if (!h) { set_error("null handle"); return 1; }
+    const unsigned e = *reinterpret_cast<volatile unsigned*>(h->d_err);
+    if (e != 0) {
+        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
+        set_error("column-split LSTM kernel: an inter-workgroup wait timed out (its workgroups were not co-resident - is the "
+                  "GPU shared with another process?); the result of that call is invalid.  FSNP_LSTM_COOP=0 avoids these kernels");
+        return 5;
+    }
+    return 0;
+}
+
+int fsnp_set_pipeline(fsnp_handle* h, int32_t enable) {
+    if (!h || (enable != 0 && enable != 1)) { set_error("fsnp_set_pipeline: 0 or 1"); return 1; }
+    if (enable == h->pipeline) return 0;
+    FSNP_ON_DEVICE(h);
+    FSNP_HIP_CHECK(hipDeviceSynchronize());              // nothing of either mode is in flight while the workspace is re-shaped
+    if (enable && !h->side_stream) {
+        FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+        for (auto& e : h->ev_side) FSNP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    drop_graphs(h);
+    if (h->ws) { FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    h->have_last = false;
+    h->pipeline = enable;
+    h->ws_slots = enable ? 2 : 1;
+    h->ws_slot = 0;
+    h->side_used[0] = h->side_used[1] = false;
+    return 0;
+}
+
+int fsnp_flush(fsnp_handle* h, void* hip_stream) {
+    if (!h) { set_error("null handle"); return 1; }
+    if (!h->pipeline) return 0;
+    FSNP_ON_DEVICE(h);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    for (int k = 0; k < 2; ++k)
+        if (h->side_used[k]) FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_side[k], 0));
+    return 0;
+}
+
 int fsnp_check_errors(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
-    FSNP_HIP_CHECK(hipSetDevice(h->device));
+    FSNP_ON_DEVICE(h);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     const unsigned e = *reinterpret_cast<volatile unsigned*>(h->d_err);
     if (e != 0) {

@@ -181,7 +181,8 @@ struct LstmArgs {
     // column-split (cooperative) kernel only
     float* coop_hx;            // per row tile: h0/h1 exchange images (double buffered) + Linear partials, zeroed per launch
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
-    unsigned* coop_err;        // set to 1 if a barrier wait timed out
+    unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
+    unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
     int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2

@@ -36,4 +36,30 @@ __device__ __forceinline__ float xchg_load(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One lane's wait on an arrival counter.  Bounded by WALL-CLOCK time (s_memrealtime, 100 MHz), not by a poll count: a
+// legitimate wait can be as long as a foreign kernel that still occupies the CUs the peers of this launch need (tens of
+// ms), a dead one (peers that can never become resident next to another spinning launch) must end in seconds.  The
+// first waiter that times out raises the launch's device-side abort word (every other waiter sees it within 256 polls
+// and leaves too - the whole launch drains in microseconds instead of timing out once per remaining step) and the
+// host-mapped error word, which fails the call loudly (fsnp_poll_errors / the next call on the handle).
+constexpr long long kXchgTimeoutTicks = 200000000LL;    // 2 s of the 100 MHz constant clock
+__device__ __forceinline__ bool xchg_wait(const unsigned* bar, unsigned target, unsigned* abort_dev, unsigned* err_host) {
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {
+            if (__hip_atomic_load(abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > kXchgTimeoutTicks) {
+                __hip_atomic_store(abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
 }  // namespace fsnp

@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
     unsigned* bar = a.coop_bar + rt;
 
+    __shared__ int abort_s;                        // set by thread 0 when an inter-workgroup wait gives up
+    if (tid == 0) abort_s = 0;
     for (int i = tid; i < KGXP * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 32) rows_s[tid] = a.rows[slot0 + tid];
     __syncthreads();
@@ -263,22 +265,17 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         return red[idx] + red[idx + NT * 1024] + red[idx + 2 * NT * 1024] + red[idx + 3 * NT * 1024];
     };
 
-    auto inter_wg_barrier = [&](unsigned target) {
+    // returns false (to every thread) once the launch is aborted: a peer never arrived (lstm_common.h: xchg_wait)
+    auto inter_wg_barrier = [&](unsigned target) -> bool {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
         __syncthreads();
         if (tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) {                         // seconds: a peer is not resident - give up loudly
-                    __hip_atomic_store(a.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word
-                    break;
-                }
-            }
+            if (!xchg_wait(bar, target, a.coop_abort, a.coop_err)) abort_s = 1;
         }
         __syncthreads();
+        return abort_s == 0;
     };
     auto fc_epilogue = [&](int t_done) {     // workgroup cs == 0 sums the S partials of step t_done in a fixed order
         if (cs == 0 && tid < 64) {
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = x_valid(i) ? (xr[i] - mdn.m) / mdn.d : 0.0f;
         }
-        inter_wg_barrier((unsigned)S * (unsigned)(t + 1));   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
+        if (!inter_wg_barrier((unsigned)S * (unsigned)(t + 1))) return;   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
 
         if constexpr (!SEQ) { if (t > 0) fc_epilogue(t - 1); }
 
@@ -411,7 +408,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     }
     if constexpr (!SEQ) {
         // last step's Linear: one more barrier so that every partial of step Tp-1 is visible
-        inter_wg_barrier((unsigned)S * (unsigned)(Tp + 1));
+        if (!inter_wg_barrier((unsigned)S * (unsigned)(Tp + 1))) return;
         fc_epilogue(Tp - 1);
     }
 }

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
 
     __shared__ __attribute__((aligned(16))) float4 Xs[2][R][KGX * 64];  // A images of x_t, double buffered by step parity
     __shared__ RowDesc rows_s[R][32];
+    __shared__ int abort_s;                        // set by thread 0 when an inter-workgroup wait gives up
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
         if (!live[r]) rt[r] = g;                   // harmless duplicate addresses; nothing is computed for it
     }
     unsigned* bar = a.coop_bar + g;
+    if (tid == 0) abort_s = 0;
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -205,22 +207,17 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
     const float wfc0 = w.wfc[unit], wfc1 = w.wfc[HID + unit];
     const int rowbase = 4 * (lane >> 5);
 
-    auto inter_wg_barrier = [&](unsigned target) {
+    // returns false (to every thread) once the launch is aborted: a peer never arrived (lstm_common.h: xchg_wait)
+    auto inter_wg_barrier = [&](unsigned target) -> bool {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
         __syncthreads();
         if (tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) {                         // seconds: a peer is not resident - give up loudly
-                    __hip_atomic_store(a.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word
-                    break;
-                }
-            }
+            if (!xchg_wait(bar, target, a.coop_abort, a.coop_err)) abort_s = 1;
         }
         __syncthreads();
+        return abort_s == 0;
     };
     auto fc_epilogue = [&](int r, int t_done) {   // workgroup cs == 0 sums the 4 S per-wave partials in a fixed order
         if (cs == 0 && tid < 64 && live[r]) {
@@ -285,7 +282,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                 for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[r][i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
             }
         }
-        inter_wg_barrier((unsigned)S * (unsigned)(t + 1));   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
+        if (!inter_wg_barrier((unsigned)S * (unsigned)(t + 1))) return;   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
 
         // ---------------- layer 1 of every row tile: [h1_{t-1} | h0_t] ----------------
 #pragma unroll
@@ -329,7 +326,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
         }
     }
     // last step's Linear: one more barrier so that every partial of step Tp-1 is visible
-    inter_wg_barrier((unsigned)S * (unsigned)(Tp + 1));
+    if (!inter_wg_barrier((unsigned)S * (unsigned)(Tp + 1))) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) fc_epilogue(r, Tp - 1);
 }

@@ -14,6 +14,7 @@
 // kernel applies the per-utterance scalars + per-channel affine while it loads its operand, so no
 // normalised tensor is ever written.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fsnp_common.h"
 
@@ -52,7 +53,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // One workgroup = 4 waves, wave w owns rows [32 w, 32 w + 32) of the 128-row tile and all BN columns
 // (BN / 32 accumulators of v_mfma_f32_32x32x2_f32).  BN = 96 makes the N = 257 GEMMs 3 column tiles (288, 11 %
 // padding) instead of 5 x 64 (25 %).
-template <int PRO, int EPI, int BN>
+// PF = register prefetch distance in k-tiles: the global loads of k-tile kt + PF are issued while tile kt is multiplied,
+// i.e. they have PF - 1 whole iterations (x 1024 MFMA cycles x the waves sharing the SIMD) to land before they are
+// normalised and stored to LDS.  With PF = 1 (round 1) a k-tile of 16 MFMAs per wave had to cover an L2 / Infinity
+// Cache round trip by itself and every iteration ended in a vmcnt(0) stall.
+template <int PRO, int EPI, int BN, int PF>
 __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     constexpr int NTILE = BN / 32;
     constexpr int BLD = (BN * 4 + 255) / 256;   // float4 B loads per thread per k-tile
@@ -87,12 +92,12 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     // staging assignment: A rows ar0, ar0+64 ; k quad kq ; B columns (tid + 256 i) >> 2
     const int kq = (tid & 3) * 4;
     const int ar0 = tid >> 2;
-    float4 areg[2], breg[BLD], ga4, be4;
+    float4 areg[PF][2], breg[PF][BLD], ga4[PF], be4[PF];
 
     // Phase 1: ISSUE the global loads of k-tile k0 (raw values only - nothing here consumes them, so they stay in flight
     // while the MFMAs of the previous tile run).  Phase 2 (finish_tiles, just before the LDS store) applies the operand
     // prologue: GroupNorm + affine / ReLU / zeroing of the K tail.
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](float4 (&ar)[2], float4 (&br)[BLD], float4& ga, float4& be, int k0) {
         const int k = k0 + kq;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -103,32 +108,32 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
                 if (k + 4 <= a_cols) v = *reinterpret_cast<const float4*>(p);
                 else { v.x = p[0]; if (k + 1 < a_cols) v.y = p[1]; if (k + 2 < a_cols) v.z = p[2]; }
             }
-            areg[i] = v;
+            ar[i] = v;
         }
         if constexpr (PRO == PRO_GN) {
             if (k < g.K) {
-                ga4 = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
-                be4 = *reinterpret_cast<const float4*>(beta + k);
+                ga = *reinterpret_cast<const float4*>(gamma + k);   // K % 4 == 0 here
+                be = *reinterpret_cast<const float4*>(beta + k);
             }
         }
 #pragma unroll
         for (int i = 0; i < BLD; ++i) {
             const int bc = (tid + 256 * i) >> 2;
-            breg[i] = bc < BN ? *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            br[i] = bc < BN ? *reinterpret_cast<const float4*>(W + (long)bc * g.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto finish_tiles = [&](int k0) {
+    auto finish_tiles = [&](float4 (&ar)[2], const float4& ga, const float4& be, int k0) {
         const int k = k0 + kq;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = t0 + ar0 + 64 * i;
-            float4 v = areg[i];
+            float4 v = ar[i];
             if (t < g.Tp && k < g.K) {
                 if constexpr (PRO == PRO_GN) {
-                    v.x = (v.x - mean) * rstd * ga4.x + be4.x;
-                    v.y = (v.y - mean) * rstd * ga4.y + be4.y;
-                    v.z = (v.z - mean) * rstd * ga4.z + be4.z;
-                    v.w = (v.w - mean) * rstd * ga4.w + be4.w;
+                    v.x = (v.x - mean) * rstd * ga.x + be.x;
+                    v.y = (v.y - mean) * rstd * ga.y + be.y;
+                    v.z = (v.z - mean) * rstd * ga.z + be.z;
+                    v.w = (v.w - mean) * rstd * ga.w + be.w;
                 }
                 if constexpr (PRO == PRO_RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
                 if (k + 2 >= g.K) v.z = 0.f;
                 if (k + 3 >= g.K) v.w = 0.f;
             }
-            areg[i] = v;
+            ar[i] = v;
         }
     };
     // a float4 of 4 consecutive k = (kh0,p) (kh1,p) (kh0,p+1) (kh1,p+1) with p = (kq>>1)&3  ->  two 8-byte LDS stores
@@ -146,15 +151,15 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         *reinterpret_cast<float2*>(base + ((kg * 2 + 0) * ld + row) * 4 + p) = make_float2(v.x, v.z);
         *reinterpret_cast<float2*>(base + ((kg * 2 + 1) * ld + row) * 4 + p) = make_float2(v.y, v.w);
     };
-    auto store_tiles = [&](int stage) {
+    auto store_tiles = [&](const float4 (&ar)[2], const float4 (&br)[BLD], int stage) {
         float* As = smem + stage * STAGE;               // [kg 2][kh 2][BM][4]
         float* Bs = As + 2 * 2 * BM * 4;                // [kg 2][kh 2][BN][4]
 #pragma unroll
-        for (int i = 0; i < 2; ++i) store_frag(As, BM, ar0 + 64 * i, areg[i]);
+        for (int i = 0; i < 2; ++i) store_frag(As, BM, ar0 + 64 * i, ar[i]);
 #pragma unroll
         for (int i = 0; i < BLD; ++i) {
             const int bc = (tid + 256 * i) >> 2;
-            if (bc < BN) store_frag(Bs, BN, bc, breg[i]);
+            if (bc < BN) store_frag(Bs, BN, bc, br[i]);
         }
     };
 
@@ -165,30 +170,45 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int ktiles = g.ldw / BK;
-    load_tiles(0);
-    finish_tiles(0);
-    store_tiles(0);
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < ktiles) load_tiles(areg[j], breg[j], ga4[j], be4[j], j * BK);
+    finish_tiles(areg[0], ga4[0], be4[0], 0);
+    store_tiles(areg[0], breg[0], 0);
     __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        // global -> registers for tile kt+1 while tile kt is multiplied out of LDS stage kt & 1; the registers go to
-        // the OTHER stage (last read in iteration kt-1, before that iteration's barrier), then one barrier
-        if (kt + 1 < ktiles) load_tiles((kt + 1) * BK);
+    // one k-tile; J = its register slot (compile time: the slot arrays must stay in registers)
+    auto k_iteration = [&](auto Jc, int kt) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int J1 = (J + 1) % PF;       // NB: PF == 1 -> the slot that was just refilled (round-1 schedule)
+        // register slot J held k-tile kt, which went to LDS one iteration ago: refill it with tile kt + PF while tile kt
+        // is multiplied out of LDS stage kt & 1.  Tile kt + 1 (slot J1, issued PF - 1 iterations ago) is then normalised
+        // and stored to the OTHER stage (last read in iteration kt - 1, before that iteration's barrier).
+        if (kt + PF < ktiles) load_tiles(areg[J], breg[J], ga4[J], be4[J], (kt + PF) * BK);
         const float4* As4 = reinterpret_cast<const float4*>(smem + (kt & 1) * STAGE);
         const float4* Bs4 = As4 + 2 * 2 * BM;
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             const float4 a4 = As4[(kg * 2 + (lane >> 5)) * BM + wave * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < NTILE; ++j) {
-                const float4 b4 = Bs4[(kg * 2 + (lane >> 5)) * BN + j * 32 + (lane & 31)];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
+            for (int jn = 0; jn < NTILE; ++jn) {
+                const float4 b4 = Bs4[(kg * 2 + (lane >> 5)) * BN + jn * 32 + (lane & 31)];
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[jn], 0, 0, 0);
             }
         }
-        if (kt + 1 < ktiles) { finish_tiles((kt + 1) * BK); store_tiles((kt + 1) & 1); }
+        if (kt + 1 < ktiles) {
+            finish_tiles(areg[J1], ga4[J1], be4[J1], (kt + 1) * BK);
+            store_tiles(areg[J1], breg[J1], (kt + 1) & 1);
+        }
         __syncthreads();
+    };
+    for (int kt0 = 0; kt0 < ktiles; kt0 += PF) {
+        k_iteration(std::integral_constant<int, 0>{}, kt0);
+        if constexpr (PF > 1) { if (kt0 + 1 < ktiles) k_iteration(std::integral_constant<int, 1 % PF>{}, kt0 + 1); }
+        if constexpr (PF > 2) { if (kt0 + 2 < ktiles) k_iteration(std::integral_constant<int, 2 % PF>{}, kt0 + 2); }
+        if constexpr (PF > 3) { if (kt0 + 3 < ktiles) k_iteration(std::integral_constant<int, 3 % PF>{}, kt0 + 3); }
     }
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -252,13 +272,24 @@ static int pick_bn(int n, int row_tiles, int num_cus, int branches) {
     return best;
 }
 
+template <int PRO, int EPI, int PF>
+static void launch_gemm_pf(const GemmArgs& g, int bn, const dim3& grid, hipStream_t s) {
+    if (bn == 128) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 128, PF>), grid, dim3(256), 0, s, g);
+    else if (bn == 96) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 96, PF>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 64, PF>), grid, dim3(256), 0, s, g);
+}
+
 template <int PRO, int EPI>
 static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches = 3) {
+    static const int pf = [] { const char* e = getenv("FSNP_GEMM_PF"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : 3; }();
     const int bn = pick_bn(n, row_tiles, num_cus, branches);
     const dim3 grid(cdiv(n, bn), row_tiles, branches);
-    if (bn == 128) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 128>), grid, dim3(256), 0, s, g);
-    else if (bn == 96) hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 96>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((tcn_gemm_kernel<PRO, EPI, 64>), grid, dim3(256), 0, s, g);
+    switch (pf) {
+        case 1: launch_gemm_pf<PRO, EPI, 1>(g, bn, grid, s); break;
+        case 2: launch_gemm_pf<PRO, EPI, 2>(g, bn, grid, s); break;
+        case 4: launch_gemm_pf<PRO, EPI, 4>(g, bn, grid, s); break;
+        default: launch_gemm_pf<PRO, EPI, 3>(g, bn, grid, s); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

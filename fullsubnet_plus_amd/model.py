@@ -151,6 +151,16 @@ class _HipModel(nn.Module):
         # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196,
         # fullsubnet.py:107-110); "full": every utterance keeps all bins (== the reference run per utterance).
         self.batch_mode = "parity"
+        # What happens to an asynchronous device-side failure (a column-split LSTM launch whose workgroups could not all be
+        # resident - a GPU shared with another process - gives up after 2 s and flags the handle):
+        #   "sync"     (default) forward() waits for its own launches, polls the flag, and - if it is set - re-runs the
+        #              batch once on the one-tile-per-CU kernel (which needs no co-residency) with a warning; a result that
+        #              forward() returned is therefore never silently invalid.  The reference's caller synchronises right
+        #              after the call anyway (inferencer.py:151-158 moves the mask to the CPU).
+        #   "deferred" nothing is waited for (throughput loops, bench.py): call check_errors() / poll_errors() before
+        #              trusting results; the next call on the handle also fails loudly.
+        self.error_check = "sync"
+        self._pipeline = False
         self._hip = _HipState()
 
     def _weights_key(self):
@@ -241,11 +251,56 @@ class _HipModel(nn.Module):
         _lib.check(rc, "fsnp_forward")
         return out
 
+    def _checked(self, run, device):
+        """Runs `run()` (one forward) under the handle's error policy (see error_check in _init_hip)."""
+        out = run()
+        if self.error_check != "sync":
+            return out
+        if self._pipeline:
+            self.flush()
+        torch.cuda.current_stream(device).synchronize()
+        lib = _lib.load()
+        if lib.fsnp_poll_errors(self._handle) == 0:
+            return out
+        msg = _lib.last_error()
+        if self.sequence_model == "GRU" and not getattr(self, "_gru_rowtile", False):
+            raise RuntimeError(msg)                      # no kernel without the co-residency requirement to fall back to
+        import warnings
+        warnings.warn(f"fullsubnet_plus_amd: {msg}; re-running this batch on the one-tile-per-CU kernel", RuntimeWarning)
+        _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, 0), "fsnp_debug_set_lstm_coop")
+        try:
+            out = run()
+            torch.cuda.current_stream(device).synchronize()
+            _lib.check(lib.fsnp_poll_errors(self._handle), "fsnp_forward (retry)")
+        finally:
+            lib.fsnp_debug_set_lstm_coop(self._handle, 1)
+        return out
+
+    def poll_errors(self):
+        """Raise if a finished launch flagged the handle; no synchronisation (fsnp_poll_errors)."""
+        _lib.check(_lib.load().fsnp_poll_errors(self._handle), "fsnp_poll_errors")
+
+    def set_pipeline(self, enable=True, device="cuda"):
+        """Pipelined serving mode (include/fsnp.h: fsnp_set_pipeline): the remainder chunks of the sub-band plan overlap
+        the NEXT forward's full-band stages.  Outputs are complete only after flush()."""
+        lib = self._ensure_handle(_resolve_device(device))
+        _lib.check(lib.fsnp_set_pipeline(self._handle, int(bool(enable))), "fsnp_set_pipeline")
+        self._pipeline = bool(enable)
+
+    def flush(self):
+        """Order the current stream after every deferred launch of earlier forwards (fsnp_flush)."""
+        if self._hip.handle is None:
+            return
+        stream = torch.cuda.current_stream(self._hip.device).cuda_stream
+        with torch.cuda.device(self._hip.device):
+            _lib.check(_lib.load().fsnp_flush(self._handle, ctypes.c_void_p(stream)), "fsnp_flush")
+
     def forward_complex(self, noisy_complex, batch_offset=0, global_batch=None):
         """the forward fed with the complex64 STFT itself ([B, F, T], any strides - torch.stft's
         output is consumed in place); mag / real / imag are derived inside the HIP repack kernel instead of by the
         three torch ops of inferencer.py:143-147.  Same result as forward(|X|, X.real, X.imag)."""
-        return self._forward_impl([noisy_complex], batch_offset, global_batch, complex_in=True)
+        return self._checked(lambda: self._forward_impl([noisy_complex], batch_offset, global_batch, complex_in=True),
+                             noisy_complex.device)
 
     def enhance(self, noisy_complex):
         """SURVEY.md 8(f-1) + (f-3): model forward + decompress_cIRM + complex multiply, all in HIP - lines 143-157 of
@@ -305,10 +360,12 @@ class _HipModel(nn.Module):
         wav, lib, stream = self._wave_args(noisy)
         B, L = wav.shape
         out = torch.empty((B, L), dtype=torch.float32, device=wav.device)
-        with torch.cuda.device(wav.device):
-            _lib.check(lib.fsnp_enhance_wave(self._handle, wav.data_ptr(), wav.stride(0), out.data_ptr(), out.stride(0), B, L,
-                                             ctypes.c_void_p(stream)), "fsnp_enhance_wave")
-        return out
+        def run():
+            with torch.cuda.device(wav.device):
+                _lib.check(lib.fsnp_enhance_wave(self._handle, wav.data_ptr(), wav.stride(0), out.data_ptr(), out.stride(0), B, L,
+                                                 ctypes.c_void_p(stream)), "fsnp_enhance_wave")
+            return out
+        return self._checked(run, wav.device)
 
     def _apply_cirm(self, mask, noisy_complex):
         B, F, T = noisy_complex.shape
@@ -510,7 +567,8 @@ class FullSubNet_Plus(_HipModel):
                     [B, 2, F//2, T] with the reference's drop_band row order (B > 1, batch_mode == "parity")
         batch_offset / global_batch: only for sharded batches (fullsubnet_plus_amd.dist).
         """
-        return self._forward_impl([noisy_mag, noisy_real, noisy_imag], batch_offset, global_batch)
+        return self._checked(lambda: self._forward_impl([noisy_mag, noisy_real, noisy_imag], batch_offset, global_batch),
+                             noisy_mag.device)
 
 
 class _FullBandLSTMParams(nn.Module):
@@ -597,7 +655,7 @@ class FullSubNet(_HipModel):
     def forward(self, noisy_mag, batch_offset=0, global_batch=None):
         """noisy_mag [B, 1, F, T] fp32 CUDA tensor (any strides) -> cIRM [B, 2, F, T] (see FullSubNet_Plus.forward
         for batch_mode and the sharding arguments)."""
-        return self._forward_impl([noisy_mag], batch_offset, global_batch)
+        return self._checked(lambda: self._forward_impl([noisy_mag], batch_offset, global_batch), noisy_mag.device)
 
 
 Model = FullSubNet_Plus  # the name BASELINE.json's north_star uses

@@ -87,7 +87,7 @@ typedef struct fsnp_config {
     int32_t fb_act;             /* FSNP_ACT_* : fb_output_activate_function */
     int32_t sb_act;             /* FSNP_ACT_* : sb_output_activate_function */
     int32_t kersize[3];         /* 3,5,10 : TSSE depthwise kernel sizes (attention_model.py:49) */
-    int32_t num_groups_in_drop_band; /* 2 (only 2 is supported in PARITY mode) */
+    int32_t num_groups_in_drop_band; /* 2; PARITY mode needs >= 2 and a global batch larger than it (feature.py:263) */
     int32_t attention;          /* FSNP_ATT_* : channel_attention_model */
     int32_t model;              /* FSNP_MODEL_* (0 = FullSubNet+) */
     int32_t sequence_model;     /* FSNP_SEQ_* : sequence_model kwarg (0 = LSTM) */
@@ -217,6 +217,21 @@ int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
  * The error word is host-mapped: without calling this, the NEXT fsnp_forward on the handle fails instead (once) as soon
  * as the failed launch has completed - a wrong result is never silent for long. */
 int fsnp_check_errors(fsnp_handle* h);
+/* The same check WITHOUT a device synchronisation: reads (and clears) the host-mapped error word.  Call it once the
+ * stream (or an event recorded after the forward) has been synchronised by other means - i.e. at the point where the
+ * result is consumed; FullSubNet_Plus.forward does so in its default error_check="sync" mode.  0 = no failure so far. */
+int fsnp_poll_errors(fsnp_handle* h);
+
+/* Pipelined serving mode (off by default).  With 1, the column-split remainder chunks that follow a one-tile-per-CU
+ * chunk in the sub-band plan (B = 32: the 32 sequences left over after 8192 fill the chip, 1.1 ms on 48 CUs) are
+ * enqueued on a private stream after that chunk, so they overlap the full-band stages of the NEXT fsnp_forward on the
+ * handle, which leave most CUs idle; the workspace is double buffered for it.  Contract: after fsnp_forward returns,
+ * work enqueued on the caller's stream is NOT ordered after those remainder chunks (the rows of `out` they own are
+ * still being written) until fsnp_flush(h, stream) has made `stream` wait for all deferred work - call it before
+ * anything consumes `out`; a serving loop calls it once per batch it hands on, a benchmark once before its final
+ * synchronisation.  Results are bit-identical to the non-pipelined call.  Switching the mode synchronises the device. */
+int fsnp_set_pipeline(fsnp_handle* h, int32_t enable);
+int fsnp_flush(fsnp_handle* h, void* hip_stream);
 
 /* Tuning hook: 1 (default) = the sub-band sequences are planned over all three kernels - the column-split kernels
  * (csrc/lstm_coop.hip <= 42 row tiles, csrc/lstm_coopn.hip 43..170; all their workgroups must be co-resident) for small
@@ -255,6 +270,11 @@ int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, in
 
 const char* fsnp_last_error(void);
 const char* fsnp_version(void);
+/* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
+ * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
+#define FSNP_ABI_VERSION 2
+int32_t fsnp_abi_version(void);
+int32_t fsnp_config_size(void);
 
 #ifdef __cplusplus
 }

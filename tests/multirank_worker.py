@@ -1,0 +1,36 @@
+"""Rank body of tests/test_gpu_multirank.py (started by torch.distributed.run): every rank drives GPU 0, computes its shard
+of a 5-utterance batch with the HIP model through fullsubnet_plus_amd.dist.forward_sharded and gathers over gloo."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, out_path = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    from fullsubnet_plus_amd import FullSubNet_Plus
+    from fullsubnet_plus_amd.dist import forward_sharded
+    from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_inputs, make_state_dict
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    m.load_state_dict(make_state_dict(0, "default"), strict=True)
+    m = m.to("cuda:0").eval()
+    m.batch_mode = mode
+    ins = [t.cuda() for t in make_inputs(5, 0.5, 77)]
+    with torch.no_grad():
+        out = forward_sharded(m, *ins, gather=True)
+    m.check_errors()
+    if dist.get_rank() == 0:
+        np.save(out_path, out.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
