@@ -61,6 +61,7 @@ def parse():
                          "sequences that do not fit the chip-filling launch) overlaps the full-band stages of forward i+1; all "
                          "K forwards are complete (fsnp_flush + synchronize) inside the timed region.  0 = every forward runs "
                          "strictly back to back.  The other mode is timed too and reported as `alt_ms_per_step`")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the other loop mode (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -215,7 +216,7 @@ def main():
             return dt, tm, o
 
         pipelined = bool(args.pipeline) and not args.wave
-        alt_elapsed, _, _ = timed_loop(not pipelined) if not args.wave else (None, None, None)
+        alt_elapsed, _, _ = timed_loop(not pipelined) if not (args.wave or args.no_alt) else (None, None, None)
         elapsed, timing, out = timed_loop(pipelined)
 
     rank_ms = None

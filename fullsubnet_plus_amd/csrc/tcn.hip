@@ -40,7 +40,22 @@ struct GemmArgs {
     int K, N, Tp, B, act;
     double gn_count;                           // elements per GroupNorm plane (PRO_GN)
     float gn_eps;
+    int ntiles_n, row_tiles, row_tiles_all;    // launch geometry: column tiles, row tiles per branch, row tiles of all branches
 };
+
+// XCD-aware workgroup order (cdna_hip_programming.md T1).  The dispatcher places workgroup id L on XCD L % 8, and every XCD
+// has its own 4 MiB L2.  With a plain (column tile, row tile) grid the 5-8 workgroups that share one 128-row A tile land on
+// 5-8 different XCDs and each of them pulls that tile from Infinity Cache / HBM again (B = 32: 100-125 MB per GEMM for a
+// 12-25 MB operand).  Here ids are decoded so that ALL column tiles of a row tile sit on ONE XCD, back to back in dispatch
+// order: the A tile is fetched once per XCD-local L2 and re-read from it.  `units` row tiles are padded to a multiple of 8;
+// returns false for the padding ids.
+__device__ __forceinline__ bool xcd_decode(int id, int inner, int units, int& unit, int& in_idx) {
+    const int xcd = id & 7, j = id >> 3;
+    in_idx = j % inner;
+    unit = (j / inner) * 8 + xcd;
+    return unit < units;
+}
+static int xcd_grid(int inner, int units) { return inner * ((units + 7) / 8 * 8); }
 
 constexpr int BM = 128, BK = 16;   // BN (32-column accumulator tiles per wave) is a template parameter
 
@@ -66,11 +81,13 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     double* red = reinterpret_cast<double*>(smem + 2 * STAGE);  // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int branch = blockIdx.z;
+    int row_tile_all, ntile;
+    if (!xcd_decode(blockIdx.x, g.ntiles_n, g.row_tiles_all, row_tile_all, ntile)) return;
+    const int branch = row_tile_all / g.row_tiles, row_tile = row_tile_all % g.row_tiles;
     const int tiles_per_utt = cdiv(g.Tp, BM);
-    const int utt = blockIdx.y / tiles_per_utt;
-    const int t0 = (blockIdx.y % tiles_per_utt) * BM;
-    const int n0 = blockIdx.x * BN;
+    const int utt = row_tile / tiles_per_utt;
+    const int t0 = (row_tile % tiles_per_utt) * BM;
+    const int n0 = ntile * BN;
 
     const float* __restrict__ A = g.A + branch * g.a_bs + (g.a_us ? (long)utt * g.a_us : ((long)utt * g.Tp) * g.lda);
     const int a_cols = g.a_cols ? g.a_cols : g.lda;
@@ -281,15 +298,15 @@ static void launch_gemm_pf(const GemmArgs& g, int bn, const dim3& grid, hipStrea
 
 template <int PRO, int EPI>
 static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches = 3) {
-    static const int pf = [] { const char* e = getenv("FSNP_GEMM_PF"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : 3; }();
+    // measured (profiles/r02_tcn_gemm.md): the prefetch distance makes no difference (1.99 / 1.90 / 1.93 / 1.93 ms full-band
+    // stage for PF = 1..4): the kernel was never latency-bound.  2 is kept (FSNP_GEMM_PF=1 = the round-1 schedule).
+    static const int pf = [] { const char* e = getenv("FSNP_GEMM_PF"); const int v = e ? atoi(e) : 0; return v == 1 ? 1 : 2; }();
     const int bn = pick_bn(n, row_tiles, num_cus, branches);
-    const dim3 grid(cdiv(n, bn), row_tiles, branches);
-    switch (pf) {
-        case 1: launch_gemm_pf<PRO, EPI, 1>(g, bn, grid, s); break;
-        case 2: launch_gemm_pf<PRO, EPI, 2>(g, bn, grid, s); break;
-        case 4: launch_gemm_pf<PRO, EPI, 4>(g, bn, grid, s); break;
-        default: launch_gemm_pf<PRO, EPI, 3>(g, bn, grid, s); break;
-    }
+    GemmArgs ga = g;
+    ga.ntiles_n = cdiv(n, bn); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
+    const dim3 grid(xcd_grid(ga.ntiles_n, ga.row_tiles_all));
+    if (pf == 1) launch_gemm_pf<PRO, EPI, 1>(ga, bn, grid, s);
+    else launch_gemm_pf<PRO, EPI, 2>(ga, bn, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,13 +320,17 @@ struct DwArgs {
     long cb_bs, w_bs, prelu_bs;
     int CH, Tp, B, dil;
     double gn_count; float gn_eps;
+    int chunks, planes;                          // DW_ROWS-row chunks per (utterance, branch) plane; planes = B * branches
 };
 constexpr int DW_ROWS = 8;
 
 __global__ __launch_bounds__(256) void tcn_dwconv_kernel(DwArgs g) {
     __shared__ double red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int branch = blockIdx.z, utt = blockIdx.y, t0 = blockIdx.x * DW_ROWS;
+    // all chunks of one (utterance, branch) plane on one XCD: the +-dilation halo rows are then L2 hits (xcd_decode)
+    int plane, chunk;
+    if (!xcd_decode(blockIdx.x, g.chunks, g.planes, plane, chunk)) return;
+    const int branch = plane / g.B, utt = plane % g.B, t0 = chunk * DW_ROWS;
     const double* st = g.gn_in + ((long)branch * g.B + utt) * 2;
     const double m = st[0] / g.gn_count;
     const double var = st[1] / g.gn_count - m * m;
@@ -390,7 +411,8 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.prelu = w.a2 + blk; g.prelu_bs = w.NB;
             g.CH = d.CH; g.Tp = d.Tp; g.B = d.B; g.dil = w.dilation[blk];
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            hipLaunchKernelGGL(tcn_dwconv_kernel, dim3(cdiv(d.Tp, DW_ROWS), d.B, branches), dim3(256), 0, s, g);
+            g.chunks = cdiv(d.Tp, DW_ROWS); g.planes = d.B * branches;
+            hipLaunchKernelGGL(tcn_dwconv_kernel, dim3(xcd_grid(g.chunks, g.planes)), dim3(256), 0, s, g);
         }
         {   // GN2 (on load) -> sconv + residual: x[M][F] = xin + GN2(y2)[M][CH] * W2^T
             GemmArgs g{};

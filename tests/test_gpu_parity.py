@@ -632,9 +632,10 @@ def test_pipelined_mode_is_bit_identical(batch):
     sd = make_state_dict(0, "default")
     m = _model(DEFAULT_MODEL_ARGS, sd, "full")
     m.error_check = "deferred"
-    assert len(m.describe_plan(batch)) > 1
     batches = [_cuda(make_inputs(batch, 0.5, 900 + i)) for i in range(3)]
     plain = [m(*b).clone() for b in batches]
+    plan = m.describe_plan(batch)
+    assert len(plan) > 1 and plan[0]["kernel"].startswith("lstm2_fc") and not plan[-1]["kernel"].startswith("lstm2_fc")
     torch.cuda.synchronize()
     m.set_pipeline(True)
     piped = [m(*b) for b in batches] + [m(*batches[0])]
