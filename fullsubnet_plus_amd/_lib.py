@@ -14,6 +14,7 @@ class FsnpConfig(ctypes.Structure):
         ("tcn_hidden", c_i32), ("num_tcn_blocks", c_i32), ("sb_hidden", c_i32), ("output_size", c_i32),
         ("norm_type", c_i32), ("fb_act", c_i32), ("sb_act", c_i32), ("kersize", c_i32 * 3),
         ("num_groups_in_drop_band", c_i32), ("attention", c_i32), ("model", c_i32), ("sequence_model", c_i32),
+        ("subband_num", c_i32),
     ]
 
 
@@ -69,7 +70,7 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 2          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 3          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

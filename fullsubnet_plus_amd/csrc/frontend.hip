@@ -249,6 +249,26 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         sq[f] = squeeze;
     }
     __syncthreads();
+    if (att == FSNP_ATT_ECA && branch == 0 && g.w.subband_num > 1) {
+        // subband_num > 1 (fullsubnet_plus.py:146-153), magnitude branch only: the normalised magnitude is reflect-padded
+        // at the high-frequency end by pad = sn - F % sn rows and viewed as [C = (F + pad) / sn channels][sn * T']; the ECA
+        // layer pools, convolves and gates those C channels, then the first F rows are kept.  So frequency f takes the gate
+        // of channel f / sn, whose squeeze is the mean over the sn rows sn c .. sn c + sn - 1 (row F + k = row F - 2 - k).
+        const int sn = g.w.subband_num, pad = sn - F % sn, C = (F + pad) / sn;
+        const float w0 = g.w.cat_w[0][0], w1 = g.w.cat_w[0][1], w2 = g.w.cat_w[0][2];
+        for (int c = tid; c < C; c += 256) {
+            float m = 0.f;
+            for (int r = 0; r < sn; ++r) { const int row = sn * c + r; m += sq[row < F ? row : 2 * (F - 1) - row]; }
+            hid[c] = m / (float)sn;
+        }
+        __syncthreads();
+        for (int o = tid; o < F; o += 256) {
+            const int c = o / sn;
+            const float y = w0 * (c > 0 ? hid[c - 1] : 0.f) + w1 * hid[c] + w2 * (c + 1 < C ? hid[c + 1] : 0.f);
+            g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-y));
+        }
+        return;
+    }
     if (att == FSNP_ATT_ECA) {
         // Conv1d(1, 1, 3, padding=1, bias=False) ALONG THE CHANNEL AXIS of the pooled vector, then sigmoid
         const float w0 = g.w.cat_w[branch][0], w1 = g.w.cat_w[branch][1], w2 = g.w.cat_w[branch][2];

@@ -637,11 +637,19 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->model != FSNP_MODEL_FULLSUBNET_PLUS && cfg->model != FSNP_MODEL_FULLSUBNET) { set_error("unknown model %d", cfg->model); return 2; }
     if (cfg->sequence_model < FSNP_SEQ_LSTM || cfg->sequence_model > FSNP_SEQ_TCN) { set_error("unknown sequence_model %d", cfg->sequence_model); return 2; }
     const bool fsn = cfg->model == FSNP_MODEL_FULLSUBNET;
+    const int subband_num = cfg->subband_num > 0 ? cfg->subband_num : 1;
+    if (cfg->subband_num < 0) { set_error("subband_num must be >= 1"); return 2; }
+    if (subband_num > 1 && (fsn || cfg->attention != FSNP_ATT_ECA)) {
+        set_error("subband_num > 1 needs channel_attention_model = ECA (the reference's other attention layers fail on it: "
+                  "fullsubnet_plus.py:47-50,155-163)");
+        return 2;
+    }
+    if (subband_num > 1 && subband_num - cfg->num_freqs % subband_num >= cfg->num_freqs) { set_error("subband_num too large for num_freqs (reflect pad)"); return 2; }
     if (fsn && cfg->sequence_model == FSNP_SEQ_TCN) { set_error("FullSubNet only supports GRU and LSTM"); return 2; }
     if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
     if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
     const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3) * (2 * cfg->fb_num_neighbors + 1);
-    if (nin > 40) { set_error("sb_num_neighbors / fb_num_neighbors too large: the sub-band input has %d features, the KX=40 kernel instantiation takes 40", nin); return 2; }
+    if (nin > 64) { set_error("sb_num_neighbors / fb_num_neighbors too large: the sub-band input has %d features, the widest (KX=64) kernel instantiation takes 64", nin); return 2; }
     if (cfg->num_freqs <= cfg->sb_num_neighbors || cfg->num_freqs <= cfg->fb_num_neighbors) { set_error("num_freqs must exceed the neighbour counts (reflect pad)"); return 2; }
     for (int c = 0; c < 3; ++c)
         if (cfg->kersize[c] < 1 || cfg->kersize[c] > 16) { set_error("kersize must be in [1,16]"); return 2; }
@@ -682,7 +690,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->H = cfg->sb_hidden;
     h->NSB = 2 * cfg->sb_num_neighbors + 1;
     h->NIN = nin;
-    h->KX = 40;
+    h->KX = nin <= 40 ? 40 : 64;       // input width the recurrent kernels are instantiated for (zero-padded K)
     h->NB = fsn ? 0 : cfg->num_tcn_blocks;
     h->Fr = cfg->num_freqs / 2;
     build_specs(h);
@@ -894,7 +902,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
         o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
         lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 && h->KX == 40; ++i) {      // the bf16-ih variant is built for the default input width only
             const int nw = i == 0 ? 4 : 12;
             o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
             lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
@@ -959,6 +967,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
     h->fw.attention = h->cfg.attention;
+    h->fw.subband_num = h->cfg.subband_num > 0 ? h->cfg.subband_num : 1;
     bind_tcn(h->tw, fb_off, d);
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
@@ -1458,6 +1467,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || (ih_bf16 != 0 && ih_bf16 != 1)) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM)"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
+    if (ih_bf16 && h->KX != 40) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 40 features only"); return 2; }
     h->ih_bf16 = ih_bf16;
     h->lw.ih_bf16 = ih_bf16;
     return 0;

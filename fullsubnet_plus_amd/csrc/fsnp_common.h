@@ -40,6 +40,7 @@ struct FrontendWeights {
     const float* fc2_b[3];   // [F]
     int ksize[3];
     int attention;           // FSNP_ATT_*; for ECA cat_w holds the 3 conv taps
+    int subband_num;         // fullsubnet_plus.py:146-153 (ECA only): > 1 groups the magnitude branch's channels
 };
 
 struct FrontendBuffers {
@@ -226,6 +227,21 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Runs `f` once per device (hipFuncSetAttribute is per device; one process may drive several GPUs from several threads).
+// A race can run it twice, never zero times before the launch that follows.
+struct PerDeviceOnce {
+    unsigned long long done = 0;
+    template <typename F>
+    void run(F f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+        if (bit && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) return;
+        f();
+        if (bit) __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+    }
+};
 
 // reflect index used by BaseModel.unfold's reflect padding (base_model.py:38): refl(-k)=k, refl(F-1+k)=F-1-k
 __host__ __device__ inline int reflect_index(int i, int F) {

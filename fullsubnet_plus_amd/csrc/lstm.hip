@@ -564,38 +564,35 @@ void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0,
                 }
 }
 
-template <int EX, int NW, bool BF>
+template <int EX, int NW, bool BF, int KX>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, KX = 40, OUT = 2;
+    constexpr int HID = 384, OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
                         (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4 + (BF ? (size_t)(HID / 16) * 64 * 16 : 0);
     LstmWeights wv = w;
     wv.wpack = BF ? (NW == 12 ? w.wpack_bf[1] : w.wpack_bf[0]) : (NW == 12 ? w.wpack12 : w.wpack);
-    if (a.prof != nullptr) {
-        auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW, BF>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
-        return;
+    if constexpr (KX == 40) {          // the phase-profile variant exists for the default input width only
+        if (a.prof != nullptr) {
+            auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW, BF>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
+            return;
+        }
     }
     auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, false, NW, BF>;
-    static bool attr_set[64] = {};             // the attribute is per device: one process may drive several GPUs
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static PerDeviceOnce attr_once;            // the attribute is per device: one process may drive several GPUs
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(64 * NW), smem, s, wv, a);
 }
 
-template <int NW, bool BF>
+template <int NW, bool BF, int KX>
 static void launch_lstm_nw(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     switch (a.ex) {
-        case 0: launch_lstm_ex<0, NW, BF>(w, a, s); break;
-        case 1: launch_lstm_ex<1, NW, BF>(w, a, s); break;
-        case 2: launch_lstm_ex<2, NW, BF>(w, a, s); break;
-        default: launch_lstm_ex<4, NW, BF>(w, a, s); break;
+        case 0: launch_lstm_ex<0, NW, BF, KX>(w, a, s); break;
+        case 1: launch_lstm_ex<1, NW, BF, KX>(w, a, s); break;
+        case 2: launch_lstm_ex<2, NW, BF, KX>(w, a, s); break;
+        default: launch_lstm_ex<4, NW, BF, KX>(w, a, s); break;
     }
 }
 
@@ -604,12 +601,15 @@ void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     // measured (profiles/r01_lstm_phase_ab.md): with VALU rows the 12-wave shape is 10 % faster, without them
     // both shapes tie and the 4-wave one needs no spills
     const int waves = w.waves != 0 ? w.waves : (a.ex > 0 ? 12 : 4);
-    if (w.ih_bf16) {
-        if (waves == 12) launch_lstm_nw<12, true>(w, a, s);
-        else launch_lstm_nw<4, true>(w, a, s);
+    if (w.KX == 64) {                  // sub-band inputs of 41..64 features (fb_num_neighbors >= 2, ...): fp32 only
+        if (waves == 12) launch_lstm_nw<12, false, 64>(w, a, s);
+        else launch_lstm_nw<4, false, 64>(w, a, s);
+    } else if (w.ih_bf16) {
+        if (waves == 12) launch_lstm_nw<12, true, 40>(w, a, s);
+        else launch_lstm_nw<4, true, 40>(w, a, s);
     } else {
-        if (waves == 12) launch_lstm_nw<12, false>(w, a, s);
-        else launch_lstm_nw<4, false>(w, a, s);
+        if (waves == 12) launch_lstm_nw<12, false, 40>(w, a, s);
+        else launch_lstm_nw<4, false, 40>(w, a, s);
     }
 }
 

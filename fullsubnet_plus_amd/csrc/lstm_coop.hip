@@ -469,13 +469,8 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     constexpr int S = HID / UNITS, NT = UNITS / 8;
     const size_t smem = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ, GRU>;
-    static bool attr_set[64] = {};             // the attribute is per device: one process may drive several GPUs
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static PerDeviceOnce attr_once;            // the attribute is per device: one process may drive several GPUs
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
     hipLaunchKernelGGL(kern, dim3(a.num_tiles * S), dim3(256), smem, s, wv, a);
@@ -504,6 +499,11 @@ static void launch_coop_units(const LstmWeights& w, const LstmArgs& a, hipStream
 
 // sub-band model: H = 384, x gathered (or dense [seq][t][NIN]), fused Linear(384, 2); w.gru selects nn.GRU
 void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (w.KX == 64) {                  // sub-band inputs of 41..64 features
+        if (w.gru) launch_coop_units<384, 64, false, true>(w, a, s);
+        else launch_coop_units<384, 64, false, false>(w, a, s);
+        return;
+    }
     if (w.gru) launch_coop_units<384, 40, false, true>(w, a, s);
     else launch_coop_units<384, 40, false, false>(w, a, s);
 }

@@ -370,22 +370,28 @@ int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups) {
     return R;
 }
 
-template <int R, bool GRU>
+template <int R, bool GRU, int KX>
 static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, KX = 40;
+    constexpr int HID = 384;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coopn;
     hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(a.coop_groups * (HID / 128)), dim3(256), 0, s, wv, a);
 }
 
-void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+template <int KX>
+static void launch_coopn_kx(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     if (w.gru) {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true>(w, a, s);
-        else launch_coopn_inst<2, true>(w, a, s);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true, KX>(w, a, s);
+        else launch_coopn_inst<2, true, KX>(w, a, s);
     } else {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false>(w, a, s);
-        else launch_coopn_inst<2, false>(w, a, s);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false, KX>(w, a, s);
+        else launch_coopn_inst<2, false, KX>(w, a, s);
     }
+}
+
+void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (w.KX == 64) launch_coopn_kx<64>(w, a, s);       // sub-band inputs of 41..64 features
+    else launch_coopn_kx<40>(w, a, s);
 }
 
 }  // namespace fsnp

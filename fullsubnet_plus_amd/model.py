@@ -487,10 +487,15 @@ class FullSubNet_Plus(_HipModel):
             raise NotImplementedError(f"Not implemented {sequence_model}")                 # sequence_model.py:72
         if channel_attention_model not in _lib.ATTENTION:
             raise NotImplementedError(f"Not implemented channel attention model {channel_attention_model}")
-        if subband_num != 1:
-            raise NotImplementedError("HIP path: subband_num != 1 is not built yet")
-        if (sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1) > 40:
-            raise NotImplementedError("HIP path: more than 40 sub-band input features (sb / fb_num_neighbors too large)")
+        if subband_num != 1 and channel_attention_model != "ECA":
+            # fullsubnet_plus.py:47-50,155-163: the reference builds its TSSE / SE / CBAM layers for
+            # num_freqs // subband_num + 1 channels and then feeds the real / imag branches num_freqs channels - its own
+            # forward raises; only ECA (no per-channel parameters) runs.
+            raise NotImplementedError("subband_num != 1 only works with channel_attention_model='ECA' (as in the reference)")
+        if subband_num < 1:
+            raise NotImplementedError("subband_num must be >= 1")
+        if (sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1) > 64:
+            raise NotImplementedError("HIP path: more than 64 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
@@ -556,6 +561,7 @@ class FullSubNet_Plus(_HipModel):
         cfg.num_groups_in_drop_band = self.num_groups_in_drop_band
         cfg.attention = _lib.ATTENTION[self.channel_attention_model]
         cfg.sequence_model = _lib.SEQUENCE_MODELS[self.sequence_model]
+        cfg.subband_num = self.subband_num
         return cfg
 
     # ------------------------------------------------------------------ forward
@@ -603,8 +609,8 @@ class FullSubNet(_HipModel):
                  ):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if (sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1) > 40:
-            raise NotImplementedError("HIP path: more than 40 sub-band input features (sb / fb_num_neighbors too large)")
+        if (sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1) > 64:
+            raise NotImplementedError("HIP path: more than 64 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")

@@ -78,10 +78,13 @@ typedef struct fsnp_config {
     int32_t num_freqs;          /* 257 */
     int32_t look_ahead;         /* 2   */
     int32_t sb_num_neighbors;   /* 15  */
-    int32_t fb_num_neighbors;   /* 0; > 0 as long as the sub-band input (2 sb + 1) + branches (2 fb + 1) has <= 40 features */
+    int32_t fb_num_neighbors;   /* 0; > 0 as long as the sub-band input (2 sb + 1) + branches (2 fb + 1) has <= 64 features
+                                   (recurrent kernels are instantiated for K = 40 and K = 64 input columns) */
     int32_t tcn_hidden;         /* 512: TCNBlock hidden_channel (causal_conv.py:68) */
     int32_t num_tcn_blocks;     /* 8, dilations 1,2,5,9,1,2,5,9 (sequence_model.py:48-57) */
-    int32_t sb_hidden;          /* 384: sb_model_hidden_size */
+    int32_t sb_hidden;          /* 384: sb_model_hidden_size.  ONLY 384 is built for the recurrent sub-band models (the MFMA tilings
+                                   of csrc/lstm*.hip are instantiated for it; anything else is rejected by fsnp_create, never
+                                   mis-computed).  Ignored for FSNP_SEQ_TCN. */
     int32_t output_size;        /* 2 */
     int32_t norm_type;          /* FSNP_NORM_* */
     int32_t fb_act;             /* FSNP_ACT_* : fb_output_activate_function */
@@ -91,6 +94,11 @@ typedef struct fsnp_config {
     int32_t attention;          /* FSNP_ATT_* : channel_attention_model */
     int32_t model;              /* FSNP_MODEL_* (0 = FullSubNet+) */
     int32_t sequence_model;     /* FSNP_SEQ_* : sequence_model kwarg (0 = LSTM) */
+    int32_t subband_num;        /* 1.  > 1 (fullsubnet_plus.py:146-153) regroups the channels of the MAGNITUDE branch's attention
+                                   layer; the reference itself only survives it with attention = FSNP_ATT_ECA (its TSSE / SE / CBAM
+                                   layers are built for num_freqs / subband_num + 1 channels but the real / imag branches feed
+                                   them num_freqs, fullsubnet_plus.py:47-50,155-163), so every other combination is rejected.
+                                   0 is read as 1. */
 } fsnp_config;
 
 /* Replaces `FullSubNet_Plus(**model.args)` (base_inferencer.py:99).  Needs a visible
@@ -272,7 +280,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 2
+#define FSNP_ABI_VERSION 3
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

@@ -188,7 +188,7 @@ def drop_band(x, num_groups=2):
 def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighbors=15,
             fb_num_neighbors=0, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
             fb_output_activate_function="ReLU", sb_output_activate_function=False,
-            output_size=2, apply_drop_band=None, stages=None, channel_attention_model="TSSE"):
+            output_size=2, apply_drop_band=None, stages=None, channel_attention_model="TSSE", subband_num=1):
     """fullsubnet_plus/model/fullsubnet_plus.py:122-209; see fsnp_numpy.forward."""
     assert noisy_mag.dim() == 4
     mag, real, imag = (Fn.pad(a, [0, look_ahead]) for a in (noisy_mag, noisy_real, noisy_imag))
@@ -203,7 +203,14 @@ def forward(p, noisy_mag, noisy_real, noisy_imag, *, look_ahead=2, sb_num_neighb
     for tag, x, att, fb in (("mag", mag, "channel_attention", "fb_model"),
                             ("real", real, "channel_attention_real", "fb_model_real"),
                             ("imag", imag, "channel_attention_imag", "fb_model_imag")):
-        xin = attention(norm(x).reshape(B, F, T), p, att, channel_attention_model)
+        if tag == "mag" and subband_num != 1:                       # fullsubnet_plus.py:146-153
+            pad_num = subband_num - F % subband_num
+            xin = Fn.pad(norm(x), [0, 0, 0, pad_num], mode="reflect")
+            xin = xin.reshape(B, (F + pad_num) // subband_num, T * subband_num)
+            xin = attention(xin, p, att, channel_attention_model)
+            xin = xin.reshape(B, F + pad_num, T)[:, :F, :]
+        else:
+            xin = attention(norm(x).reshape(B, F, T), p, att, channel_attention_model)
         rec(f"att_{tag}", xin)
         if tag == "mag":
             fb_in_mag = xin

@@ -90,6 +90,17 @@ CASES = [
     dict(name="b1_t20_tanh_relu6", wseed=26, profile="default",
          args={"fb_output_activate_function": "Tanh", "sb_output_activate_function": "ReLU6"}, inp=("spec", 1, 20, 26), stages=False),
     dict(name="b3_t16_f161", wseed=27, profile="harsh", args={"num_freqs": 161}, inp=("spec", 3, 16, 27), stages=False),
+    # subband_num > 1 (fullsubnet_plus.py:146-153): only ECA survives it in the reference
+    dict(name="b1_t20_eca_sub2", wseed=28, profile="harsh", args={"channel_attention_model": "ECA", "subband_num": 2},
+         inp=("spec", 1, 20, 28), stages=False),
+    dict(name="b3_t18_eca_sub3", wseed=29, profile="default", args={"channel_attention_model": "ECA", "subband_num": 3},
+         inp=("spec", 3, 18, 29), stages=False),
+    dict(name="b1_t16_eca_sub7_f161", wseed=30, profile="harsh",
+         args={"channel_attention_model": "ECA", "subband_num": 7, "num_freqs": 161}, inp=("spec", 1, 16, 30), stages=False),
+    # sub-band inputs wider than 40 features (fb_num_neighbors >= 2): the K = 64 instantiations of the recurrent kernels
+    dict(name="b3_t16_fbn2", wseed=31, profile="harsh", args={"fb_num_neighbors": 2}, inp=("spec", 3, 16, 31), stages=False),
+    dict(name="gru_b1_t20_fbn3", wseed=32, profile="default", args={"fb_num_neighbors": 3, "sequence_model": "GRU"},
+         inp=("spec", 1, 20, 32), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -114,6 +125,7 @@ FSN_CASES = [
     dict(name="fsn_b3_t18_la1_nb10_f161_tanh", wseed=12, profile="harsh",
          args={"look_ahead": 1, "sb_num_neighbors": 10, "num_freqs": 161, "sb_output_activate_function": "Tanh"},
          inp=("spec", 3, 18, 32), stages=False),
+    dict(name="fsn_b3_t16_fbn8", wseed=13, profile="harsh", args={"fb_num_neighbors": 8}, inp=("spec", 3, 16, 33), stages=False),
     dict(name="fsn_gru_b3_t20_default", wseed=10, profile="default", args={"sequence_model": "GRU"},
          inp=("spec", 3, 20, 30), stages=False),
 ]
@@ -272,7 +284,7 @@ def main():
         kw = dict(look_ahead=args["look_ahead"], sb_num_neighbors=args["sb_num_neighbors"],
                   fb_num_neighbors=args["fb_num_neighbors"], norm_type=args["norm_type"],
                   num_groups_in_drop_band=args["num_groups_in_drop_band"],
-                  channel_attention_model=args["channel_attention_model"],
+                  channel_attention_model=args["channel_attention_model"], subband_num=args.get("subband_num", 1),
                   fb_output_activate_function=args["fb_output_activate_function"],
                   sb_output_activate_function=args["sb_output_activate_function"])
         sub = case.get("subsample_f") or 1
@@ -283,7 +295,7 @@ def main():
               f"torch-port {np.abs(ot - payload['out']).max() / scale:.2e}"
         if mag.shape[-1] <= 40 and args["channel_attention_model"] == "TSSE" and args["sequence_model"] == "LSTM":
             sdn = {k: v.numpy() for k, v in sd.items()}
-            kwn = {k: v for k, v in kw.items() if k != "channel_attention_model"}
+            kwn = {k: v for k, v in kw.items() if k not in ("channel_attention_model", "subband_num")}
             on = fsnp_numpy.forward(sdn, mag.numpy(), real.numpy(), imag.numpy(), dtype=np.float64, **kwn)
             msg += f" numpy64-vs-ref64 {np.abs(on[:, :, ::sub, :] - payload['out64']).max() / scale:.2e}"
         print(msg, f"[{os.path.getsize(path) / 1024:.0f} KB]", flush=True)

@@ -67,6 +67,7 @@ class Golden:
                     fb_num_neighbors=a["fb_num_neighbors"], norm_type=a["norm_type"],
                     num_groups_in_drop_band=a["num_groups_in_drop_band"],
                     channel_attention_model=a.get("channel_attention_model", "TSSE"),
+                    subband_num=a.get("subband_num", 1),
                     fb_output_activate_function=a.get("fb_output_activate_function", "ReLU"),
                     sb_output_activate_function=a.get("sb_output_activate_function", False))
 

@@ -40,7 +40,8 @@ def test_create_fails_loudly_without_gpu():
 
 
 @pytest.mark.parametrize("field,value,msg", [("num_freqs", 1, b"num_freqs"), ("look_ahead", -1, b"look_ahead"),
-                                             ("sb_num_neighbors", -1, b"neighbors"), ("fb_num_neighbors", 4, b"40"),
+                                             ("sb_num_neighbors", -1, b"neighbors"), ("fb_num_neighbors", 6, b"64"),
+                                             ("subband_num", 2, b"ECA"), ("subband_num", -1, b"subband_num"),
                                              ("num_groups_in_drop_band", 0, b"num_groups_in_drop_band"),
                                              ("output_size", 3, b"output_size"), ("sb_hidden", 256, b"384"),
                                              ("norm_type", 7, b"norm_type"), ("attention", 9, b"attention"),
@@ -69,6 +70,24 @@ def test_module_has_reference_parameter_tree_and_strict_load():
         assert hasattr(m, attr)
     m2 = copy.deepcopy(m)
     assert m2._hip is not m._hip
+
+
+def test_subband_num_follows_the_reference():
+    """fullsubnet_plus.py:47-50,146-163: subband_num > 1 only runs with ECA in the reference (its other attention layers are
+    sized num_freqs // subband_num + 1 but the real / imag branches feed them num_freqs); the HIP model accepts exactly that."""
+    with pytest.raises(NotImplementedError):
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "subband_num": 2})
+    m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "subband_num": 2, "channel_attention_model": "ECA"})
+    assert m.subband_num == 2 and m._config().subband_num == 2
+
+
+def test_wide_subband_inputs_pick_the_k64_kernels():
+    """fb_num_neighbors = 2..5 (41..64 sub-band features) are accepted (K = 64 instantiations); more is refused, not mis-computed."""
+    for fbn in (2, 5):
+        m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "fb_num_neighbors": fbn})
+        assert m.sb_model.sequence_model.input_size == 31 + 3 * (2 * fbn + 1)
+    with pytest.raises(NotImplementedError):
+        FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "fb_num_neighbors": 6})
 
 
 @pytest.mark.parametrize("att", ["SE", "ECA", "CBAM"])

@@ -7,7 +7,7 @@ import torch
 from oracle import fsnp_numpy, fsnp_torch, ref_loader
 from tests._util import Golden, golden_names, rel_err
 
-SMALL = [n for n in golden_names() if "2s" not in n and "10s" not in n and "_att_" not in n and "gru" not in n and "tcn" not in n and "fbn" not in n]
+SMALL = [n for n in golden_names() if "2s" not in n and "10s" not in n and "_att_" not in n and "_eca_" not in n and "gru" not in n and "tcn" not in n and "fbn" not in n]
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -29,7 +29,7 @@ def test_numpy_fp64_matches_reference_fp64(name):
     mag, real, imag = (a.numpy() for a in g.inputs())
     sd = {k: v.numpy() for k, v in g.state_dict().items()}
     stages = {}
-    kw = {k: v for k, v in g.fwd_kwargs().items() if k != "channel_attention_model"}
+    kw = {k: v for k, v in g.fwd_kwargs().items() if k not in ("channel_attention_model", "subband_num")}
     out = fsnp_numpy.forward(sd, mag, real, imag, dtype=np.float64, stages=stages, **kw)
     # out64 is stored as fp32 -> 6e-8 quantisation
     assert rel_err(out, g.arrays["out64"]) < 5e-7
