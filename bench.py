@@ -291,6 +291,12 @@ def main():
                           "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref0, ref_last = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
+        ref_path = os.path.join(ROOT, "profiles", "r02_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
+        if os.path.exists(ref_path) and not fsn:                        # (tools/cli_e2e.py; the reference is not on this box)
+            with open(ref_path) as f:
+                rm = json.load(f)["reference_cpu_forward"]
+            base["reference_measured"] = {"value": rm["value"], "unit": "frames/s", "cores": rm["best_threads"], "kind": "reference",
+                                          "source": "profiles/r02_cli_e2e.json (committed measurement, not re-run here)"}
         result["cpu_baseline"] = base
         if args.mode == "full" and not args.wave:           # first and last utterance of the timed batch vs the oracle
             got, got_last = out[:1].cpu(), out[-1:].cpu()

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -51,6 +52,14 @@ struct GraphKey {
 };
 struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
 
+// per-step cost table of the sub-band planner (see default_costs / calibrate_costs)
+struct CostTable {
+    double ksplit[4][2];       // K-split kernel at 8 / 16 / 32 / 64 units per workgroup x {<= 1, 2} workgroups per CU
+    double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
+    double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
+    int calibrated;
+};
+
 struct TimingRec {
     hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
 };
@@ -90,6 +99,9 @@ struct fsnp_handle {
     int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
     int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
     bool rowtile_ok = true;      // a one-tile-per-CU kernel (lstm.hip / lstm_gru.hip) exists for this handle's sub-band model
+    CostTable cost{};            // per-step costs the planner minimises (defaults, then measured on the device)
+    int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (2 only if they fit)
+    int calibrate = 1;           // FSNP_CALIBRATE=0: keep the default table
     int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
     TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
     int XS = 0;                  //     row stride of its [slot][t][NIN] activations
@@ -380,47 +392,86 @@ struct SbPlan {
     std::vector<SbChunk> chunks;
     int total_slots = 0, coop_tiles = 0;
 };
-static double est_step_us(const fsnp_handle* h, const SbChunk& c) {      // measured per-step costs (profiles/r01_column_split.md)
-    if (c.kind == 1) return c.units <= 8 ? 9.0 : c.units <= 16 ? 19.0 : c.units <= 32 ? 29.0 : 55.0;
-    if (c.kind == 2) return c.rpg == 1 ? 76.0 : 151.0;
-    return cdiv(c.num_tiles, h->num_cus) * 208.0 * (1.0 + 0.11 * c.ex);
+// Per-step cost (microseconds) of every kernel shape the planner can choose.  The defaults are the round-1 measurements
+// (profiles/r01_column_split.md); fsnp_forward replaces them once per process and device with values MEASURED on the
+// device (calibrate_costs below: each shape timed at two step counts, cost = slope), so a kernel change can no longer
+// silently mis-plan.  [.][1] = the launch has more workgroups than CUs, i.e. two are co-resident per CU and share its
+// matrix pipes (their hand-off stalls then overlap: two independent row tiles per CU) - only planned when the kernels'
+// occupancy allows it (coop_occ >= 2) and, without a calibration, priced so that it is never chosen.
+static CostTable default_costs() {
+    CostTable t{};
+    const double ks[4] = {9.0, 19.0, 29.0, 55.0}, cn[2] = {76.0, 151.0};
+    for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 2.2 * ks[i]; }
+    for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
+    t.rowtile = 208.0; t.rowtile_ex = 0.11;
+    return t;
+}
+static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
+static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) {
+    if (c.kind == 1) return c.num_tiles * (h->H / c.units);
+    if (c.kind == 2) return c.groups * (h->H / 128);
+    return c.num_tiles;
+}
+static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
+    const int dbl = chunk_workgroups(h, c) > h->num_cus_real ? 1 : 0;
+    if (c.kind == 1) return h->cost.ksplit[units_index(c.units)][dbl];
+    if (c.kind == 2) return h->cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
+    return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
     const LstmPlan lp = plan_lstm_tiles(nrows, h->num_cus);
     return SbChunk{0, row0, nrows, lp.num_tiles, lp.ex, lp.rows_per_slot_tile, 0, 0, 0, 0, 0};
 }
-static SbChunk column_chunk(const fsnp_handle* h, int row0, int nrows) {   // kind 0 = not applicable (too many tiles)
-    SbChunk c{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};
-    c.units = lstm_coop_pick_units(h->H, c.num_tiles, h->num_cus_real, 8);
-    if (c.units != 0) { c.kind = 1; return c; }
-    c.rpg = lstm_coopn_plan(h->H, c.num_tiles, h->num_cus_real, &c.groups);
-    if (c.rpg != 0) c.kind = 2;
-    return c;
-}
-// Column-split launches for `nrows` sequences (any count).  A launch costs the same per step whether its kernel is full or
-// not (K split 9..55 us, one row tile per group 76 us, two 151 us), so with G = 85 groups on 256 CUs:
-//   <= 42 tiles: one K-split launch;   43..G: one tile per group;   G+1..G+42: G tiles one per group + the rest K split
-//   (97 tiles: 76 + 29 us instead of 151; up to 5 tiles more: a full K-split launch + a tiny one, 128 tiles = 85 + 42 + 1:
-//   76 + 55 + 9 us);   otherwise up to 2G: two tiles per group;   more (GRU only): full 2G launches first.
+// Column-split launches for `nrows` sequences (any count): the cheapest sequence of launches by the cost table.  A launch
+// costs the same per step whether its kernel is full or not, so this is a shortest path over tile counts: best[t] = min over
+// launch shapes c (K split at 8..64 units, one or two row tiles per three-workgroup group; one or - if the kernels fit -
+// two workgroups per CU) of cost(c) + best[t - min(t, capacity(c))].  E.g. with the round-1 table: 128 tiles = 85 one per
+// group (76 us) + 42 K-split (55) + 1 (9) instead of two per group (151); 97 = 85 + 12 (76 + 29).
 static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nrows) {
     std::vector<SbChunk> out;
-    const int G = h->H >= 128 ? h->num_cus_real / (h->H / 128) : 0;
-    if (G <= 0) return out;                 // fewer CUs than one group needs: no column-split plan (callers fall back / fail)
+    const int S3 = h->H / 128;
+    if (h->H < 128 || h->num_cus_real / S3 <= 0) return out;   // fewer CUs than one group needs: no column-split plan
+    const int T = cdiv(nrows, 32);
+    struct Shape { int kind, units, rpg, cap, dbl; };
+    std::vector<Shape> shapes;
+    for (int occ = 1; occ <= (h->coop_occ >= 2 ? 2 : 1); ++occ) {
+        const int slots = h->num_cus_real * occ;
+        for (int u = 8; u <= 64; u *= 2)
+            if (h->H % u == 0 && slots / (h->H / u) > 0) shapes.push_back({1, u, 0, slots / (h->H / u), occ - 1});
+        for (int rpg = 1; rpg <= 2; ++rpg) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
+    }
+    auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
+        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
+        return est_step_us(h, c) + 1.2;                         // + a launch (prologue / drain, amortised over ~100 steps): fewer chunks win near-ties
+    };
+    std::vector<double> best(T + 1, 0.0);
+    std::vector<int> pick(T + 1, -1);
+    for (int t = 1; t <= T; ++t) {
+        best[t] = 1e30;
+        for (int i = 0; i < (int)shapes.size(); ++i) {
+            const int n = t < shapes[i].cap ? t : shapes[i].cap;
+            if (shapes[i].kind == 2 && shapes[i].rpg == 2 && n < 2) continue;
+            const double c = shape_cost(shapes[i], n) + best[t - n];
+            if (c < best[t] - 1e-9) { best[t] = c; pick[t] = i; }
+        }
+        if (pick[t] < 0) return out;
+    }
+    std::vector<std::pair<int, int>> taken;                     // (tiles, shape), largest first
+    for (int t = T; t > 0;) {
+        const Shape& sh = shapes[pick[t]];
+        const int n = t < sh.cap ? t : sh.cap;
+        taken.push_back({n, pick[t]});
+        t -= n;
+    }
+    std::stable_sort(taken.begin(), taken.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
     int r0 = row0, left = nrows;
-    while (cdiv(left, 32) > 2 * G) { out.push_back(column_chunk(h, r0, 2 * G * 32)); r0 += 2 * G * 32; left -= 2 * G * 32; }
-    // K-split capacity at the coarsest (64-unit) split and at the finest (8-unit) one: 42 and 5 tiles on 256 CUs
-    const int k64 = h->num_cus_real / (h->H / 64), k8 = h->num_cus_real / (h->H / 8);
-    auto small = [&](int t) { return t <= k64 + k8; };                  // one K-split launch, or a full one + a tiny one (55 + 9 us)
-    int tiles = cdiv(left, 32);
-    if (tiles > G && tiles <= 2 * G && small(tiles - G)) {              // G tiles one per group first
-        out.push_back(column_chunk(h, r0, G * 32));
-        r0 += G * 32; left -= G * 32; tiles -= G;
+    for (const auto& tk : taken) {
+        const Shape& sh = shapes[tk.second];
+        const int rows = tk.first * 32 < left ? tk.first * 32 : left;
+        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
+        out.push_back(c);
+        r0 += rows; left -= rows;
     }
-    if (tiles > k64 && tiles <= k64 + k8) {                             // e.g. the 43 tiles left of parity-mode B = 32 (128 tiles)
-        out.push_back(column_chunk(h, r0, k64 * 32));
-        r0 += k64 * 32; left -= k64 * 32;
-    }
-    if (left > 0) out.push_back(column_chunk(h, r0, left));
     return out;
 }
 
@@ -432,39 +483,36 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
         p.chunks.push_back(c);
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
-    const int col_max_rows = h->H >= 128 ? 2 * (h->num_cus_real / (h->H / 128)) * 32 : 0;   // one lstm_coopn launch: 170 tiles on 256 CUs
-    auto usable = [](const std::vector<SbChunk>& v) {          // a column-split plan exists and every chunk found a kernel
-        if (v.empty()) return false;
-        for (const SbChunk& c : v) if (c.kind == 0) return false;
-        return true;
-    };
+    auto cost_of = [&](const std::vector<SbChunk>& v) { double c = 0; for (const SbChunk& k : v) c += est_step_us(h, k); return c; };
     const bool rowtile_ok = h->rowtile_ok;                     // a one-tile-per-CU kernel exists for this cell / size
     const bool coop_on = h->lstm_coop != 0 || !rowtile_ok;     // (without one the column-split kernels are the only path)
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
     // bf16-ih mode (configs[4]) only changes the row-tile kernel: sequences that run on a column-split kernel (small
     // batches, remainder tiles) stay fp32 - more accurate and, there, faster
     if (!coop_on) { push(whole); return p; }
-    if (num_rows <= col_max_rows || !rowtile_ok) {
-        const std::vector<SbChunk> cols = plan_columns(h, 0, num_rows);
-        if (usable(cols)) { for (const SbChunk& c : cols) push(c); return p; }
-        if (rowtile_ok) push(whole);                           // else: empty plan = "this device cannot run the model"
-        return p;
-    }
-    // full rounds on the row-tile kernel + the remainder on whatever runs it fastest, if that beats VALU rows / one more round
+    // candidates: everything column-split; one launch of the row-tile kernel (VALU rows / extra rounds as needed); full
+    // rounds of the row-tile kernel + the remainder column-split (must be `composite_gain` cheaper than the single launch)
     const int full = h->num_cus * 32, q = num_rows / full, rem = num_rows - q * full;
-    if (q >= 1 && rem > 0) {
-        std::vector<SbChunk> rc = rem <= col_max_rows ? plan_columns(h, q * full, rem) : std::vector<SbChunk>{rowtile_chunk(h, q * full, rem)};
-        const SbChunk main_c{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0};
-        double cost = est_step_us(h, main_c);
-        for (const SbChunk& c : rc) cost += est_step_us(h, c);
-        const bool rc_ok = rem > col_max_rows || usable(rc);
-        if (rc_ok && cost < h->composite_gain * est_step_us(h, whole)) {
-            push(main_c);
-            for (const SbChunk& c : rc) push(c);
-            return p;
+    std::vector<SbChunk> best;
+    double best_cost = 1e30;
+    if (cdiv(num_rows, 32) <= 4 * h->num_cus_real || !rowtile_ok) {        // (bounded: the shortest path is O(tiles x shapes))
+        const std::vector<SbChunk> cols = plan_columns(h, 0, num_rows);
+        if (!cols.empty()) { best = cols; best_cost = cost_of(cols); }
+    }
+    if (rowtile_ok) {
+        const double cw = est_step_us(h, whole);
+        if (cw < best_cost) { best = {whole}; best_cost = cw; }
+        if (q >= 1 && rem > 0) {
+            std::vector<SbChunk> comp{SbChunk{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0}};
+            const std::vector<SbChunk> rc = plan_columns(h, q * full, rem);
+            if (!rc.empty()) {
+                comp.insert(comp.end(), rc.begin(), rc.end());
+                const double cc = cost_of(comp);
+                if (cc < h->composite_gain * cw && cc < best_cost) { best = comp; best_cost = cc; }
+            }
         }
     }
-    push(whole);
+    for (const SbChunk& c : best) push(c);                     // empty = "this device cannot run the model"
     return p;
 }
 // Launches chunks [first, last) of the plan on stream s.  `bar` = per-tile arrival counters followed (at bar +
@@ -612,6 +660,133 @@ static double fb_lstm_flops_per_frame(const fsnp_handle* h) {   // original Full
     return 2.0 * h->NG * CH * (F + CH) + 2.0 * h->NG * CH * (2 * CH) + 2.0 * CH * F;
 }
 
+// The fused recurrent model + Linear on a dense input x [num_seq][steps][NIN] with a given plan (fsnp_lstm2_fc, calibration).
+static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, float* out, int num_seq, int steps, hipStream_t s) {
+    const int num_slots = plan.total_slots;
+    const bool coop = plan.coop_tiles != 0;
+    const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
+    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
+    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 4, 256);
+    const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
+    if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
+    if (h->pipeline && h->side_stream) FSNP_HIP_CHECK(hipStreamSynchronize(h->side_stream));   // slot 0 may still be read
+    RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
+    h->have_last = false;   // the workspace no longer holds a forward's stages
+    if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, s);
+    LstmArgs a{};
+    a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
+    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
+    launch_sb_lstm(h, plan, a, reinterpret_cast<float*>(h->ws + coop_off),
+                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes),
+                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes + coop_bar_bytes), s);
+    FSNP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- calibration of the planner's cost table: once per process and (device, cell, sizes), on the first call that plans.
+// Every launch shape the planner can pick is run on zeros at two step counts; the per-step cost is the slope (launch and
+// prologue cancel).  ~0.1 s and ~60 MB of scratch, then cached for every later handle of the same kind.  FSNP_CALIBRATE=0
+// keeps the built-in table (the round-1 measurements).
+struct CalKey {
+    int dev, H, KX, gru, occ, cus;
+    bool operator<(const CalKey& o) const {
+        const int a[6] = {dev, H, KX, gru, occ, cus}, b[6] = {o.dev, o.H, o.KX, o.gru, o.occ, o.cus};
+        for (int i = 0; i < 6; ++i) if (a[i] != b[i]) return a[i] < b[i];
+        return false;
+    }
+};
+static std::mutex g_cal_mu;
+static std::map<CalKey, CostTable> g_cal_cache;
+
+static int calibrate_costs(fsnp_handle* h) {
+    if (h->cost.calibrated || !h->calibrate || h->sb_tcn || !h->committed) return 0;
+    const CalKey key{h->device, h->H, h->KX, h->gru, h->coop_occ, h->num_cus_real};
+    {
+        std::lock_guard<std::mutex> lk(g_cal_mu);
+        auto it = g_cal_cache.find(key);
+        if (it != g_cal_cache.end()) { h->cost = it->second; return 0; }
+    }
+    const int S3 = h->H / 128, occ = h->coop_occ >= 2 ? 2 : 1;
+    const int steps_a = 6, steps_b = 22;
+    const int max_tiles = std::max(h->num_cus_real, (h->num_cus_real * occ / S3) * 2);
+    const size_t x_floats = (size_t)max_tiles * 32 * steps_b * h->NIN, o_floats = (size_t)max_tiles * 32 * 2 * steps_b;
+    float* scratch = nullptr;
+    hipStream_t cs = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (x_floats + o_floats) * 4));
+    int rc = 0;
+    auto cleanup = [&] {
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(scratch);
+    };
+#define FSNP_CAL_CHECK(expr) do { if ((expr) != hipSuccess) { set_error("calibration: %s failed", #expr); cleanup(); return 4; } } while (0)
+    FSNP_CAL_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    FSNP_CAL_CHECK(hipEventCreate(&e0));
+    FSNP_CAL_CHECK(hipEventCreate(&e1));
+    FSNP_CAL_CHECK(hipMemsetAsync(scratch, 0, (x_floats + o_floats) * 4, cs));
+    const bool had_pipeline = h->pipeline != 0;
+    CostTable t = h->cost;
+    // one shape: returns its per-step cost in microseconds (< 0 on failure)
+    auto time_shape = [&](SbChunk c) -> double {
+        c.row0 = 0; c.nrows = c.num_tiles * 32; c.slot0 = 0; c.coop_tile0 = 0;
+        SbPlan plan;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = c.kind != 0 ? c.num_tiles : 0;
+        double ms[2] = {0, 0};
+        for (int k = 0; k < 2; ++k) {
+            const int steps = k == 0 ? steps_a : steps_b;
+            for (int rep = 0; rep < 2; ++rep) {            // rep 0 warms caches / code, rep 1 is timed
+                if (hipEventRecord(e0, cs) != hipSuccess) return -1.0;
+                if (run_dense_plan(h, plan, scratch, scratch + x_floats, c.nrows, steps, cs)) return -1.0;
+                if (hipEventRecord(e1, cs) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
+                float f = 0;
+                if (hipEventElapsedTime(&f, e0, e1) != hipSuccess) return -1.0;
+                ms[k] = f;
+            }
+        }
+        return (ms[1] - ms[0]) * 1000.0 / (steps_b - steps_a);
+    };
+    (void)had_pipeline;
+    for (int o = 0; o < occ && rc == 0; ++o) {
+        const int slots = h->num_cus_real * (o + 1);
+        for (int ui = 0; ui < 4 && rc == 0; ++ui) {
+            const int u = 8 << ui, S = h->H / u;
+            int tiles = slots / S;
+            if (o == 1 && tiles * S <= h->num_cus_real) continue;       // no launch of this shape needs the second slot
+            if (tiles <= 0) continue;
+            const double us = time_shape(SbChunk{1, 0, 0, tiles, 0, 32, u, 0, 0, 0, 0});
+            if (us < 0) rc = 4; else t.ksplit[ui][o] = us;
+        }
+        for (int rpg = 1; rpg <= 2 && rc == 0; ++rpg) {
+            const int groups = slots / S3;
+            if (groups <= 0) continue;
+            const double us = time_shape(SbChunk{2, 0, 0, groups * rpg, 0, 32, 0, groups, rpg, 0, 0});
+            if (us < 0) rc = 4; else t.coopn[rpg - 1][o] = us;
+        }
+    }
+    if (rc == 0 && h->rowtile_ok) {
+        const double us0 = time_shape(SbChunk{0, 0, 0, h->num_cus_real, 0, 32, 0, 0, 0, 0, 0});
+        if (us0 < 0) rc = 4;
+        else t.rowtile = us0;           // the VALU-row surcharge keeps its measured ratio (0.11 per row)
+    }
+    cleanup();
+#undef FSNP_CAL_CHECK
+    if (rc) { if (g_last_error.empty()) set_error("calibration of the sub-band planner failed"); return rc; }
+    if (*reinterpret_cast<volatile unsigned*>(h->d_err) != 0) {
+        // a calibration launch gave up (its workgroups were not all resident): never plan two workgroups per CU
+        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
+        t = default_costs();
+        h->coop_occ = 1;
+    }
+    t.calibrated = 1;
+    h->cost = t;
+    std::lock_guard<std::mutex> lk(g_cal_mu);
+    g_cal_cache[key] = t;
+    return 0;
+}
+
 }  // namespace fsnp
 
 extern "C" {
@@ -680,6 +855,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->model = cfg->model;
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
     h->rowtile_ok = !h->gru;
+    h->cost = default_costs();
+    const char* ce = getenv("FSNP_CALIBRATE");
+    if (ce && ce[0] == '0') h->calibrate = 0;
+    const char* oe = getenv("FSNP_COOP_OCC");          // 1 = never plan two column-split workgroups per CU
+    h->coop_occ = oe && oe[0] == '1' ? 1 : 2;          // (2 is confirmed against the kernels' occupancy at commit time)
     h->sb_tcn = cfg->sequence_model == FSNP_SEQ_TCN;
     h->XS = (int)align_up(nin, 4);
     h->NG = h->gru ? 3 : 4;
@@ -983,6 +1163,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     h->d_refl_w = d + o_refl;
     h->d_refl_wfb = d + o_reflfb;
+    if (h->coop_occ >= 2 && !h->sb_tcn) {       // two workgroups per CU only if EVERY column-split instantiation fits twice
+        int occ = 2;
+        for (int u = 8; u <= 64; u *= 2) occ = std::min(occ, lstm_coop_occupancy(h->lw, u));
+        for (int rpg = 1; rpg <= 2; ++rpg) occ = std::min(occ, lstm_coopn_occupancy(h->lw, rpg));
+        if (occ < 2) h->coop_occ = 1;
+    }
     h->committed = true;
     (void)Fr;
     return 0;
@@ -1025,6 +1211,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     if (fsn && fb_units == 0) { set_error("FullSubNet: at most %d utterances per call (full-band LSTM residency); split the batch", 32 * (h->num_cus_real / 16)); return 2; }
 
     FSNP_ON_DEVICE(h);
+    if (calibrate_costs(h)) return 4;            // first planning call of the process for this kind of handle only (~0.1 s)
     const int num_rows = batch * rows_per_utt(h, mode);
     const SbPlan plan = plan_sb(h, num_rows);
     if (plan.chunks.empty()) {
@@ -1340,28 +1527,10 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_ON_DEVICE(h);
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
+    if (calibrate_costs(h)) return 4;
     const SbPlan plan = plan_sb(h, num_seq);
-    const int num_slots = plan.total_slots;
-    const bool coop = plan.coop_tiles != 0;
-    const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
-    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 4, 256);
-    const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
     if (plan.chunks.empty()) { set_error("fsnp_lstm2_fc: no kernel plan for %d sequences on this device", num_seq); return 2; }
-    if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
-    if (h->pipeline && h->side_stream) FSNP_HIP_CHECK(hipStreamSynchronize(h->side_stream));   // slot 0 may still be read
-    RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
-    h->have_last = false;   // the workspace no longer holds a forward's stages
-    if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
-    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, s);
-    LstmArgs a{};
-    a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
-    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
-    launch_sb_lstm(h, plan, a, reinterpret_cast<float*>(h->ws + coop_off),
-                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes),
-                   reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes + coop_bar_bytes), s);
-    FSNP_HIP_CHECK(hipGetLastError());
-    return 0;
+    return run_dense_plan(h, plan, x, out, num_seq, steps, s);
 }
 
 int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t numel) {
@@ -1409,9 +1578,20 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
 
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks) {
+    return fsnp_debug_plan_rows2(num_rows, num_cus, hidden, gru, coop, composite_gain, 1, nullptr, out, max_chunks);
+}
+
+int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
+                          int32_t workgroups_per_cu, const double* costs, int32_t* out, int32_t max_chunks) {
     if (!out || num_rows <= 0 || num_cus <= 0 || hidden < 128 || hidden % 128 != 0 || max_chunks <= 0) { set_error("fsnp_debug_plan_rows: bad argument"); return -1; }
     fsnp_handle h;                      // host-only: the planner never touches the device
     h.H = hidden; h.num_cus = num_cus; h.num_cus_real = num_cus; h.gru = gru; h.lstm_coop = coop; h.composite_gain = composite_gain;
+    h.cost = default_costs(); h.coop_occ = workgroups_per_cu >= 2 ? 2 : 1;
+    if (costs) {
+        for (int i = 0; i < 4; ++i) { h.cost.ksplit[i][0] = costs[2 * i]; h.cost.ksplit[i][1] = costs[2 * i + 1]; }
+        for (int i = 0; i < 2; ++i) { h.cost.coopn[i][0] = costs[8 + 2 * i]; h.cost.coopn[i][1] = costs[9 + 2 * i]; }
+        h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
+    }
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 2: plan as a GRU handle WITH its one-tile-per-CU kernel (lstm_gru.hip)
     h.gru = gru != 0;
     const SbPlan plan = plan_sb(&h, num_rows);
@@ -1424,6 +1604,38 @@ int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int3
         ++n;
     }
     return n;
+}
+
+int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, int32_t* occ) {
+    if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
+    for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
+    for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
+    out[12] = h->cost.rowtile; out[13] = h->cost.rowtile_ex;
+    if (calibrated) *calibrated = h->cost.calibrated;
+    if (occ) *occ = h->coop_occ;
+    return 0;
+}
+
+int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups_per_cu) {
+    if (!h || (workgroups_per_cu != 1 && workgroups_per_cu != 2)) { set_error("fsnp_debug_set_costs: bad argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_debug_set_costs: commit the weights first (the kernels' occupancy is checked then)"); return 2; }
+    if (workgroups_per_cu == 2 && !h->sb_tcn) {
+        FSNP_ON_DEVICE(h);
+        int occ = 2;
+        for (int u = 8; u <= 64; u *= 2) occ = std::min(occ, lstm_coop_occupancy(h->lw, u));
+        for (int rpg = 1; rpg <= 2; ++rpg) occ = std::min(occ, lstm_coopn_occupancy(h->lw, rpg));
+        if (occ < 2) { set_error("fsnp_debug_set_costs: the column-split kernels do not fit twice on a CU (occupancy %d)", occ); return 2; }
+    }
+    h->cost = default_costs();
+    if (costs) {
+        for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] = costs[2 * i]; h->cost.ksplit[i][1] = costs[2 * i + 1]; }
+        for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] = costs[8 + 2 * i]; h->cost.coopn[i][1] = costs[9 + 2 * i]; }
+        h->cost.rowtile = costs[12]; h->cost.rowtile_ex = costs[13];
+    }
+    h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
+    h->coop_occ = workgroups_per_cu;
+    drop_graphs(h);
+    return 0;
 }
 
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks) {

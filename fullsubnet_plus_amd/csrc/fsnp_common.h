@@ -206,6 +206,9 @@ void lstm_coopn_pack_weights(int H, int NIN, int KX, const float* wih0, const fl
                              const float* whh1, float* wpack);
 int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups);   // rows tiles per group (0 = not applicable)
 int lstm_coop_pick_units(int H, int row_tiles, int num_cus, int min_units);   // 0 = not applicable
+// workgroups of one instantiation that fit a CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 = unknown)
+int lstm_coop_occupancy(const LstmWeights& w, int units);
+int lstm_coopn_occupancy(const LstmWeights& w, int rows_per_group);
 size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
 size_t lstm_pack_floats_bf16ih(int H, int KX, int NW);

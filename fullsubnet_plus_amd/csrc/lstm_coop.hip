@@ -464,13 +464,18 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles) {
     return (size_t)row_tiles * (4 * (size_t)(H / 8) * 64 + 2 * (size_t)(H / 8) * 16) * 16;
 }
 
+// occ != nullptr: do not launch; report how many workgroups of this instantiation fit one CU at once
 template <int HID, int KX, int UNITS, bool SEQ, bool GRU>
-static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     constexpr int S = HID / UNITS, NT = UNITS / 8;
     const size_t smem = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ, GRU>;
     static PerDeviceOnce attr_once;            // the attribute is per device: one process may drive several GPUs
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+    if (occ) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess) *occ = 0;
+        return;
+    }
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
     hipLaunchKernelGGL(kern, dim3(a.num_tiles * S), dim3(256), smem, s, wv, a);
@@ -485,27 +490,36 @@ int lstm_coop_pick_units(int H, int row_tiles, int num_cus, int min_units) {
 }
 
 template <int HID, int KX, bool SEQ, bool GRU>
-static void launch_coop_units(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+static void launch_coop_units(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ = nullptr) {
     switch (a.coop_units) {
-        case 8: launch_coop_inst<HID, KX, 8, SEQ, GRU>(w, a, s); break;
-        case 16: launch_coop_inst<HID, KX, 16, SEQ, GRU>(w, a, s); break;
-        case 32: launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s); break;
+        case 8: launch_coop_inst<HID, KX, 8, SEQ, GRU>(w, a, s, occ); break;
+        case 16: launch_coop_inst<HID, KX, 16, SEQ, GRU>(w, a, s, occ); break;
+        case 32: launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s, occ); break;
         default:
-            if constexpr (!SEQ) launch_coop_inst<HID, KX, 64, SEQ, GRU>(w, a, s);
-            else launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s);
+            if constexpr (!SEQ) launch_coop_inst<HID, KX, 64, SEQ, GRU>(w, a, s, occ);
+            else launch_coop_inst<HID, KX, 32, SEQ, GRU>(w, a, s, occ);
             break;
     }
 }
 
 // sub-band model: H = 384, x gathered (or dense [seq][t][NIN]), fused Linear(384, 2); w.gru selects nn.GRU
-void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+static void dispatch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     if (w.KX == 64) {                  // sub-band inputs of 41..64 features
-        if (w.gru) launch_coop_units<384, 64, false, true>(w, a, s);
-        else launch_coop_units<384, 64, false, false>(w, a, s);
+        if (w.gru) launch_coop_units<384, 64, false, true>(w, a, s, occ);
+        else launch_coop_units<384, 64, false, false>(w, a, s, occ);
         return;
     }
-    if (w.gru) launch_coop_units<384, 40, false, true>(w, a, s);
-    else launch_coop_units<384, 40, false, false>(w, a, s);
+    if (w.gru) launch_coop_units<384, 40, false, true>(w, a, s, occ);
+    else launch_coop_units<384, 40, false, false>(w, a, s, occ);
+}
+void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s) { dispatch_lstm_coop(w, a, s, nullptr); }
+// workgroups of the sub-band K-split kernel at `units` hidden units per workgroup that fit one CU at once (0 = unknown)
+int lstm_coop_occupancy(const LstmWeights& w, int units) {
+    LstmArgs a{};
+    a.coop_units = units;
+    int occ = 0;
+    dispatch_lstm_coop(w, a, nullptr, &occ);
+    return occ;
 }
 
 // full-band model of the original FullSubNet: H = 512, dense input rows of <= 264 features, h1 sequence out

@@ -371,27 +371,39 @@ int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups) {
 }
 
 template <int R, bool GRU, int KX>
-static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     constexpr int HID = 384;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coopn;
+    if (occ) {        // do not launch: how many workgroups of this instantiation fit one CU at once
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, reinterpret_cast<const void*>(lstm2_coopn_kernel<HID, KX, R, GRU>), 256, 0) != hipSuccess) *occ = 0;
+        return;
+    }
     hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(a.coop_groups * (HID / 128)), dim3(256), 0, s, wv, a);
 }
 
 template <int KX>
-static void launch_coopn_kx(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+static void launch_coopn_kx(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     if (w.gru) {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true, KX>(w, a, s);
-        else launch_coopn_inst<2, true, KX>(w, a, s);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true, KX>(w, a, s, occ);
+        else launch_coopn_inst<2, true, KX>(w, a, s, occ);
     } else {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false, KX>(w, a, s);
-        else launch_coopn_inst<2, false, KX>(w, a, s);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false, KX>(w, a, s, occ);
+        else launch_coopn_inst<2, false, KX>(w, a, s, occ);
     }
 }
 
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    if (w.KX == 64) launch_coopn_kx<64>(w, a, s);       // sub-band inputs of 41..64 features
-    else launch_coopn_kx<40>(w, a, s);
+    if (w.KX == 64) launch_coopn_kx<64>(w, a, s, nullptr);       // sub-band inputs of 41..64 features
+    else launch_coopn_kx<40>(w, a, s, nullptr);
+}
+int lstm_coopn_occupancy(const LstmWeights& w, int rows_per_group) {
+    LstmArgs a{};
+    a.coop_rows_per_group = rows_per_group;
+    int occ = 0;
+    if (w.KX == 64) launch_coopn_kx<64>(w, a, nullptr, &occ);
+    else launch_coopn_kx<40>(w, a, nullptr, &occ);
+    return occ;
 }
 
 }  // namespace fsnp

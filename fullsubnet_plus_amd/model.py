@@ -458,6 +458,22 @@ class _HipModel(nn.Module):
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]
 
+    def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
+        """Test hook: pin the planner's cost table (14 values, planner_costs() order; None = built-in) and whether it may put
+        two column-split workgroups on a CU (fsnp_debug_set_costs)."""
+        lib = self._ensure_handle(_resolve_device(device))
+        arr = (ctypes.c_double * 14)(*costs) if costs is not None else None
+        _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
+
+    def planner_costs(self):
+        """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
+        buf, cal, occ = (ctypes.c_double * 14)(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
+        v = list(buf)
+        return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1]} for i, u in enumerate((8, 16, 32, 64))},
+                "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
+                "rowtile_us": v[12], "valu_row_surcharge": v[13], "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
+
     def forward_flops(self, batch, frames, parity=False):
         return float(_lib.load().fsnp_forward_flops(self._handle, batch, frames, int(parity)))
 

@@ -196,11 +196,29 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
+/* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
+ * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU},
+ * out[8..11] = three-way split with 1 / 2 row tiles per group x {one, two}, out[12] = one round of the one-tile-per-CU
+ * kernel, out[13] = its relative surcharge per VALU row.  The built-in defaults (round-1 measurements) are replaced by
+ * values MEASURED on the device the first time a call on a handle of this kind plans (once per process: ~0.1 s, the only
+ * synchronising moment of fsnp_forward; FSNP_CALIBRATE=0 keeps the defaults): *calibrated = 1 from then on.  *occ =
+ * workgroups per CU the column-split kernels may be planned with (2 only if every instantiation fits twice, FSNP_COOP_OCC=1
+ * forces 1). */
+int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, int32_t* occ);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
  * (kernel 1) or groups (kernel 2), row tiles per group, first slot}.  Used by the CPU tests. */
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks);
+
+/* Test hook: pin the handle's cost table (fsnp_get_costs' layout; NULL = the built-in round-1 table) and the number of
+ * column-split workgroups the planner may put on a CU (2 is refused if the kernels do not fit twice); the lazy calibration
+ * then leaves it alone.  Needs committed weights. */
+int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups_per_cu);
+/* The same with `workgroups_per_cu` (1 or 2) column-split workgroups allowed per CU and, if costs != NULL, a cost table in
+ * fsnp_get_costs' layout instead of the built-in one. */
+int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
+                          int32_t workgroups_per_cu, const double* costs, int32_t* out, int32_t max_chunks);
 
 /* Static facts for roofline accounting: algorithmic FLOPs of one forward. */
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);

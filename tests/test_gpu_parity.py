@@ -116,6 +116,54 @@ def test_lstm2_fc_cooperative_kernel(n, steps):
     assert rel_err(tile, want) < 2e-5
 
 
+CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11]   # a table in which two workgroups per CU pay
+
+
+@pytest.mark.parametrize("n,steps", [(257, 40), (514, 20), (1285, 12), (2700, 9), (4112, 7), (5440, 6), (8000, 5), (10870, 4)])
+def test_column_split_two_workgroups_per_cu(n, steps):
+    """The planner may put TWO column-split workgroups on a CU (their hand-off stalls overlap: two independent row tiles share
+    the CU's matrix pipes) when the kernels fit twice - 257 sequences then run at 8 units per workgroup (432 workgroups),
+    129 tiles as one launch of 129 groups, 340 tiles as 170 groups of two.  Pinned here with a cost table that makes it pay;
+    the result must equal the oracle, the one-per-CU plan of round 1 (same kernels, same summation order per row: bitwise)
+    and itself on repetition."""
+    sd = make_state_dict(9, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    rng = np.random.Generator(np.random.PCG64(99 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
+    m.lstm2_fc(x[:4])                                     # creates the handle, commits the weights
+    m.debug_set_costs(None, 1)
+    one = m.lstm2_fc(x).cpu().numpy()
+    m.check_errors()
+    m.debug_set_costs(CHEAP_TWO_PER_CU, 2)
+    two = m.lstm2_fc(x).cpu().numpy()
+    m.check_errors()
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
+    _record(f"lstm_two_per_cu_{n}x{steps}", rel=rel_err(two, want), vs_one_per_cu=rel_err(two, one))
+    assert rel_err(two, want) < 2e-5 and rel_err(one, want) < 2e-5
+    for _ in range(3):
+        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), two)
+
+
+def test_planner_costs_are_measured_on_the_device():
+    """The cost table the planner minimises is calibrated on the device at the first planning call of the process (fsnp.h:
+    fsnp_get_costs); kept in gpurun_out/planner_costs.json.  Sanity: every shape measured, finer K splits are cheaper per
+    step, two row tiles per group cost more than one, and the B = 32 headline still runs 8192 sequences on the one-tile-per-CU
+    kernel first."""
+    sd = make_state_dict(0, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    m(*_cuda(make_spec(1, 12, 5)))
+    c = m.planner_costs()
+    with open(os.path.join(ROOT, "gpurun_out", "planner_costs.json"), "w") as f:
+        json.dump(c, f, indent=1)
+    assert c["calibrated"]
+    ks = [c["ksplit_us"][u]["one_per_cu"] for u in (8, 16, 32, 64)]
+    assert all(1.0 < v < 400.0 for v in ks) and ks[0] < ks[2] < ks[3]
+    assert 20.0 < c["coopn_us"][1]["one_per_cu"] < c["coopn_us"][2]["one_per_cu"] < 600.0
+    assert 120.0 < c["rowtile_us"] < 400.0
+    plan = m.describe_plan(32)
+    assert plan[0]["kernel"].startswith("lstm2_fc") and plan[0]["sequences"] == 8192
+
+
 def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle():
     """B = 8 (65 row tiles -> lstm_coopn.hip, one row tile per group) through the whole forward, cumulative norm
     (per-row (m, d) tables) included."""

@@ -377,12 +377,17 @@ def test_subband_plans_cover_every_sequence_and_fit_the_chip(rows, gru):
 
 
 def test_subband_plan_choices_match_the_design():
-    """The cuts DESIGN.md 4.1 / 4.1b describe, for the batch sizes of BASELINE.json and of the tables in profiles/."""
+    """The cuts DESIGN.md 4.1 / 4.1b describe, for the batch sizes of BASELINE.json and of the tables in profiles/ (built-in
+    cost table = the round-1 measurements, one workgroup per CU; the shortest-path planner may move tiles between chunks of
+    equal total cost, so multi-chunk cuts are checked by kernel sequence, coverage and capacity)."""
     kinds = lambda rows, **kw: [(c["kind"], c["rows"]) for c in _plan(rows, **kw)]
+    seq = lambda rows, **kw: [c["kind"] for c in _plan(rows, **kw)]
     assert kinds(257) == [(1, 257)] and _plan(257)[0]["par"] == 16                 # B = 1: K split, 16 units
     assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
     assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
-    assert kinds(4096) == [(2, 2720), (1, 1344), (1, 32)]                           # parity-mode B = 32: 128 tiles = 85 + 42 + 1
+    p = _plan(4096)                                                                 # parity-mode B = 32: 128 tiles = one per group
+    assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # + 42 + a few (76 + 55 + 9 us)
+    assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
     assert kinds(4256) == [(2, 4256)] and _plan(4256)[0]["rpg"] == 2                # 133 tiles: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
@@ -390,12 +395,50 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
     assert kinds(8224, coop=0) == [(0, 8224)] and _plan(8224, coop=0)[0]["ex"] == 1  # column-split kernels off: VALU rows
     assert kinds(8224, gain=0.0) == [(0, 8224)]                                     # composite plans off
-    g = kinds(65792, gru=1)                                                         # GRU, B = 256: full 170-tile launches,
-    assert [k for k, _ in g[:-1]] == [2] * 12 and g[-1] == (1, 65792 - 12 * 5440)   # the short last one K split
-    assert kinds(8224, gru=1) == [(2, 5440), (2, 2720), (1, 64)]                    # GRU, B = 32: 170 + 85 + 2 tiles
-    assert kinds(3084) == [(2, 2720), (1, 364)]                                     # B = 12: 85 tiles one per group + 12 K split
-    assert kinds(4112) == [(2, 2720), (1, 1344), (1, 48)]                           # B = 16: 129 tiles = 85 + 42 + 2
-    assert kinds(1376) == [(1, 1344), (1, 32)]                                      # 43 tiles: a full K-split launch + a tiny one
+    g = _plan(65792, gru=1)                                                         # GRU, B = 256: 170-tile launches (two per group)
+    assert [c["kind"] for c in g[:12]] == [2] * 12 and all(c["rpg"] == 2 and c["tiles"] <= 170 for c in g[:12])
+    assert all(c["tiles"] == 170 for c in g[:11])
+    assert sum(c["rows"] for c in g) == 65792 and all(c["kind"] == 1 for c in g[12:])   # the short rest K split
+    g = _plan(8224, gru=1)                                                          # GRU, B = 32: 257 tiles = 170 + 85 + 2
+    assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
+    p = _plan(3084)                                                                 # B = 12: 97 tiles = one per group + the rest K split
+    assert [c["kind"] for c in p] == [2, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 32 and sum(c["rows"] for c in p) == 3084
+    assert seq(4112) == [2, 1, 1]                                                   # B = 16: 129 tiles = 85 + 42 + 2
+    p = _plan(1376)                                                                 # 43 tiles: a full K-split launch + a tiny one
+    assert [c["kind"] for c in p] == [1, 1] and p[0]["par"] == 64 and p[1]["par"] == 8 and sum(c["rows"] for c in p) == 1376
+
+
+def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
+    """fsnp_debug_plan_rows2: the planner minimises whatever cost table it is given (on the device: the calibrated one).  With
+    two column-split workgroups allowed per CU and a table in which that pays (each CU then overlaps the hand-off stalls of
+    two independent row tiles), B = 1 runs at 8 units per workgroup (432 workgroups), B = 16 at one row tile per group on
+    129 groups; with the built-in table (two per CU priced prohibitively) nothing changes; capacity is never exceeded."""
+    import ctypes as ct
+    lib = _lib.load()
+
+    def plan(rows, occ, costs=None, gru=0):
+        buf = (ct.c_int32 * (8 * 64))()
+        arr = (ct.c_double * 14)(*costs) if costs else None
+        n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
+        assert n > 0, lib.fsnp_last_error()
+        keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
+        return [dict(zip(keys, buf[8 * i:8 * i + 8])) for i in range(n)]
+
+    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11]
+    p = plan(257, 2, cheap2)
+    assert len(p) == 1 and p[0]["kind"] == 1 and p[0]["par"] == 8 and 9 * 48 <= 512
+    p = plan(4112, 2, cheap2)                    # 129 tiles
+    assert len(p) == 1 and p[0]["kind"] == 2 and p[0]["rpg"] == 1 and p[0]["par"] == 129
+    assert [(c["kind"], c["rows"]) for c in plan(257, 2)] == [(c["kind"], c["rows"]) for c in plan(257, 1)]
+    assert [(c["kind"], c["rows"]) for c in plan(4112, 2)] == [(c["kind"], c["rows"]) for c in plan(4112, 1)]
+    for rows in (257, 514, 1285, 2056, 4096, 4112, 5440, 8224, 10280, 65792):
+        for gru in (0, 1):
+            for c in plan(rows, 2, cheap2, gru):
+                wgs = c["tiles"] * (384 // c["par"]) if c["kind"] == 1 else c["par"] * 3 if c["kind"] == 2 else 0
+                assert wgs <= 512 and (c["kind"] != 2 or c["par"] * c["rpg"] >= c["tiles"])
+    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11]      # K split suddenly slow: 9 tiles move
+    p = plan(257, 1, slow_k)
+    assert p[0]["kind"] == 2
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():
