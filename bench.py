@@ -135,6 +135,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.same_device:
         local_rank = 0
+        # several ranks on ONE GPU (plumbing tests only): the column-split kernels need all their workgroups resident, so
+        # two processes must not each plan launches that fill every CU twice, nor calibrate against each other
+        os.environ.setdefault("FSNP_COOP_OCC", "1")
+        os.environ.setdefault("FSNP_CALIBRATE", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -100,7 +100,8 @@ struct fsnp_handle {
     int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
     bool rowtile_ok = true;      // a one-tile-per-CU kernel (lstm.hip / lstm_gru.hip) exists for this handle's sub-band model
     CostTable cost{};            // per-step costs the planner minimises (defaults, then measured on the device)
-    int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (2 only if they fit)
+    int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (FSNP_COOP_OCC; 1 or 2) ...
+    int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};   // ... and what each instantiation really fits (measured at commit)
     int calibrate = 1;           // FSNP_CALIBRATE=0: keep the default table
     int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
     TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
@@ -419,6 +420,7 @@ static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
     return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
+    if (h->gru) return SbChunk{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};   // lstm_gru.hip has no VALU rows
     const LstmPlan lp = plan_lstm_tiles(nrows, h->num_cus);
     return SbChunk{0, row0, nrows, lp.num_tiles, lp.ex, lp.rows_per_slot_tile, 0, 0, 0, 0, 0};
 }
@@ -434,11 +436,13 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
     const int T = cdiv(nrows, 32);
     struct Shape { int kind, units, rpg, cap, dbl; };
     std::vector<Shape> shapes;
-    for (int occ = 1; occ <= (h->coop_occ >= 2 ? 2 : 1); ++occ) {
+    for (int occ = 1; occ <= (h->coop_occ >= 2 ? 2 : 1); ++occ) {          // two per CU: only shapes whose kernel fits twice
         const int slots = h->num_cus_real * occ;
         for (int u = 8; u <= 64; u *= 2)
-            if (h->H % u == 0 && slots / (h->H / u) > 0) shapes.push_back({1, u, 0, slots / (h->H / u), occ - 1});
-        for (int rpg = 1; rpg <= 2; ++rpg) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
+            if (h->H % u == 0 && slots / (h->H / u) > 0 && h->occ_ksplit[units_index(u)] >= occ)
+                shapes.push_back({1, u, 0, slots / (h->H / u), occ - 1});
+        for (int rpg = 1; rpg <= 2; ++rpg)
+            if (h->occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
         SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
@@ -529,7 +533,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.rows = a.rows + c.slot0;
         ca.num_rows = c.nrows; ca.num_tiles = c.num_tiles; ca.ex = c.ex;
         if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
-        if (c.kind == 0) { launch_lstm(h->lw, ca, s); continue; }
+        if (c.kind == 0) { if (h->gru) launch_gru(h->lw, ca, s); else launch_lstm(h->lw, ca, s); continue; }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_err = h->d_err;
@@ -701,7 +705,10 @@ static std::map<CalKey, CostTable> g_cal_cache;
 
 static int calibrate_costs(fsnp_handle* h) {
     if (h->cost.calibrated || !h->calibrate || h->sb_tcn || !h->committed) return 0;
-    const CalKey key{h->device, h->H, h->KX, h->gru, h->coop_occ, h->num_cus_real};
+    int occ_sig = h->coop_occ;
+    for (int i = 0; i < 4; ++i) occ_sig = occ_sig * 4 + h->occ_ksplit[i];
+    for (int i = 0; i < 2; ++i) occ_sig = occ_sig * 4 + h->occ_coopn[i];
+    const CalKey key{h->device, h->H, h->KX, h->gru, occ_sig, h->num_cus_real};
     {
         std::lock_guard<std::mutex> lk(g_cal_mu);
         auto it = g_cal_cache.find(key);
@@ -754,14 +761,14 @@ static int calibrate_costs(fsnp_handle* h) {
         for (int ui = 0; ui < 4 && rc == 0; ++ui) {
             const int u = 8 << ui, S = h->H / u;
             int tiles = slots / S;
-            if (o == 1 && tiles * S <= h->num_cus_real) continue;       // no launch of this shape needs the second slot
+            if (o == 1 && (tiles * S <= h->num_cus_real || h->occ_ksplit[ui] < 2)) continue;   // never planned two per CU
             if (tiles <= 0) continue;
             const double us = time_shape(SbChunk{1, 0, 0, tiles, 0, 32, u, 0, 0, 0, 0});
             if (us < 0) rc = 4; else t.ksplit[ui][o] = us;
         }
         for (int rpg = 1; rpg <= 2 && rc == 0; ++rpg) {
             const int groups = slots / S3;
-            if (groups <= 0) continue;
+            if (groups <= 0 || (o == 1 && h->occ_coopn[rpg - 1] < 2)) continue;
             const double us = time_shape(SbChunk{2, 0, 0, groups * rpg, 0, 32, 0, groups, rpg, 0, 0});
             if (us < 0) rc = 4; else t.coopn[rpg - 1][o] = us;
         }
@@ -854,8 +861,9 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     }
     h->model = cfg->model;
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
-    h->rowtile_ok = !h->gru;
+    h->rowtile_ok = true;               // LSTM: lstm.hip, GRU: lstm_gru.hip
     h->cost = default_costs();
+    if (h->gru) h->cost.rowtile *= 0.75;   // three of the four gate tiles per k-group
     const char* ce = getenv("FSNP_CALIBRATE");
     if (ce && ce[0] == '0') h->calibrate = 0;
     const char* oe = getenv("FSNP_COOP_OCC");          // 1 = never plan two column-split workgroups per CU
@@ -1089,6 +1097,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
                                      blob.data() + o_wpack_bf[i]);
         }
     }
+    size_t o_wpack_gru = 0;
+    if (h->gru && !h->sb_tcn) {
+        o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
+        gru_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_gru);
+    }
     size_t o_wpack_coop[4] = {0, 0, 0, 0};
     for (int ui = 0; ui < 4 && !h->sb_tcn; ++ui) {
         const int units = 8 << ui;
@@ -1151,6 +1164,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     bind_tcn(h->tw, fb_off, d);
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
+    h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
     if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
@@ -1163,11 +1177,9 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
     h->d_refl_w = d + o_refl;
     h->d_refl_wfb = d + o_reflfb;
-    if (h->coop_occ >= 2 && !h->sb_tcn) {       // two workgroups per CU only if EVERY column-split instantiation fits twice
-        int occ = 2;
-        for (int u = 8; u <= 64; u *= 2) occ = std::min(occ, lstm_coop_occupancy(h->lw, u));
-        for (int rpg = 1; rpg <= 2; ++rpg) occ = std::min(occ, lstm_coopn_occupancy(h->lw, rpg));
-        if (occ < 2) h->coop_occ = 1;
+    if (!h->sb_tcn) {                           // which column-split instantiations fit twice on a CU (registers, LDS)
+        for (int ui = 0; ui < 4; ++ui) h->occ_ksplit[ui] = std::max(1, lstm_coop_occupancy(h->lw, 8 << ui));
+        for (int rpg = 1; rpg <= 2; ++rpg) h->occ_coopn[rpg - 1] = std::max(1, lstm_coopn_occupancy(h->lw, rpg));
     }
     h->committed = true;
     (void)Fr;
@@ -1587,13 +1599,16 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     fsnp_handle h;                      // host-only: the planner never touches the device
     h.H = hidden; h.num_cus = num_cus; h.num_cus_real = num_cus; h.gru = gru; h.lstm_coop = coop; h.composite_gain = composite_gain;
     h.cost = default_costs(); h.coop_occ = workgroups_per_cu >= 2 ? 2 : 1;
+    for (int i = 0; i < 4; ++i) h.occ_ksplit[i] = h.coop_occ;
+    for (int i = 0; i < 2; ++i) h.occ_coopn[i] = h.coop_occ;
     if (costs) {
         for (int i = 0; i < 4; ++i) { h.cost.ksplit[i][0] = costs[2 * i]; h.cost.ksplit[i][1] = costs[2 * i + 1]; }
         for (int i = 0; i < 2; ++i) { h.cost.coopn[i][0] = costs[8 + 2 * i]; h.cost.coopn[i][1] = costs[9 + 2 * i]; }
         h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
     }
-    h.rowtile_ok = gru == 0 || gru == 2;      // gru = 2: plan as a GRU handle WITH its one-tile-per-CU kernel (lstm_gru.hip)
+    h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
+    if (gru == 2) h.cost.rowtile *= 0.75;
     const SbPlan plan = plan_sb(&h, num_rows);
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
@@ -1619,13 +1634,6 @@ int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, in
 int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups_per_cu) {
     if (!h || (workgroups_per_cu != 1 && workgroups_per_cu != 2)) { set_error("fsnp_debug_set_costs: bad argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_set_costs: commit the weights first (the kernels' occupancy is checked then)"); return 2; }
-    if (workgroups_per_cu == 2 && !h->sb_tcn) {
-        FSNP_ON_DEVICE(h);
-        int occ = 2;
-        for (int u = 8; u <= 64; u *= 2) occ = std::min(occ, lstm_coop_occupancy(h->lw, u));
-        for (int rpg = 1; rpg <= 2; ++rpg) occ = std::min(occ, lstm_coopn_occupancy(h->lw, rpg));
-        if (occ < 2) { set_error("fsnp_debug_set_costs: the column-split kernels do not fit twice on a CU (occupancy %d)", occ); return 2; }
-    }
     h->cost = default_costs();
     if (costs) {
         for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] = costs[2 * i]; h->cost.ksplit[i][1] = costs[2 * i + 1]; }

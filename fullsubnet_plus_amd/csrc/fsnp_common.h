@@ -149,6 +149,7 @@ struct LstmWeights {
     int ih_bf16;                // 1 = use them
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
+    const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
@@ -192,6 +193,11 @@ struct LstmArgs {
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+// lstm_gru.hip: the same decomposition for nn.GRU (three live gate tiles per k-group, no VALU rows)
+void launch_gru(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t gru_pack_floats(int H, int KX, int NW);
+void gru_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
+                      const float* whh1, float* wpack);   // inputs: the four-slot [4H][cols] matrices (r, z, n_x | n_h)
 // lstm_coop.hip: column-split kernel for small batches (row_tiles * H/32 workgroups, all co-resident)
 void launch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s);       // H = 384, KX = 40, Linear(H, 2) fused
 void launch_lstm_coop_seq(const LstmWeights& w, const LstmArgs& a, hipStream_t s);   // H = 512, KX = 264, h1 sequence out

@@ -263,8 +263,6 @@ class _HipModel(nn.Module):
         if lib.fsnp_poll_errors(self._handle) == 0:
             return out
         msg = _lib.last_error()
-        if self.sequence_model == "GRU" and not getattr(self, "_gru_rowtile", False):
-            raise RuntimeError(msg)                      # no kernel without the co-residency requirement to fall back to
         import warnings
         warnings.warn(f"fullsubnet_plus_amd: {msg}; re-running this batch on the one-tile-per-CU kernel", RuntimeWarning)
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, 0), "fsnp_debug_set_lstm_coop")
@@ -453,7 +451,8 @@ class _HipModel(nn.Module):
         n = _lib.load().fsnp_describe_plan(self._handle, int(batch), int(parity), buf, 16)
         if n < 0:
             raise RuntimeError(_lib.last_error())
-        names = {0: "lstm2_fc_kernel (one 32-row tile per CU)", 1: "lstm2_coop_kernel (K split)",
+        names = {0: ("gru2_fc_kernel" if self.sequence_model == "GRU" else "lstm2_fc_kernel") + " (one 32-row tile per CU)",
+                 1: "lstm2_coop_kernel (K split)",
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN"}
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]

@@ -202,8 +202,8 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
  * kernel, out[13] = its relative surcharge per VALU row.  The built-in defaults (round-1 measurements) are replaced by
  * values MEASURED on the device the first time a call on a handle of this kind plans (once per process: ~0.1 s, the only
  * synchronising moment of fsnp_forward; FSNP_CALIBRATE=0 keeps the defaults): *calibrated = 1 from then on.  *occ =
- * workgroups per CU the column-split kernels may be planned with (2 only if every instantiation fits twice, FSNP_COOP_OCC=1
- * forces 1). */
+ * workgroups per CU the column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU
+ * twice; FSNP_COOP_OCC=1 forces 1). */
 int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, int32_t* occ);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
@@ -212,8 +212,9 @@ int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int3
                          int32_t* out, int32_t max_chunks);
 
 /* Test hook: pin the handle's cost table (fsnp_get_costs' layout; NULL = the built-in round-1 table) and the number of
- * column-split workgroups the planner may put on a CU (2 is refused if the kernels do not fit twice); the lazy calibration
- * then leaves it alone.  Needs committed weights. */
+ * column-split workgroups the planner may put on a CU (2 only ever applies to the launch shapes whose kernel fits a CU
+ * twice - registers, LDS - as measured with hipOccupancyMaxActiveBlocksPerMultiprocessor at commit time); the lazy
+ * calibration then leaves it alone.  Needs committed weights. */
 int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups_per_cu);
 /* The same with `workgroups_per_cu` (1 or 2) column-split workgroups allowed per CU and, if costs != NULL, a cost table in
  * fsnp_get_costs' layout instead of the built-in one. */

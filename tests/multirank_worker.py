@@ -14,6 +14,9 @@ sys.path.insert(0, ROOT)
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
+    # two processes share GPU 0 here: keep every column-split launch at one workgroup per CU (see bench.py --same-device)
+    os.environ.setdefault("FSNP_COOP_OCC", "1")
+    os.environ.setdefault("FSNP_CALIBRATE", "0")
     torch.cuda.set_device(0)
     from fullsubnet_plus_amd import FullSubNet_Plus
     from fullsubnet_plus_amd.dist import forward_sharded

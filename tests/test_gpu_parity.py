@@ -124,8 +124,7 @@ def test_column_split_two_workgroups_per_cu(n, steps):
     """The planner may put TWO column-split workgroups on a CU (their hand-off stalls overlap: two independent row tiles share
     the CU's matrix pipes) when the kernels fit twice - 257 sequences then run at 8 units per workgroup (432 workgroups),
     129 tiles as one launch of 129 groups, 340 tiles as 170 groups of two.  Pinned here with a cost table that makes it pay;
-    the result must equal the oracle, the one-per-CU plan of round 1 (same kernels, same summation order per row: bitwise)
-    and itself on repetition."""
+    the result must equal the oracle (as the one-per-CU plan of round 1 does) and itself, bitwise, on repetition."""
     sd = make_state_dict(9, "harsh")
     m = _model(DEFAULT_MODEL_ARGS, sd)
     rng = np.random.Generator(np.random.PCG64(99 + n))
@@ -476,8 +475,9 @@ def test_forward_complex_equals_three_plane_forward():
 # ---------------------------------------------------------------- sub-band GRU (sequence_model.py:39-46)
 @pytest.mark.parametrize("n,steps", [(50, 9), (257, 40), (1300, 7), (2750, 6), (6000, 5), (9000, 4)])
 def test_gru2_fc_dense_vs_oracle(n, steps):
-    """nn.GRU cells on the column-split kernels: K-split (<= 42 tiles), three-way split (1-2 tiles per group) and,
-    beyond 170 tiles, consecutive chunks (6000 rows = 170 + 18 tiles, 9000 rows = 170 + 112)."""
+    """nn.GRU cells: on the column-split kernels (K split, three-way split) as the planner cuts them, beyond a chip-filling
+    round on the one-tile-per-CU GRU kernel + a column-split remainder (9000 rows = 256 + 26 tiles), and on the
+    one-tile-per-CU kernel alone."""
     args = {**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"}
     sd = make_state_dict(31, "harsh", sequence_model="GRU")
     m = _model(args, sd)
@@ -492,6 +492,13 @@ def test_gru2_fc_dense_vs_oracle(n, steps):
     assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
     with pytest.raises(RuntimeError, match="LSTM sub-band model only"):
         m.set_precision("bf16_ih")
+    # the one-tile-per-CU GRU kernel (csrc/lstm_gru.hip: three live gate tiles per k-group) on every row, ragged last tile
+    m.debug_set_lstm_coop(0)
+    assert all(c["kernel"].startswith("gru2_fc_kernel") for c in m.describe_plan(1))
+    tile = m.lstm2_fc(x.cuda()).cpu().numpy()
+    m.debug_set_lstm_coop(1)
+    _record(f"gru2_fc_rowtile_{n}x{steps}", rel=rel_err(tile, want))
+    assert rel_err(tile, want) < 2e-5
 
 
 def test_gru_forward_b32_full_vs_oracle():
