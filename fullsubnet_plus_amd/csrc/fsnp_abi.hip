@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "fsnp_common.h"
+#include "lstm_common.h"
 
 namespace fsnp {
 
@@ -539,6 +540,12 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_err = h->d_err;
         ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
+        // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
+        static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
+        {
+            const int S = c.kind == 1 ? h->H / c.units : h->H / 128, T = c.kind == 1 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
+            ca.coop_xcd = xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
+        }
         launch_coop_chained(h->device, s, [&] {
             if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
@@ -1711,7 +1718,14 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable) {
     FSNP_ON_DEVICE(h);
     FSNP_HIP_CHECK(hipDeviceSynchronize());              // nothing of either mode is in flight while the workspace is re-shaped
     if (enable && !h->side_stream) {
-        FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        // the deferred remainder chunk is a latency-bound chain of inter-workgroup hand-offs: at the highest stream priority
+        // its waves win the arbitration against the full-band GEMMs it shares CUs with (FSNP_SIDE_PRIO=0: default priority)
+        int lo = 0, hi = 0;
+        const char* pe = getenv("FSNP_SIDE_PRIO");
+        if (!(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            FSNP_HIP_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi));
+        else
+            FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
         for (auto& e : h->ev_side) FSNP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }

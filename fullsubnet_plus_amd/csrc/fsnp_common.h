@@ -186,6 +186,7 @@ struct LstmArgs {
     unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
+    int coop_xcd;              // > 0 = CUs per XCD: place the workgroups that share a row tile on one XCD (lstm_common.h)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
     int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2
 };

@@ -22,6 +22,31 @@ __host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
 }
 
 
+// ---- XCD-local placement of the column-split kernels' workgroups.  The S workgroups that share a row tile (a group)
+// exchange h through global memory every step; the dispatcher places workgroup id i on XCD i % 8, so with consecutive ids
+// they sit on S different XCDs.  Decoding ids XCD-major keeps a tile's S workgroups on ONE XCD: measured 20.7 -> 17.8 us per
+// step at 16 units per workgroup, 30.2 -> 26.4 at 32, 56.5 -> 53.1 at 64 (profiles/r02_column_split.md).  Lx = tiles whose S
+// workgroups fit one XCD's CUs; tiles beyond 8 Lx are "spread" over the XCDs as before, so capacities do not change
+// (9 tiles at S = 24: 8 local + 1 spread, 27 workgroups per XCD).  Placement is a speed matter only: nothing depends on it.
+__host__ __device__ __forceinline__ int xcd_local_tiles(int S, int T, int cus_per_xcd) {
+    const int fit = cus_per_xcd / S, need = (T + 7) / 8;
+    return fit < need ? fit : need;
+}
+__host__ __device__ __forceinline__ int xcd_local_blocks_per_xcd(int S, int T, int cus_per_xcd) {
+    const int Lx = xcd_local_tiles(S, T, cus_per_xcd);
+    const int t_local = T < 8 * Lx ? T : 8 * Lx;
+    return Lx * S + ((T - t_local) * S + 7) / 8;
+}
+__device__ __forceinline__ bool xcd_local_decode(int id, int S, int T, int cus_per_xcd, int& tile, int& cs) {
+    const int Lx = xcd_local_tiles(S, T, cus_per_xcd);
+    const int t_local = T < 8 * Lx ? T : 8 * Lx;
+    const int xcd = id & 7, j = id >> 3;
+    if (j < Lx * S) { tile = (j / S) * 8 + xcd; cs = j % S; return tile < t_local; }
+    const int q = (j - Lx * S) * 8 + xcd;
+    tile = t_local + q / S; cs = q % S;
+    return tile < T;
+}
+
 // ---- inter-workgroup exchange of the column-split kernels (lstm_coop.hip, lstm_coopn.hip): WRITE-THROUGH protocol.
 // Producers store h / Linear partials with sc1 (write-through) stores - a relaxed agent-scope atomic store of 4 bytes is
 // exactly `global_store_dword ... sc1` - every storing wave drains vmcnt, __syncthreads, ONE lane arrives on the counter;

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rt = blockIdx.x / S, cs = blockIdx.x % S;
+    // workgroup id -> (row tile, column slice).  Flat: consecutive ids = the S slices of one tile (spread over the 8 XCDs by
+    // the dispatcher's id % 8 placement).  XCD-local (a.coop_xcd = CUs per XCD): see lstm_common.h xcd_local_decode.
+    int rt = blockIdx.x / S, cs = blockIdx.x % S;
+    if (a.coop_xcd && !xcd_local_decode(blockIdx.x, S, a.num_tiles, a.coop_xcd, rt, cs)) return;
     const int slot0 = rt * 32;
     const int Tp = a.Tp;
 
@@ -478,7 +481,8 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     }
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
-    hipLaunchKernelGGL(kern, dim3(a.num_tiles * S), dim3(256), smem, s, wv, a);
+    const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(S, a.num_tiles, a.coop_xcd) : a.num_tiles * S;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, wv, a);
 }
 
 // Finest column split (fewest units per workgroup, >= min_units) whose row_tiles * H / units workgroups are all

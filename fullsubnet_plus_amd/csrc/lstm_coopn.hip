@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = a.coop_groups;
-    const int g = blockIdx.x / S, cs = blockIdx.x % S;
+    int g = blockIdx.x / S, cs = blockIdx.x % S;       // group, 128-unit column slice; XCD-local: lstm_common.h
+    if (a.coop_xcd && !xcd_local_decode(blockIdx.x, S, G, a.coop_xcd, g, cs)) return;
     const int Tp = a.Tp;
     const int ub = cs * 4 + wave;                  // 32-unit block of this wave
     const int unit = ub * 32 + (lane & 31);        // hidden unit of this lane
@@ -379,7 +380,8 @@ static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, reinterpret_cast<const void*>(lstm2_coopn_kernel<HID, KX, R, GRU>), 256, 0) != hipSuccess) *occ = 0;
         return;
     }
-    hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(a.coop_groups * (HID / 128)), dim3(256), 0, s, wv, a);
+    const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(HID / 128, a.coop_groups, a.coop_xcd) : a.coop_groups * (HID / 128);
+    hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(grid), dim3(256), 0, s, wv, a);
 }
 
 template <int KX>

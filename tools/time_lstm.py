@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time the fused recurrent kernel alone on dense inputs: python tools/time_lstm.py n steps [reps] -> ms per call, us per step."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fullsubnet_plus_amd import FullSubNet_Plus  # noqa: E402
+from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_state_dict  # noqa: E402
+
+n, steps = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+seq = os.environ.get("SEQ", "LSTM")
+m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": seq})
+m.load_state_dict(make_state_dict(0, "default", sequence_model=seq), strict=True)
+m = m.to("cuda").eval()
+x = torch.randn(n, 34, steps, device="cuda")
+out = m.lstm2_fc(x)
+if os.environ.get("PIN_R01"):
+    m.debug_set_costs(None, 1)
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = m.lstm2_fc(x)
+    torch.cuda.synchronize()
+    best = min(best, time.perf_counter() - t0)
+m.check_errors()
+print(f"n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
