@@ -55,7 +55,8 @@ struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
 
 // per-step cost table of the sub-band planner (see default_costs / calibrate_costs)
 struct CostTable {
-    double ksplit[4][2];       // K-split kernel at 8 / 16 / 32 / 64 units per workgroup x {<= 1, 2} workgroups per CU
+    double ksplit[4][2];       // K-split kernel at 8 / 16 / 32 / 64 units per workgroup x {<= 1, 2} workgroups per CU, launch FULL
+    double ksplit1[4];         // the same with ONE row tile (the exchange traffic, hence a step, grows with the tiles in flight)
     double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
     int calibrated;
@@ -125,6 +126,7 @@ struct fsnp_handle {
     int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
     int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
+    int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
                                  // so the NEXT call on the handle can fail loudly without a device synchronisation
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
@@ -402,10 +404,11 @@ struct SbPlan {
 // occupancy allows it (coop_occ >= 2) and, without a calibration, priced so that it is never chosen.
 static CostTable default_costs() {
     CostTable t{};
-    const double ks[4] = {9.0, 19.0, 29.0, 55.0}, cn[2] = {76.0, 151.0};
-    for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 2.2 * ks[i]; }
+    // round-2 measurements (profiles/r02_planner_costs.json): a full launch, one row tile, three-way split, one-tile-per-CU
+    const double ks[4] = {14.4, 20.4, 32.8, 58.6}, k1[4] = {8.7, 15.0, 25.0, 45.0}, cn[2] = {85.4, 162.3};
+    for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 208.0; t.rowtile_ex = 0.11;
+    t.rowtile = 210.0; t.rowtile_ex = 0.11;
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
@@ -416,7 +419,12 @@ static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) {
 }
 static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
     const int dbl = chunk_workgroups(h, c) > h->num_cus_real ? 1 : 0;
-    if (c.kind == 1) return h->cost.ksplit[units_index(c.units)][dbl];
+    if (c.kind == 1) {
+        const int ui = units_index(c.units), cap = h->num_cus_real / (h->H / c.units);
+        if (dbl || cap <= 1) return h->cost.ksplit[ui][dbl];
+        const double f = (double)(c.num_tiles - 1) / (cap - 1);              // 1 tile .. a full launch
+        return h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
+    }
     if (c.kind == 2) return h->cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
     return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
@@ -537,6 +545,8 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         if (c.kind == 0) { if (h->gru) launch_gru(h->lw, ca, s); else launch_lstm(h->lw, ca, s); continue; }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
+        ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
+        ca.coop_skew = h->coop_skew;
         ca.coop_err = h->d_err;
         ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
@@ -604,7 +614,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
-    w.coop_bar = take((size_t)plan.coop_tiles * 4);
+    w.coop_bar = take((size_t)plan.coop_tiles * 2 * 4);      // two arrival counters per row tile
     w.coop_abort = take(256);             // [0] sub-band launches, [16] full-band LSTM (FullSubNet)
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
@@ -677,7 +687,7 @@ static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, fl
     const bool coop = plan.coop_tiles != 0;
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
     const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
-    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 4, 256);
+    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 2 * 4, 256);
     const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
     if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
     if (h->pipeline && h->side_stream) FSNP_HIP_CHECK(hipStreamSynchronize(h->side_stream));   // slot 0 may still be read
@@ -715,6 +725,7 @@ static int calibrate_costs(fsnp_handle* h) {
     int occ_sig = h->coop_occ;
     for (int i = 0; i < 4; ++i) occ_sig = occ_sig * 4 + h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) occ_sig = occ_sig * 4 + h->occ_coopn[i];
+    occ_sig = occ_sig * 2 + h->coop_skew;
     const CalKey key{h->device, h->H, h->KX, h->gru, occ_sig, h->num_cus_real};
     {
         std::lock_guard<std::mutex> lk(g_cal_mu);
@@ -772,6 +783,10 @@ static int calibrate_costs(fsnp_handle* h) {
             if (tiles <= 0) continue;
             const double us = time_shape(SbChunk{1, 0, 0, tiles, 0, 32, u, 0, 0, 0, 0});
             if (us < 0) rc = 4; else t.ksplit[ui][o] = us;
+            if (o == 0 && rc == 0) {
+                const double u1 = tiles > 1 ? time_shape(SbChunk{1, 0, 0, 1, 0, 32, u, 0, 0, 0, 0}) : us;
+                if (u1 < 0) rc = 4; else t.ksplit1[ui] = u1 < us ? u1 : us;
+            }
         }
         for (int rpg = 1; rpg <= 2 && rc == 0; ++rpg) {
             const int groups = slots / S3;
@@ -891,6 +906,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
+    const char* sk = getenv("FSNP_COOP_SKEW");
+    if (sk && sk[0] == '0') h->coop_skew = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&h->d_err), 256, hipHostMallocMapped) != hipSuccess) {
         set_error("hipHostMalloc of the error word failed");
         delete h;
@@ -1612,6 +1629,7 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
         for (int i = 0; i < 4; ++i) { h.cost.ksplit[i][0] = costs[2 * i]; h.cost.ksplit[i][1] = costs[2 * i + 1]; }
         for (int i = 0; i < 2; ++i) { h.cost.coopn[i][0] = costs[8 + 2 * i]; h.cost.coopn[i][1] = costs[9 + 2 * i]; }
         h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
+        for (int i = 0; i < 4; ++i) h.cost.ksplit1[i] = costs[14 + i];
     }
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
@@ -1628,11 +1646,12 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     return n;
 }
 
-int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, int32_t* occ) {
+int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, int32_t* occ) {
     if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
     for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
     out[12] = h->cost.rowtile; out[13] = h->cost.rowtile_ex;
+    for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
     return 0;
@@ -1646,6 +1665,7 @@ int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups
         for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] = costs[2 * i]; h->cost.ksplit[i][1] = costs[2 * i + 1]; }
         for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] = costs[8 + 2 * i]; h->cost.coopn[i][1] = costs[9 + 2 * i]; }
         h->cost.rowtile = costs[12]; h->cost.rowtile_ex = costs[13];
+        for (int i = 0; i < 4; ++i) h->cost.ksplit1[i] = costs[14 + i];
     }
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
@@ -1776,8 +1796,11 @@ int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off) or 1 (auto)"); return 1; }
-    h->lstm_coop = mode;
+    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto) or 2 (auto, serial K-split schedule)"); return 1; }
+    h->lstm_coop = mode != 0;
+    h->coop_skew = mode == 1;
+    h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
+    if (!h->cost.calibrated) { const int occ = h->coop_occ; h->cost = default_costs(); if (h->gru) h->cost.rowtile *= 0.75; h->coop_occ = occ; }
     return 0;
 }
 

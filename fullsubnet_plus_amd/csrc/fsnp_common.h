@@ -183,6 +183,8 @@ struct LstmArgs {
     // column-split (cooperative) kernel only
     float* coop_hx;            // per row tile: h0/h1 exchange images (double buffered) + Linear partials, zeroed per launch
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
+    unsigned* coop_bar2;       // second counter per row tile (layer-skewed K-split kernel: finished layer-1 phases)
+    int coop_skew;             // lstm_coop.hip: 1 = layer-skewed schedule (lstm2_coop_skew_kernel)
     unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64

@@ -22,6 +22,11 @@ __host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
 }
 
 
+// ---- per-row-tile exchange region of the column-split kernels, in float4 units (HIMG = (HID / 8) * 64 = one 32 x HID image
+// in A-fragment order):  [h0 parity 0][h0 parity 1][h1 parity 0][h1 parity 1][Linear partials 2 x (HID / 8) x 16][h0 third]
+// The third h0 image is used by the layer-skewed K-split kernel only (lstm_coop.hip: lstm2_coop_skew_kernel).
+__host__ __device__ constexpr int coop_tile_f4(int HID) { return 5 * (HID / 8) * 64 + 2 * (HID / 8) * 16; }
+
 // ---- XCD-local placement of the column-split kernels' workgroups.  The S workgroups that share a row tile (a group)
 // exchange h through global memory every step; the dispatcher places workgroup id i on XCD i % 8, so with consecutive ids
 // they sit on S different XCDs.  Decoding ids XCD-major keeps a tile's S workgroups on ONE XCD: measured 20.7 -> 17.8 us per

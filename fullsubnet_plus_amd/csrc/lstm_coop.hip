@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     const int Tp = a.Tp;
 
     // exchange region of this row tile: [h0 p0][h0 p1][h1 p0][h1 p1] images + FC partials [2][H/8][64]
-    float4* hx = reinterpret_cast<float4*>(a.coop_hx) + (size_t)rt * (4 * HIMG + 2 * (HID / 8) * 16);
+    float4* hx = reinterpret_cast<float4*>(a.coop_hx) + (size_t)rt * coop_tile_f4(HID);
     float4* h0img[2] = {hx, hx + HIMG};
     float4* h1img[2] = {hx + 2 * HIMG, hx + 3 * HIMG};
     float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
@@ -417,6 +417,295 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer-skewed schedule of the same kernel (sub-band model only).  In lstm2_coop_kernel a step is a serial chain
+//     L0 MFMAs -> cell 0 -> publish h0_t -> [inter-workgroup barrier] -> L1 MFMAs -> cell 1 -> publish h1_t
+// and the barrier's round trips (drain, arrive, poll) sit in the middle of it with nothing to overlap.  Layer 0 of step t+1
+// and layer 1 of step t only need what was published up to h0_t / h1_{t-1}, so here every workgroup runs
+//     A_0,  [A_1, C_0],  [A_2, C_1],  ...,  [A_{T-1}, C_{T-2}],  C_{T-1}          A_t = layer 0 of step t, C_t = layer 1
+// with TWO arrival counters per row tile: b0 counts finished A phases, b1 finished C phases.  A_t waits for b0 >= S t (all of
+// h0_{t-1}), C_t for b0 >= S (t+1) (h0_t: the very wait A_{t+1} just passed) and b1 >= S t (h1_{t-1}).  Every wait is for an
+// arrival that happened one whole phase earlier - the peers arrived on b0 before their C phase, on b1 before their next A
+// phase - so in lockstep the poll finds the counter complete on its first read.  Buffers: h0_t is read by A_{t+1} AND C_t,
+// and A_{t+2} (which overwrites the image of parity t in a double buffer) may start in a fast workgroup while a slow one is
+// still in C_t, so h0 cycles through THREE images (A_{t+3} starts only after every workgroup finished A_{t+2}, which follows
+// C_t); h1_t is read by C_{t+1} only: two images; the Linear partials of step t are summed by slice 0 after it passed the
+// b1 wait of C_{t+1}: two buffers.  Same arithmetic and summation order as lstm2_coop_kernel: results are bit-identical.
+template <int HID, int KX, int UNITS, bool GRU>
+__global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, LstmArgs a) {
+    constexpr int NT = UNITS / 8, NP = UNITS / 8;
+    constexpr int KGX = KX / 8, KGH = HID / 8;
+    constexpr int KGXP = (KGX + 3) / 4 * 4;
+    constexpr int G0W = (KGXP + KGH) / 4, G1W = KGH / 2;
+    constexpr int S = HID / UNITS;
+    constexpr int HIMG = KGH * 64;
+    constexpr int FCP4 = 2 * (HID / 8) * 16;
+    constexpr bool BIAS_REGS = UNITS <= 32;
+    constexpr bool WREG = NT * (G0W + G1W) * 4 <= 232;
+    static_assert(KX <= 64, "gathered sub-band input");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* Xs = reinterpret_cast<float4*>(smem_raw);                     // [KGXP][64] A image of x_t
+    float* red = reinterpret_cast<float*>(Xs + KGXP * 64);                // [4 waves][NT][16][64]
+    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 16 * 64); // [32]
+    __shared__ int abort_s;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rt = blockIdx.x / S, cs = blockIdx.x % S;
+    if (a.coop_xcd && !xcd_local_decode(blockIdx.x, S, a.num_tiles, a.coop_xcd, rt, cs)) return;
+    const int slot0 = rt * 32;
+    const int Tp = a.Tp;
+
+    float4* hx = reinterpret_cast<float4*>(a.coop_hx) + (size_t)rt * coop_tile_f4(HID);
+    // float4 offsets of the images inside the tile's region (lstm_common.h: coop_tile_f4)
+    auto h0off = [](int m3) -> int { return m3 < 2 ? m3 * HIMG : 4 * HIMG + FCP4; };
+    auto h1off = [](int par) -> int { return (2 + par) * HIMG; };
+    float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
+    unsigned* bar0 = a.coop_bar + rt;
+    unsigned* bar1 = a.coop_bar2 + rt;
+
+    if (tid == 0) abort_s = 0;
+    for (int i = tid; i < KGXP * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 32) rows_s[tid] = a.rows[slot0 + tid];
+    __syncthreads();
+
+    // ---- input plan: thread owns row = tid & 31, features j = (tid >> 5) + 8 i
+    const bool dense = a.dense != nullptr;
+    const float* __restrict__ gbase = dense ? a.dense : a.att_mag;
+    const int gstep = dense ? a.dense_stride : a.FP;
+    constexpr int NG = KGX;
+    const int grow = tid & 31, jrow = tid >> 5;
+    int goff[NG];
+    NormMD md = {0.0f, 1.0f};
+    const NormMD* md_t = nullptr;
+    {
+        const RowDesc rd = rows_s[grow];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int j = jrow + 8 * i;
+            int off = -1;
+            if (rd.valid && j < w.NIN) {
+                if (dense) off = rd.b * Tp * gstep + j;
+                else off = sb_feature_offset(j, rd.f, rd.b * Tp * a.FP, a.F, a.NSBN, a.NFBN, a.fb_rel, a.fb_branch_stride);
+            }
+            goff[i] = off;
+        }
+        if (rd.valid) {
+            if (a.md_seq != nullptr) md_t = a.md_seq + (size_t)rd.b * Tp;
+            else if (!dense && a.md_row != nullptr) md_t = a.md_row + (size_t)(slot0 + grow) * Tp;
+            else if (!dense) md = a.md_utt[rd.b];
+        }
+    }
+    auto x_load = [&](int i, int t) -> float { return goff[i] >= 0 ? gbase[goff[i] + t * gstep] : 0.0f; };
+    const int xdst0 = a_frag_index(grow, jrow);
+    float* Xf = reinterpret_cast<float*>(Xs);
+    {
+        const NormMD m0 = md_t ? md_t[0] : md;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (x_load(i, 0) - m0.m) / m0.d : 0.0f;
+    }
+
+    CoopStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(w.wpack) + (size_t)(cs * 4 + wave) * (G0W + G1W) * NT * 256, 0, (G0W + G1W) * NT * 1024, 0x00020000);
+    ws.voff = lane * 16;
+    float4 bw0[WREG ? G0W : 1][NT], bw1[WREG ? G1W : 1][NT];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int i = 0; i < G0W; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw0[i][n] = coop_wload<NT>(ws, i, n);
+#pragma unroll
+        for (int i = 0; i < G1W; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw1[i][n] = coop_wload<NT>(ws, G0W + i, n);
+    }
+    const float4* Xw = Xs + wave * 64 + lane;
+    CoopStream hs;
+    hs.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(hx), 0, coop_tile_f4(HID) * 16, 0x00020000);
+    hs.voff = (wave * 64 + lane) * 16;
+    auto hload = [&](int off_f4, int i) -> float4 {      // local k-group i (global 4 i + wave) of the image at float4 offset off_f4
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hs.rsrc, hs.voff, off_f4 * 16 + i * 4096, kSc1));
+    };
+
+    int prow[NP], pk[NP], pred[NP][4];
+    float c0[NP], c1[NP];
+    float bias0[BIAS_REGS ? NP : 1][4], bias1[BIAS_REGS ? NP : 1][4];
+    float wfc0[NP], wfc1[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = tid + 256 * i;
+        const int u = p % UNITS, row = p / UNITS;
+        prow[i] = row;
+        pk[i] = cs * UNITS + u;
+        c0[i] = 0.f; c1[i] = 0.f;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const int j = gate * UNITS + u;
+            pred[i][gate] = (((j >> 5) * 16) + (row & 3) + 4 * (row >> 3)) * 64 + (j & 31) + 32 * ((row >> 2) & 1);
+            if constexpr (BIAS_REGS) {
+                bias0[i][gate] = w.bias[gate * HID + pk[i]];
+                bias1[i][gate] = w.bias[4 * HID + gate * HID + pk[i]];
+            }
+        }
+        wfc0[i] = w.wfc[pk[i]];
+        wfc1[i] = w.wfc[HID + pk[i]];
+    }
+    if constexpr (!BIAS_REGS) { bias0[0][0] = 0.f; bias1[0][0] = 0.f; }
+
+    auto publish_tiles = [&](f32x16 (&acc)[NT]) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NT + n) * 16 + r) * 64 + lane] = acc[n][r];
+        __syncthreads();
+    };
+    auto red_sum = [&](int idx) -> float { return red[idx] + red[idx + NT * 1024] + red[idx + 2 * NT * 1024] + red[idx + 3 * NT * 1024]; };
+    // one layer's cell update of this thread's NP (row, unit) pairs from the summed tiles; returns h through `emit`
+    auto cell = [&](float (&c)[NP], const float (&bias)[BIAS_REGS ? NP : 1][4], int layer, auto emit) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float bi, bf, bg, bo;
+            if constexpr (BIAS_REGS) { bi = bias[i][0]; bf = bias[i][1]; bg = bias[i][2]; bo = bias[i][3]; }
+            else {
+                const float* b = w.bias + layer * 4 * HID + pk[i];
+                bi = b[0]; bf = b[HID]; bg = b[2 * HID]; bo = b[3 * HID];
+            }
+            float hval;
+            if constexpr (GRU) {
+                const float rg = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                const float zg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                const float ng = fast_tanh(red_sum(pred[i][2]) + bg + rg * (red_sum(pred[i][3]) + bo));
+                hval = ng + zg * (c[i] - ng);
+                c[i] = hval;
+            } else {
+                const float ig = fast_sigmoid(red_sum(pred[i][0]) + bi);
+                const float fg = fast_sigmoid(red_sum(pred[i][1]) + bf);
+                const float gg = fast_tanh(red_sum(pred[i][2]) + bg);
+                const float og = fast_sigmoid(red_sum(pred[i][3]) + bo);
+                const float cn = fg * c[i] + ig * gg;
+                c[i] = cn;
+                hval = og * fast_tanh(cn);
+            }
+            emit(i, hval);
+        }
+    };
+    // split-phase barrier: arrive now, wait a phase later
+    auto arrive = [&](unsigned* bar) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // `early` = the counter as thread 0 read it at the end of the previous MFMA phase (poll_early): in lockstep it is already
+    // complete, and the wait costs one __syncthreads instead of a fabric round trip
+    auto poll_early = [&](unsigned* bar) -> unsigned {
+        return tid == 0 ? __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    };
+    auto wait_for = [&](unsigned* bar, unsigned target, unsigned early) -> bool {
+        if (tid == 0 && early < target && !xchg_wait(bar, target, a.coop_abort, a.coop_err)) abort_s = 1;
+        __syncthreads();
+        return abort_s == 0;
+    };
+    auto fc_epilogue = [&](int t_done) {     // slice 0 sums the S partials of step t_done in a fixed order
+        if (cs == 0 && tid < 64) {
+            const int row = tid & 31, o = tid >> 5;
+            const RowDesc rd = rows_s[row];
+            const float* part = fcp + (size_t)(t_done & 1) * S * 64;
+            float sum = w.bfc[o];
+            for (int p = 0; p < S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
+            if (rd.valid && t_done >= a.LA)
+                a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
+        }
+    };
+
+    // A_t: layer 0 of step t.  m3 = t % 3, pm3 = (t - 1) % 3
+    unsigned early0 = 0, early1 = 0;                    // counters as read ahead of the next waits
+    auto phase_a = [&](int t, int m3, int pm3) {
+        float xr[NG];
+        NormMD mdn = md;
+        const bool have_next = t + 1 < Tp;
+        if (have_next) {
+            if (md_t) mdn = md_t[t + 1];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) xr[i] = x_load(i, t + 1);
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        const int hprev = h0off(pm3);
+        if constexpr (WREG)
+            coop_layer_resident<NT, G0W, KGXP / 4>(acc, bw0, [&](int i) -> float4 { return Xw[i * 256]; },
+                                                   [&](int i) -> float4 { return hload(hprev, i); });
+        else
+            coop_layer<NT, G0W, KGXP / 4, 0>(acc, ws, [&](int i) -> float4 { return Xw[i * 256]; },
+                                             [&](int i) -> float4 { return hload(hprev, i); });
+        early1 = poll_early(bar1);                       // for the wait in front of the C phase that follows
+        publish_tiles(acc);
+        float* img = reinterpret_cast<float*>(hx + h0off(m3));
+        cell(c0, bias0, 0, [&](int i, float hval) { xchg_store(img + a_frag_index(prow[i], pk[i]), hval); });
+        if (have_next) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
+        }
+        arrive(bar0);
+    };
+    // C_t: layer 1 of step t over [h1_{t-1} | h0_t]
+    auto phase_c = [&](int t, int m3) {
+        const int cur = t & 1, prv = cur ^ 1;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        const int h1p = h1off(prv), h0c = h0off(m3);
+        if constexpr (WREG)
+            coop_layer_resident<NT, G1W, KGH / 4>(acc, bw1, [&](int i) -> float4 { return hload(h1p, i); },
+                                                  [&](int i) -> float4 { return hload(h0c, i); });
+        else
+            coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(h1p, i); },
+                                              [&](int i) -> float4 { return hload(h0c, i); });
+        early0 = poll_early(bar0);                       // for the wait in front of the next A phase
+        publish_tiles(acc);
+        float* img = reinterpret_cast<float*>(hx + h1off(cur));
+        cell(c1, bias1, 1, [&](int i, float h) {
+            xchg_store(img + a_frag_index(prow[i], pk[i]), h);
+            float p0 = h * wfc0[i], p1 = h * wfc1[i];                 // partial Linear over this workgroup's units
+#pragma unroll
+            for (int m = UNITS / 2; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
+            if ((tid & (UNITS - 1)) == 0) {
+                float* part = fcp + ((size_t)cur * S + cs) * 64;
+                xchg_store(part + prow[i], p0);
+                xchg_store(part + 32 + prow[i], p1);
+            }
+        });
+        arrive(bar1);
+    };
+
+    __syncthreads();
+    phase_a(0, 0, 2);                                   // h0_{-1} = the (zeroed) third image
+    int m3 = 1, pm3 = 0;                                // t % 3, (t - 1) % 3 for t = 1
+    for (int t = 1; t < Tp; ++t) {
+        if (!wait_for(bar0, (unsigned)S * (unsigned)t, early0)) return;            // h0_{t-1} published by every slice
+        phase_a(t, m3, pm3);
+        if (!wait_for(bar1, (unsigned)S * (unsigned)(t - 1), early1)) return;      // h1_{t-2} and the Linear partials of step t-2
+        if (t >= 2) fc_epilogue(t - 2);
+        phase_c(t - 1, pm3);
+        pm3 = m3;
+        m3 = m3 == 2 ? 0 : m3 + 1;
+    }
+    if (!wait_for(bar0, (unsigned)S * (unsigned)Tp, early0)) return;
+    if (!wait_for(bar1, (unsigned)S * (unsigned)(Tp - 1), early1)) return;
+    if (Tp >= 2) fc_epilogue(Tp - 2);
+    phase_c(Tp - 1, pm3);
+    if (!wait_for(bar1, (unsigned)S * (unsigned)Tp, 0u)) return;
+    fc_epilogue(Tp - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 static int coop_kgxp(int KX) { return (KX / 8 + 3) / 4 * 4; }
 
 size_t lstm_coop_pack_floats(int H, int KX, int units) {
@@ -464,7 +753,7 @@ void lstm_coop_pack_weights(int H, int NIN, int KX, int units, const float* wih0
 
 // per row tile: 4 h images + Linear partials sized for the finest split (units = 8)
 size_t lstm_coop_exchange_bytes(int H, int row_tiles) {
-    return (size_t)row_tiles * (4 * (size_t)(H / 8) * 64 + 2 * (size_t)(H / 8) * 16) * 16;
+    return (size_t)row_tiles * (size_t)coop_tile_f4(H) * 16;
 }
 
 // occ != nullptr: do not launch; report how many workgroups of this instantiation fit one CU at once
@@ -482,6 +771,18 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
     const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(S, a.num_tiles, a.coop_xcd) : a.num_tiles * S;
+    if constexpr (!SEQ) {
+        // layer-skewed schedule (lstm2_coop_skew_kernel), same launch shape.  Measured (profiles/r02_column_split.md): it pays from
+        // 16 units per workgroup up (9 tiles 19.8 -> 18.0 us per step, 17 tiles 28.1 -> 25.8, 41 tiles 53.0 -> 48.4); at 8 units
+        // the MFMA phases (2 us) are too short to cover the second drain + arrival per step (1 tile 11.0 -> 10.8, 5 tiles 16 -> 28)
+        if (a.coop_skew && UNITS >= 16) {
+            auto skew = lstm2_coop_skew_kernel<HID, KX, UNITS, GRU>;
+            static PerDeviceOnce skew_once;
+            skew_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+            hipLaunchKernelGGL(skew, dim3(grid), dim3(256), smem, s, wv, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, wv, a);
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
     constexpr int S = HID / UNITS;
     constexpr int KGX = KX / 8, KGH = HID / 8, KG0 = KGX + KGH, KG1 = 2 * KGH;
     constexpr int HIMG = KGH * 64;                 // float4 per exchange image (32 rows x HID)
-    constexpr int HXT = 4 * HIMG + 2 * (HID / 8) * 16;   // float4 per row tile of the exchange region (lstm_coop.hip)
+    constexpr int HXT = coop_tile_f4(HID);         // float4 per row tile of the exchange region (lstm_common.h)
     constexpr int NG = KGX;
 
     __shared__ __attribute__((aligned(16))) float4 Xs[2][R][KGX * 64];  // A images of x_t, double buffered by step parity

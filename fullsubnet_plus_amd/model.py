@@ -410,7 +410,8 @@ class _HipModel(nn.Module):
         _lib.check(lib.fsnp_debug_set_lstm_waves(self._handle, int(waves)), "fsnp_debug_set_lstm_waves")
 
     def debug_set_lstm_coop(self, mode, device="cuda"):
-        """Tuning hook: 1 = use the cooperative column-split LSTM kernel for small batches (default), 0 = never."""
+        """Tuning hook: 1 = use the column-split LSTM kernels for small batches (default), 0 = never, 2 = as 1 with the
+        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
@@ -458,18 +459,18 @@ class _HipModel(nn.Module):
                 for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
-        """Test hook: pin the planner's cost table (14 values, planner_costs() order; None = built-in) and whether it may put
+        """Test hook: pin the planner's cost table (18 values, fsnp_get_costs order; None = built-in) and whether it may put
         two column-split workgroups on a CU (fsnp_debug_set_costs)."""
         lib = self._ensure_handle(_resolve_device(device))
-        arr = (ctypes.c_double * 14)(*costs) if costs is not None else None
+        arr = (ctypes.c_double * 18)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
-        buf, cal, occ = (ctypes.c_double * 14)(), ctypes.c_int32(), ctypes.c_int32()
+        buf, cal, occ = (ctypes.c_double * 18)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
         v = list(buf)
-        return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1]} for i, u in enumerate((8, 16, 32, 64))},
+        return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
                 "rowtile_us": v[12], "valu_row_surcharge": v[13], "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 

@@ -197,14 +197,15 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
- * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU},
+ * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU} when the
+ * launch is full, out[14..17] = the same four with ONE row tile (costs in between are interpolated in the tile count),
  * out[8..11] = three-way split with 1 / 2 row tiles per group x {one, two}, out[12] = one round of the one-tile-per-CU
  * kernel, out[13] = its relative surcharge per VALU row.  The built-in defaults (round-1 measurements) are replaced by
  * values MEASURED on the device the first time a call on a handle of this kind plans (once per process: ~0.1 s, the only
  * synchronising moment of fsnp_forward; FSNP_CALIBRATE=0 keeps the defaults): *calibrated = 1 from then on.  *occ =
  * workgroups per CU the column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU
  * twice; FSNP_COOP_OCC=1 forces 1). */
-int fsnp_get_costs(const fsnp_handle* h, double out[14], int32_t* calibrated, int32_t* occ);
+int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, int32_t* occ);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
  * (kernel 1) or groups (kernel 2), row tiles per group, first slot}.  Used by the CPU tests. */
@@ -265,7 +266,8 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * batches and for the remainder of larger ones, the one-tile-per-CU kernel for full rounds (fsnp_describe_plan shows the
  * cut); 0 = the one-tile-per-CU kernel only (also FSNP_LSTM_COOP=0 at fsnp_create time; use it when the GPU is shared
  * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
-int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);
+int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
+                                                                  schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0) */
 /* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
  * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph
  * and replayed on a private stream ordered by events (1) or straight into the caller's stream (2).  Off by default:
@@ -299,7 +301,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 3
+#define FSNP_ABI_VERSION 4
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

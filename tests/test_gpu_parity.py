@@ -116,7 +116,36 @@ def test_lstm2_fc_cooperative_kernel(n, steps):
     assert rel_err(tile, want) < 2e-5
 
 
-CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11]   # a table in which two workgroups per CU pay
+@pytest.mark.parametrize("seq", ["LSTM", "GRU"])
+@pytest.mark.parametrize("n,steps", [(7, 1), (32, 2), (40, 3), (257, 41), (514, 9), (1285, 6), (1344, 5)])
+def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
+    """csrc/lstm_coop.hip: lstm2_coop_skew_kernel runs layer 0 of step t+1 before layer 1 of step t (two arrival counters, three
+    h0 images) so that every inter-workgroup wait is for an arrival one phase old.  Same arithmetic, same summation order:
+    bit-identical to the serial schedule, for 1, 2, 3 and many steps, LSTM and GRU cells, every K-split width."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": seq}
+    sd = make_state_dict(9, "harsh", sequence_model=seq)
+    m = _model(args, sd)
+    rng = np.random.Generator(np.random.PCG64(321 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
+    m.lstm2_fc(x[:1])
+    m.debug_set_costs(None, 1)                # both runs on the same (round-1) plan
+    m.debug_set_lstm_coop(2)
+    m.debug_set_costs(None, 1)
+    serial = m.lstm2_fc(x).cpu().numpy()
+    m.check_errors()
+    m.debug_set_lstm_coop(1)
+    m.debug_set_costs(None, 1)
+    assert all(c["kernel"].startswith("lstm2_coop_kernel") for c in m.describe_plan(1))
+    skew = m.lstm2_fc(x).cpu().numpy()       # (the skewed schedule is used from 16 units per workgroup up: n >= 257 here)
+    m.check_errors()
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
+    assert rel_err(skew, want) < 2e-5
+    assert np.array_equal(skew, serial)
+    for _ in range(3):
+        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), skew)
+
+
+CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55]   # a table in which two workgroups per CU pay
 
 
 @pytest.mark.parametrize("n,steps", [(257, 40), (514, 20), (1285, 12), (2700, 9), (4112, 7), (5440, 6), (8000, 5), (10870, 4)])

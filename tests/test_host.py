@@ -418,13 +418,13 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
 
     def plan(rows, occ, costs=None, gru=0):
         buf = (ct.c_int32 * (8 * 64))()
-        arr = (ct.c_double * 14)(*costs) if costs else None
+        arr = (ct.c_double * 18)(*costs) if costs else None
         n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
         assert n > 0, lib.fsnp_last_error()
         keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
         return [dict(zip(keys, buf[8 * i:8 * i + 8])) for i in range(n)]
 
-    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11]
+    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55]
     p = plan(257, 2, cheap2)
     assert len(p) == 1 and p[0]["kind"] == 1 and p[0]["par"] == 8 and 9 * 48 <= 512
     p = plan(4112, 2, cheap2)                    # 129 tiles
@@ -436,7 +436,7 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
             for c in plan(rows, 2, cheap2, gru):
                 wgs = c["tiles"] * (384 // c["par"]) if c["kind"] == 1 else c["par"] * 3 if c["kind"] == 2 else 0
                 assert wgs <= 512 and (c["kind"] != 2 or c["par"] * c["rpg"] >= c["tiles"])
-    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11]      # K split suddenly slow: 9 tiles move
+    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100]      # K split suddenly slow: 9 tiles move
     p = plan(257, 1, slow_k)
     assert p[0]["kind"] == 2
 
