@@ -325,8 +325,9 @@ def test_enhance_epilogue_vs_oracle():
 @pytest.mark.parametrize("n,cus", [(700, 256), (257, 8), (8192 + 32, 256)])
 def test_bf16_ih_variant(n, cus):
     """BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM on bf16 MFMA (fp32 accumulate), everything else
-    fp32.  Tolerance re-stated against the fp32 oracle: 2e-2 rel (bf16 has 8 mantissa bits: h0 and W_ih_l1 are each
-    rounded to ~4e-3 relative); the fp32 path on the same inputs must stay at 2e-5."""
+    fp32.  Tolerance re-stated against the fp32 oracle: 2.5e-3 rel on the recurrent model alone (measured 1.1e-3 - 1.2e-3;
+    bf16 has 8 mantissa bits: h0 and W_ih_l1 are each rounded to ~4e-3 relative, the fp32 accumulation averages it down);
+    the fp32 path on the same inputs must stay at 2e-5."""
     sd = make_state_dict(10, "default")
     m = _model(DEFAULT_MODEL_ARGS, sd)
     m.debug_set_num_cus(cus)
@@ -342,7 +343,7 @@ def test_bf16_ih_variant(n, cus):
     got32 = m.lstm2_fc(x.cuda()).cpu().numpy()
     _record(f"bf16_ih_{n}_cus{cus}", rel_bf16=err, rel_fp32=rel_err(got32, want))
     assert rel_err(got32, want) < 2e-5
-    assert 1e-6 < err < 2e-2, err            # must differ from fp32 (the mode is really on) and stay inside the stated bound
+    assert 1e-6 < err < 2.5e-3, err          # must differ from fp32 (the mode is really on) and stay inside the stated bound
 
 
 def test_bf16_ih_forward_b32():
@@ -355,7 +356,7 @@ def test_bf16_ih_forward_b32():
     got = m(*ins).cpu().numpy()
     err = rel_err(got, ref)
     _record("bf16_ih_forward_b32_vs_fp32_hip", rel=err)
-    assert 1e-6 < err < 2e-2, err
+    assert 1e-6 < err < 6e-3, err            # whole forward at BASELINE configs[4]'s per-GPU shape: measured 4.9e-3
 
 
 def test_batch2_raises_like_reference():
