@@ -10,6 +10,9 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | 
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench.log
 rm -rf gpurun_out/prof gpurun_out/pmc*
 cd /tmp
+# (profiling runs: FSNP_CALIBRATE=0 keeps the planner's one-off calibration launches out of the per-kernel statistics; the
+#  built-in table yields the same B = 32 plan)
+export FSNP_CALIBRATE=0
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $R/gpurun_out/prof_bench.log 2>&1
 f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats.csv
 i=0
@@ -30,10 +33,13 @@ for i in (1, 2, 3, 4):
         print(f"pmc{i} {k:70s} {c:30s} sum={v:.6g} n={n} per_launch={v/n:.6g}")
 PY
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
+unset FSNP_CALIBRATE
 : > gpurun_out/b_final.log
 for args in "--batch 31" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--precision bf16_ih" "--batch 1" "--batch 2" "--batch 5" "--batch 8" "--batch 16" "--batch 21" "--batch 40" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
   timeout 400 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 >> gpurun_out/b_final.log
 done
+python tools/make_config_table.py > /dev/null
+python tools/dump_costs.py > gpurun_out/dump_costs.log 2>&1
 python - <<'PY' | tee gpurun_out/b_final.txt
 import json
 r = json.loads(open("gpurun_out/bench.log").read())
