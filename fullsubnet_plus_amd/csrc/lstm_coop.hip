@@ -46,18 +46,37 @@ __device__ __forceinline__ float4 coop_wload(const CoopStream& ws, int group, in
 // at stream groups [WBASE, WBASE + G).  The first XG local groups take their A operand from srcx(i), the others from
 // srch(i - XG).  Register pipeline D groups deep: a k-group lasts NT * 256 cycles, D = 16 / NT keeps ~4096 cycles
 // (> the L2 round trip) of loads in flight.
+template <int NT, int G>
+struct CoopDepth { static constexpr int value = (16 / NT < G) ? 16 / NT : G; };
+template <int NT, int G>
+using CoopA = float4[CoopDepth<NT, G>::value];            // A fragments of the D groups in flight
+template <int NT, int G>
+using CoopB = float4[CoopDepth<NT, G>::value][NT];        // their weight fragments
+
+// the first D groups' loads of a layer (coop_layer = coop_layer_prefill + coop_layer_run; the layer-skewed kernel issues the
+// prefill of its layer-1 phase BEFORE the drain / arrival / wait that end its layer-0 phase: those operands were published
+// a whole phase earlier, so their round trip overlaps the hand-off instead of following it)
 template <int NT, int G, int XG, int WBASE, typename SrcX, typename SrcH>
-__device__ __forceinline__ void coop_layer(f32x16 (&acc)[NT], const CoopStream& ws, SrcX srcx, SrcH srch) {
-    constexpr int D = 16 / NT < G ? 16 / NT : G;
-    float4 a[D];
-    float4 b[D][NT];
+__device__ __forceinline__ void coop_layer_prefill(CoopA<NT, G>& a, CoopB<NT, G>& b,
+                                                   const CoopStream& ws, SrcX srcx, SrcH srch) {
+    constexpr int D = CoopDepth<NT, G>::value;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        a[k] = k < XG ? srcx(k) : srch(k - XG);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[k][n] = coop_wload<NT>(ws, WBASE + k, n);
+    }
+}
+
+template <int NT, int G, int XG, int WBASE, typename SrcX, typename SrcH>
+__device__ __forceinline__ void coop_layer_run(f32x16 (&acc)[NT], CoopA<NT, G>& a, CoopB<NT, G>& b,
+                                               const CoopStream& ws, SrcX srcx, SrcH srch) {
+    constexpr int D = CoopDepth<NT, G>::value;
     auto fill = [&](int slot, int i) {
         a[slot] = i < XG ? srcx(i) : srch(i - XG);
 #pragma unroll
         for (int n = 0; n < NT; ++n) b[slot][n] = coop_wload<NT>(ws, WBASE + i, n);
     };
-#pragma unroll
-    for (int k = 0; k < D; ++k) fill(k, k);
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int slot = i % D;
@@ -71,6 +90,15 @@ __device__ __forceinline__ void coop_layer(f32x16 (&acc)[NT], const CoopStream& 
         if (i + D < G) fill(slot, i + D);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int NT, int G, int XG, int WBASE, typename SrcX, typename SrcH>
+__device__ __forceinline__ void coop_layer(f32x16 (&acc)[NT], const CoopStream& ws, SrcX srcx, SrcH srch) {
+    constexpr int D = CoopDepth<NT, G>::value;
+    float4 a[D];
+    float4 b[D][NT];
+    coop_layer_prefill<NT, G, XG, WBASE>(a, b, ws, srcx, srch);
+    coop_layer_run<NT, G, XG, WBASE>(acc, a, b, ws, srcx, srch);
 }
 
 // The same with the wave's weights RESIDENT in registers (bw[i][n], loaded once before the time loop): with <= 16 hidden
@@ -622,7 +650,12 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
 
     // A_t: layer 0 of step t.  m3 = t % 3, pm3 = (t - 1) % 3
     unsigned early0 = 0, early1 = 0;                    // counters as read ahead of the next waits
-    auto phase_a = [&](int t, int m3, int pm3) {
+    // operands of the first groups of the NEXT layer-1 phase, issued before the hand-off that ends a layer-0 phase
+    CoopA<NT, G1W> ca;
+    CoopB<NT, G1W> cb;
+    // A_t; with_c: C_{t-1} follows - its b1 wait and the prefill of its first operand groups happen in here, between the
+    // stores of h0_t and the drain + arrival, so that their round trips overlap.  Returns false once the launch is aborted.
+    auto phase_a = [&](int t, int m3, int pm3, bool with_c) -> bool {
         float xr[NG];
         NormMD mdn = md;
         const bool have_next = t + 1 < Tp;
@@ -643,7 +676,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         else
             coop_layer<NT, G0W, KGXP / 4, 0>(acc, ws, [&](int i) -> float4 { return Xw[i * 256]; },
                                              [&](int i) -> float4 { return hload(hprev, i); });
-        early1 = poll_early(bar1);                       // for the wait in front of the C phase that follows
+        if (with_c) early1 = poll_early(bar1);           // for the wait in front of the C phase that follows
         publish_tiles(acc);
         float* img = reinterpret_cast<float*>(hx + h0off(m3));
         cell(c0, bias0, 0, [&](int i, float hval) { xchg_store(img + a_frag_index(prow[i], pk[i]), hval); });
@@ -651,10 +684,19 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
         }
+        if (with_c) {
+            if (!wait_for(bar1, (unsigned)S * (unsigned)(t - 1), early1)) return false;   // h1_{t-2}, Linear partials of step t-2
+            if constexpr (!WREG) {
+                const int h1p = h1off(t & 1), h0c = h0off(pm3);      // C_{t-1} reads h1_{t-2} (parity t & 1) and h0_{t-1}
+                coop_layer_prefill<NT, G1W, KGH / 4, G0W>(ca, cb, ws, [&](int i) -> float4 { return hload(h1p, i); },
+                                                          [&](int i) -> float4 { return hload(h0c, i); });
+            }
+        }
         arrive(bar0);
+        return true;
     };
     // C_t: layer 1 of step t over [h1_{t-1} | h0_t]
-    auto phase_c = [&](int t, int m3) {
+    auto phase_c = [&](int t, int m3, bool prefilled) {
         const int cur = t & 1, prv = cur ^ 1;
         f32x16 acc[NT];
 #pragma unroll
@@ -665,9 +707,13 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         if constexpr (WREG)
             coop_layer_resident<NT, G1W, KGH / 4>(acc, bw1, [&](int i) -> float4 { return hload(h1p, i); },
                                                   [&](int i) -> float4 { return hload(h0c, i); });
-        else
-            coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(h1p, i); },
-                                              [&](int i) -> float4 { return hload(h0c, i); });
+        else {
+            if (!prefilled)
+                coop_layer_prefill<NT, G1W, KGH / 4, G0W>(ca, cb, ws, [&](int i) -> float4 { return hload(h1p, i); },
+                                                          [&](int i) -> float4 { return hload(h0c, i); });
+            coop_layer_run<NT, G1W, KGH / 4, G0W>(acc, ca, cb, ws, [&](int i) -> float4 { return hload(h1p, i); },
+                                                  [&](int i) -> float4 { return hload(h0c, i); });
+        }
         early0 = poll_early(bar0);                       // for the wait in front of the next A phase
         publish_tiles(acc);
         float* img = reinterpret_cast<float*>(hx + h1off(cur));
@@ -686,21 +732,20 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
     };
 
     __syncthreads();
-    phase_a(0, 0, 2);                                   // h0_{-1} = the (zeroed) third image
+    (void)phase_a(0, 0, 2, false);                      // h0_{-1} = the (zeroed) third image
     int m3 = 1, pm3 = 0;                                // t % 3, (t - 1) % 3 for t = 1
     for (int t = 1; t < Tp; ++t) {
         if (!wait_for(bar0, (unsigned)S * (unsigned)t, early0)) return;            // h0_{t-1} published by every slice
-        phase_a(t, m3, pm3);
-        if (!wait_for(bar1, (unsigned)S * (unsigned)(t - 1), early1)) return;      // h1_{t-2} and the Linear partials of step t-2
+        if (!phase_a(t, m3, pm3, true)) return;                                    // (waits for b1 >= S (t-1) inside)
         if (t >= 2) fc_epilogue(t - 2);
-        phase_c(t - 1, pm3);
+        phase_c(t - 1, pm3, !WREG);
         pm3 = m3;
         m3 = m3 == 2 ? 0 : m3 + 1;
     }
     if (!wait_for(bar0, (unsigned)S * (unsigned)Tp, early0)) return;
-    if (!wait_for(bar1, (unsigned)S * (unsigned)(Tp - 1), early1)) return;
+    if (!wait_for(bar1, (unsigned)S * (unsigned)(Tp - 1), Tp >= 2 ? poll_early(bar1) : 0u)) return;
     if (Tp >= 2) fc_epilogue(Tp - 2);
-    phase_c(Tp - 1, pm3);
+    phase_c(Tp - 1, pm3, false);
     if (!wait_for(bar1, (unsigned)S * (unsigned)Tp, 0u)) return;
     fc_epilogue(Tp - 1);
 }
