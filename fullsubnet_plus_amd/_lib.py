@@ -50,6 +50,7 @@ SYMBOLS = {
     "fsnp_describe_plan": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 18), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fsnp_debug_plan_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_i32), c_i32]),
+    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 18)]),
     "fsnp_debug_set_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), c_i32]),
     "fsnp_debug_plan_rows2": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(c_i32), c_i32]),

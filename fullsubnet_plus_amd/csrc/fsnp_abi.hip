@@ -104,7 +104,7 @@ struct fsnp_handle {
     CostTable cost{};            // per-step costs the planner minimises (defaults, then measured on the device)
     int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (FSNP_COOP_OCC; 1 or 2) ...
     int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};   // ... and what each instantiation really fits (measured at commit)
-    int calibrate = 1;           // FSNP_CALIBRATE=0: keep the default table
+    int calibrate = 0;           // FSNP_CALIBRATE=1: replace the built-in table by one measured on this device at the first planning call
     int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
     TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
     int XS = 0;                  //     row stride of its [slot][t][NIN] activations
@@ -405,10 +405,12 @@ struct SbPlan {
 static CostTable default_costs() {
     CostTable t{};
     // round-2 measurements (profiles/r02_planner_costs.json): a full launch, one row tile, three-way split, one-tile-per-CU
-    const double ks[4] = {14.4, 20.4, 32.8, 58.6}, k1[4] = {8.7, 15.0, 25.0, 45.0}, cn[2] = {85.4, 162.3};
+    // K split (serial schedule at 8 units, layer-skewed from 16 up): a full launch / one row tile; three-way split at 85 / 170 row
+    // tiles; one round of the one-tile-per-CU kernel - from 128-step runs (profiles/r02_column_split.md)
+    const double ks[4] = {14.4, 16.5, 26.0, 48.5}, k1[4] = {8.7, 14.0, 22.5, 42.0}, cn[2] = {78.0, 157.0};
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 210.0; t.rowtile_ex = 0.11;
+    t.rowtile = 208.0; t.rowtile_ex = 0.11;
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
@@ -720,8 +722,9 @@ struct CalKey {
 static std::mutex g_cal_mu;
 static std::map<CalKey, CostTable> g_cal_cache;
 
-static int calibrate_costs(fsnp_handle* h) {
-    if (h->cost.calibrated || !h->calibrate || h->sb_tcn || !h->committed) return 0;
+static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measured = nullptr) {
+    if (adopt && (h->cost.calibrated || !h->calibrate)) return 0;
+    if (h->sb_tcn || !h->committed) return 0;
     int occ_sig = h->coop_occ;
     for (int i = 0; i < 4; ++i) occ_sig = occ_sig * 4 + h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) occ_sig = occ_sig * 4 + h->occ_coopn[i];
@@ -730,10 +733,14 @@ static int calibrate_costs(fsnp_handle* h) {
     {
         std::lock_guard<std::mutex> lk(g_cal_mu);
         auto it = g_cal_cache.find(key);
-        if (it != g_cal_cache.end()) { h->cost = it->second; return 0; }
+        if (it != g_cal_cache.end()) {
+            if (measured) *measured = it->second;
+            if (adopt) h->cost = it->second;
+            return 0;
+        }
     }
     const int S3 = h->H / 128, occ = h->coop_occ >= 2 ? 2 : 1;
-    const int steps_a = 6, steps_b = 22;
+    const int steps_a = 8, steps_b = 40;
     const int max_tiles = std::max(h->num_cus_real, (h->num_cus_real * occ / S3) * 2);
     const size_t x_floats = (size_t)max_tiles * 32 * steps_b * h->NIN, o_floats = (size_t)max_tiles * 32 * 2 * steps_b;
     float* scratch = nullptr;
@@ -754,6 +761,12 @@ static int calibrate_costs(fsnp_handle* h) {
     FSNP_CAL_CHECK(hipMemsetAsync(scratch, 0, (x_floats + o_floats) * 4, cs));
     const bool had_pipeline = h->pipeline != 0;
     CostTable t = h->cost;
+    if (h->rowtile_ok) {            // ramp the clocks: short launches on an idle chip run at a lower power state than a forward does
+        SbPlan warm;
+        warm.chunks = {SbChunk{0, 0, h->num_cus_real * 32, h->num_cus_real, 0, 32, 0, 0, 0, 0, 0}};
+        warm.total_slots = h->num_cus_real * 32;
+        (void)run_dense_plan(h, warm, scratch, scratch + x_floats, h->num_cus_real * 32, 64, cs);
+    }
     // one shape: returns its per-step cost in microseconds (< 0 on failure)
     auto time_shape = [&](SbChunk c) -> double {
         c.row0 = 0; c.nrows = c.num_tiles * 32; c.slot0 = 0; c.coop_tile0 = 0;
@@ -762,14 +775,16 @@ static int calibrate_costs(fsnp_handle* h) {
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
-            for (int rep = 0; rep < 2; ++rep) {            // rep 0 warms caches / code, rep 1 is timed
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {            // rep 0 warms caches / code / clocks; the faster of reps 1, 2 counts
                 if (hipEventRecord(e0, cs) != hipSuccess) return -1.0;
                 if (run_dense_plan(h, plan, scratch, scratch + x_floats, c.nrows, steps, cs)) return -1.0;
                 if (hipEventRecord(e1, cs) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
                 float f = 0;
                 if (hipEventElapsedTime(&f, e0, e1) != hipSuccess) return -1.0;
-                ms[k] = f;
+                if (rep > 0 && f < best) best = f;
             }
+            ms[k] = best;
         }
         return (ms[1] - ms[0]) * 1000.0 / (steps_b - steps_a);
     };
@@ -810,7 +825,8 @@ static int calibrate_costs(fsnp_handle* h) {
         h->coop_occ = 1;
     }
     t.calibrated = 1;
-    h->cost = t;
+    if (measured) *measured = t;
+    if (adopt) h->cost = t;
     std::lock_guard<std::mutex> lk(g_cal_mu);
     g_cal_cache[key] = t;
     return 0;
@@ -887,7 +903,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->cost = default_costs();
     if (h->gru) h->cost.rowtile *= 0.75;   // three of the four gate tiles per k-group
     const char* ce = getenv("FSNP_CALIBRATE");
-    if (ce && ce[0] == '0') h->calibrate = 0;
+    if (ce && ce[0] == '1') h->calibrate = 1;
     const char* oe = getenv("FSNP_COOP_OCC");          // 1 = never plan two column-split workgroups per CU
     h->coop_occ = oe && oe[0] == '1' ? 1 : 2;          // (2 is confirmed against the kernels' occupancy at commit time)
     h->sb_tcn = cfg->sequence_model == FSNP_SEQ_TCN;
@@ -1654,6 +1670,19 @@ int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, in
     for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
+    return 0;
+}
+
+int fsnp_measure_costs(fsnp_handle* h, double out[18]) {
+    if (!h || !out) { set_error("fsnp_measure_costs: null argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_measure_costs: weights not committed"); return 2; }
+    if (h->sb_tcn) { set_error("fsnp_measure_costs: the sub-band model of this handle is a TCN (no recurrent kernels)"); return 2; }
+    FSNP_ON_DEVICE(h);
+    CostTable t = h->cost;
+    if (calibrate_costs(h, false, &t)) return 4;
+    for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
+    for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
+    out[12] = t.rowtile; out[13] = t.rowtile_ex;
     return 0;
 }
 

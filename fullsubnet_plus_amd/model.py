@@ -465,14 +465,24 @@ class _HipModel(nn.Module):
         arr = (ctypes.c_double * 18)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
+    @staticmethod
+    def _cost_dict(v):
+        return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
+                "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
+                "rowtile_us": v[12], "valu_row_surcharge": v[13]}
+
+    def measure_costs(self):
+        """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""
+        buf = (ctypes.c_double * 18)()
+        with torch.cuda.device(self._hip.device):
+            _lib.check(_lib.load().fsnp_measure_costs(self._handle, ctypes.byref(buf)), "fsnp_measure_costs")
+        return self._cost_dict(list(buf))
+
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
         buf, cal, occ = (ctypes.c_double * 18)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
-        v = list(buf)
-        return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
-                "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
-                "rowtile_us": v[12], "valu_row_surcharge": v[13], "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
+        return {**self._cost_dict(list(buf)), "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 
     def forward_flops(self, batch, frames, parity=False):
         return float(_lib.load().fsnp_forward_flops(self._handle, batch, frames, int(parity)))

@@ -200,12 +200,17 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
  * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU} when the
  * launch is full, out[14..17] = the same four with ONE row tile (costs in between are interpolated in the tile count),
  * out[8..11] = three-way split with 1 / 2 row tiles per group x {one, two}, out[12] = one round of the one-tile-per-CU
- * kernel, out[13] = its relative surcharge per VALU row.  The built-in defaults (round-1 measurements) are replaced by
- * values MEASURED on the device the first time a call on a handle of this kind plans (once per process: ~0.1 s, the only
- * synchronising moment of fsnp_forward; FSNP_CALIBRATE=0 keeps the defaults): *calibrated = 1 from then on.  *occ =
- * workgroups per CU the column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU
- * twice; FSNP_COOP_OCC=1 forces 1). */
+ * kernel, out[13] = its relative surcharge per VALU row.  The built-in table holds round-2 measurements from 128-step runs
+ * (profiles/r02_column_split.md), so plans - and performance - are reproducible from run to run and box to box.
+ * fsnp_measure_costs MEASURES the same 18 numbers on the device (every launch shape on zeros at two step counts, slope;
+ * ~0.3 s, synchronises; cached per process) without touching the plan: tests/test_gpu_parity.py asserts that the built-in
+ * table has not drifted from the kernels.  FSNP_CALIBRATE=1 makes a handle ADOPT the measured table at its first planning
+ * call (*calibrated = 1 from then on) - short calibration launches run at other clocks than a forward, so measured tables
+ * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
+ * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
+ * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
 int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, int32_t* occ);
+int fsnp_measure_costs(fsnp_handle* h, double out[18]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
  * (kernel 1) or groups (kernel 2), row tiles per group, first slot}.  Used by the CPU tests. */

@@ -388,7 +388,8 @@ def test_subband_plan_choices_match_the_design():
     p = _plan(4096)                                                                 # parity-mode B = 32: 128 tiles = one per group
     assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # + 42 + a few (76 + 55 + 9 us)
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert kinds(4256) == [(2, 4256)] and _plan(4256)[0]["rpg"] == 2                # 133 tiles: two per group
+    assert seq(4256) == [2, 1, 1]                                                   # 133 tiles: 85 + 42 + 6 (78 + 48.5 + ~15 us < 157)
+    assert kinds(5397) == [(2, 5397)] and _plan(5397)[0]["rpg"] == 2                # B = 21, 169 tiles: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles

@@ -23,6 +23,7 @@ for seq in ("LSTM", "GRU"):
     m(*ins)
     torch.cuda.synchronize()
     c = m.planner_costs()
+    c["measured"] = m.measure_costs()
     c["first_forward_s"] = time.perf_counter() - t0
     c["plans"] = {b: [f'{k["kernel"].split(" ")[0]} x{k["sequences"]}' for k in m.describe_plan(b)] for b in (1, 2, 3, 5, 8, 12, 16, 21, 32, 40)}
     c["plan_parity_b32"] = [f'{k["kernel"].split(" ")[0]} x{k["sequences"]}' for k in m.describe_plan(32, parity=True)]

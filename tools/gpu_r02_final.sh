@@ -12,7 +12,7 @@ rm -rf gpurun_out/prof gpurun_out/pmc*
 cd /tmp
 # (profiling runs: FSNP_CALIBRATE=0 keeps the planner's one-off calibration launches out of the per-kernel statistics; the
 #  built-in table yields the same B = 32 plan)
-export FSNP_CALIBRATE=0
+export FSNP_CALIBRATE=0   # (the default since the built-in table drives the planner; kept explicit)
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $R/gpurun_out/prof_bench.log 2>&1
 f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats.csv
 i=0
