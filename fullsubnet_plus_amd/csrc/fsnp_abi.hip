@@ -765,7 +765,8 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         SbPlan warm;
         warm.chunks = {SbChunk{0, 0, h->num_cus_real * 32, h->num_cus_real, 0, 32, 0, 0, 0, 0, 0}};
         warm.total_slots = h->num_cus_real * 32;
-        (void)run_dense_plan(h, warm, scratch, scratch + x_floats, h->num_cus_real * 32, 64, cs);
+        for (int k = 0; k < 2; ++k)         // (the scratch buffers hold steps_b steps of max_tiles tiles: stay inside them)
+            (void)run_dense_plan(h, warm, scratch, scratch + x_floats, h->num_cus_real * 32, steps_b, cs);
     }
     // one shape: returns its per-step cost in microseconds (< 0 on failure)
     auto time_shape = [&](SbChunk c) -> double {
