@@ -17,7 +17,7 @@ hp = " + ".join("%s ×%d" % (c["kernel"].split(" ")[0], c["sequences"]) for c in
 out = ["# r02 - bench.py on one MI355X: every configuration measured at the end of round 2 (gpurun, `tools/gpu_r02_final.sh`)", "",
        "fp32 unless stated; frames/s = B·T / wall time of the whole forward, inputs resident in HBM.  `ms/step` = the default loop of",
        "bench.py (pipelined serving loop, `fsnp_set_pipeline`: only differs where the plan has a remainder chunk behind a one-tile-per-CU",
-       "chunk), `back to back` = `alt_ms_per_step` (forwards strictly serialised).  Plans are the calibrated planner's.", "",
+       "chunk), `back to back` = `alt_ms_per_step` (forwards strictly serialised).  Plans are those of the built-in cost table.", "",
        "| configuration | frames/s | ms/step | back to back | plan of the sub-band model |", "|---|---|---|---|---|",
        "| **headline** `--gpus 1 --steps 20 --warmup 5`: batch 32 × 2 s, full mode | **%.0f** | **%.3f** | %.3f | %s; dominant kernel %.2f ms = %.3f of "
        "the fp32 MFMA peak; cpu_baseline (port, %d threads) %.0f frames/s; cIRM rel err vs oracle (utterances 0, 31) %.1e |"
