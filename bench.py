@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--mode", default="full", choices=["full", "parity"])
     ap.add_argument("--norm", default="offline_laplace_norm")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_ih"],
-                    help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_ih", "bf16x3"],
+                    help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM); bf16x3 = optional: fp32 "
+                         "products of the LSTM emulated by three bf16 MFMAs (NOT the headline either)")
     ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
                     help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
     ap.add_argument("--sequence-model", default="LSTM", choices=["LSTM", "GRU", "TCN"],
@@ -268,7 +269,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "alt_ms_per_step": None if alt_elapsed is None else alt_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 + bf16 ih-GEMM (configs[4])",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_ih": "f32 + bf16 ih-GEMM (configs[4])",
+                                  "bf16x3": "f32 emulated by split bf16 (3 MFMAs per product, fp32 accumulate) - optional mode"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
                                f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)" +

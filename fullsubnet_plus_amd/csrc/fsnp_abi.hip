@@ -544,7 +544,12 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.rows = a.rows + c.slot0;
         ca.num_rows = c.nrows; ca.num_tiles = c.num_tiles; ca.ex = c.ex;
         if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
-        if (c.kind == 0) { if (h->gru) launch_gru(h->lw, ca, s); else launch_lstm(h->lw, ca, s); continue; }
+        if (c.kind == 0) {
+            if (h->gru) launch_gru(h->lw, ca, s);
+            else if (h->ih_bf16 == 2 && c.ex == 0) launch_lstm_bf3(h->lw, ca, s);      // (VALU-row tiles exist in fp32 / bf16-ih only)
+            else launch_lstm(h->lw, ca, s);
+            continue;
+        }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
@@ -1138,6 +1143,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
                                      blob.data() + o_wpack_bf[i]);
         }
     }
+    size_t o_wpack_bf3 = 0;
+    if (!h->gru && !h->sb_tcn && h->KX == 40) {      // optional split-bf16 variant of the one-tile-per-CU kernel
+        o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
+        lstm_bf3_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_bf3);
+    }
     size_t o_wpack_gru = 0;
     if (h->gru && !h->sb_tcn) {
         o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
@@ -1206,6 +1216,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_gru = d + o_wpack_gru;
+    h->lw.wpack_bf3 = d + o_wpack_bf3;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
     if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
@@ -1742,11 +1753,11 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 }
 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
-    if (!h || (ih_bf16 != 0 && ih_bf16 != 1)) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM)"); return 1; }
+    if (!h || ih_bf16 < 0 || ih_bf16 > 2) { set_error("fsnp_set_precision: 0 (fp32), 1 (bf16 ih-GEMM) or 2 (split-bf16 emulation of fp32)"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
     if (ih_bf16 && h->KX != 40) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 40 features only"); return 2; }
     h->ih_bf16 = ih_bf16;
-    h->lw.ih_bf16 = ih_bf16;
+    h->lw.ih_bf16 = ih_bf16 == 1 ? 1 : 0;       // (launch_lstm's own switch: the bf16-ih variant of lstm.hip)
     return 0;
 }
 

@@ -146,9 +146,10 @@ struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
     const float* wpack_bf[2];   // bf16-ih streams (4-wave, 12-wave): layer-1 W_ih as bf16 k-steps (configs[4])
-    int ih_bf16;                // 1 = use them
+    int ih_bf16;                // 1 = use them; 2 = the split-bf16 variant (wpack_bf3, lstm_bf3.hip)
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
+    const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
@@ -196,6 +197,11 @@ struct LstmArgs {
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+// lstm_bf3.hip: the same decomposition with every fp32 product emulated by three bf16 MFMAs (optional precision mode 2)
+void launch_lstm_bf3(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t lstm_bf3_pack_floats(int H, int KX, int NW);
+void lstm_bf3_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
+                           const float* whh1, float* wpack);
 // lstm_gru.hip: the same decomposition for nn.GRU (three live gate tiles per k-group, no VALU rows)
 void launch_gru(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t gru_pack_floats(int H, int KX, int NW);

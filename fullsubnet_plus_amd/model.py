@@ -421,10 +421,11 @@ class _HipModel(nn.Module):
         _lib.check(lib.fsnp_debug_set_graph(self._handle, int(mode)), "fsnp_debug_set_graph")
 
     def set_precision(self, mode, device="cuda"):
-        """"fp32" (default) or "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16)."""
-        assert mode in ("fp32", "bf16_ih")
+        """"fp32" (default), "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16) or "bf16x3"
+        (optional: every fp32 product of the one-tile-per-CU LSTM kernel emulated by three bf16 MFMAs, fsnp.h)."""
+        assert mode in ("fp32", "bf16_ih", "bf16x3")
         lib = self._ensure_handle(_resolve_device(device))
-        _lib.check(lib.fsnp_set_precision(self._handle, int(mode == "bf16_ih")), "fsnp_set_precision")
+        _lib.check(lib.fsnp_set_precision(self._handle, {"fp32": 0, "bf16_ih": 1, "bf16x3": 2}[mode]), "fsnp_set_precision")
 
     def debug_inject_error(self):
         """Test hook: pretend an inter-workgroup wait timed out (see fsnp_debug_inject_error)."""

@@ -245,6 +245,11 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
  * mode vs the fp32 reference: 2.5e-3 rel on the recurrent model, 6e-3 on the whole forward at B = 32 (measured 1.2e-3 /
  * 4.9e-3; tests/test_gpu_parity.py::test_bf16_ih_variant, ::test_bf16_ih_forward_b32).  Sub-band inputs of <= 40 features only. */
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
+/* ih_bf16 = 2: OPTIONAL, not a BASELINE.json configuration and never the headline: the one-tile-per-CU LSTM kernel with
+ * every fp32 product emulated by three bf16 MFMAs on operands split into hi + lo bf16 parts (csrc/lstm_bf3.hip: 16
+ * significant bits per operand, fp32 accumulation, the lo x lo term dropped; column-split chunks stay fp32).  The only way
+ * past the 157 TFLOP/s fp32 matrix roof; error vs the fp32 path and speed: tests/test_gpu_parity.py::test_bf16x3_variant,
+ * profiles/r02_bf16x3.md. */
 
 /* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
  * inter-workgroup wait in a column-split LSTM kernel, whose workgroups must all be co-resident).  0 = none.

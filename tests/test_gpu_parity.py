@@ -364,6 +364,42 @@ def test_bf16_ih_forward_b32():
     assert 1e-6 < err < 6e-3, err            # whole forward at BASELINE configs[4]'s per-GPU shape: measured 4.9e-3
 
 
+@pytest.mark.parametrize("n,steps", [(70, 24), (700, 40), (8192 + 32, 24)])
+def test_bf16x3_variant(n, steps):
+    """Optional precision mode 2 (csrc/lstm_bf3.hip, fsnp.h: fsnp_set_precision): every fp32 product of the one-tile-per-CU
+    LSTM kernel emulated by three bf16 MFMAs on operands split into hi + lo bf16 parts (16 significant bits, fp32
+    accumulation).  Not fp32-exact, but two orders of magnitude inside the 1e-3 bar: asserted < 1e-4 vs the fp32 oracle."""
+    sd = make_state_dict(10, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    m.debug_set_lstm_coop(0)
+    rng = np.random.Generator(np.random.PCG64(66 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    m.set_precision("bf16x3")
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+    m.set_precision("fp32")
+    got32 = m.lstm2_fc(x.cuda()).cpu().numpy()
+    err = rel_err(got, want)
+    _record(f"bf16x3_{n}x{steps}", rel_bf16x3=err, rel_fp32=rel_err(got32, want))
+    assert rel_err(got32, want) < 2e-5
+    assert 1e-9 < rel_err(got, got32) and err < 1e-4, err
+
+
+def test_bf16x3_forward_b32():
+    sd = make_state_dict(0, "default")
+    mag, real, imag = make_inputs(32, 2.0, 100)
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    ins = _cuda((mag, real, imag))
+    ref = m(*ins).cpu().numpy()
+    m.set_precision("bf16x3")
+    got = m(*ins).cpu().numpy()
+    m.set_precision("fp32")
+    err = rel_err(got, ref)
+    _record("bf16x3_forward_b32_vs_fp32_hip", rel=err)
+    assert 1e-9 < err < 2e-4, err
+
+
 def test_batch2_raises_like_reference():
     g = Golden("b4_t16_default")
     m = _model(g.args, g.state_dict(), "parity")
