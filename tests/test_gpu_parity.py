@@ -364,7 +364,7 @@ def test_bf16_ih_forward_b32():
     assert 1e-6 < err < 6e-3, err            # whole forward at BASELINE configs[4]'s per-GPU shape: measured 4.9e-3
 
 
-@pytest.mark.parametrize("n,steps", [(70, 24), (700, 40), (8192 + 32, 24)])
+@pytest.mark.parametrize("n,steps", [(70, 24), (700, 40), (8192, 24)])
 def test_bf16x3_variant(n, steps):
     """Optional precision mode 2 (csrc/lstm_bf3.hip, fsnp.h: fsnp_set_precision): every fp32 product of the one-tile-per-CU
     LSTM kernel emulated by three bf16 MFMAs on operands split into hi + lo bf16 parts (16 significant bits, fp32
