@@ -35,7 +35,7 @@ PY
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
 unset FSNP_CALIBRATE
 : > gpurun_out/b_final.log
-for args in "--batch 31" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--precision bf16_ih" "--batch 1" "--batch 2" "--batch 5" "--batch 8" "--batch 16" "--batch 21" "--batch 40" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
+for args in "--batch 31" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--precision bf16_ih" "--precision bf16x3" "--precision bf16x3 --batch 64" "--batch 1" "--batch 2" "--batch 5" "--batch 8" "--batch 16" "--batch 21" "--batch 40" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
   timeout 400 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 >> gpurun_out/b_final.log
 done
 python tools/make_config_table.py > /dev/null
