@@ -431,7 +431,7 @@ static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
     return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
-    if (h->gru) return SbChunk{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};   // lstm_gru.hip has no VALU rows
+    if (h->gru || h->H != 384) return SbChunk{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};   // VALU rows: LSTM at H = 384 only
     const LstmPlan lp = plan_lstm_tiles(nrows, h->num_cus);
     return SbChunk{0, row0, nrows, lp.num_tiles, lp.ex, lp.rows_per_slot_tile, 0, 0, 0, 0, 0};
 }
@@ -855,7 +855,10 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->sb_num_neighbors < 0 || cfg->fb_num_neighbors < 0) { set_error("sb_num_neighbors / fb_num_neighbors must be >= 0"); return 2; }
     if (cfg->num_groups_in_drop_band < 1) { set_error("num_groups_in_drop_band must be >= 1"); return 2; }
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
-    if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be 384 (fused LSTM kernel instantiation)"); return 2; }
+    if (cfg->sb_hidden != 384 && cfg->sb_hidden != 256 && cfg->sb_hidden != 512 && cfg->sequence_model != FSNP_SEQ_TCN) {
+        set_error("sb_model_hidden_size must be 256, 384 or 512 (the instantiations of the recurrent kernels)");
+        return 2;
+    }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
     if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
@@ -905,9 +908,17 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     }
     h->model = cfg->model;
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
-    h->rowtile_ok = true;               // LSTM: lstm.hip, GRU: lstm_gru.hip
+    // one-tile-per-CU kernels: LSTM lstm.hip (H = 384, and 256 without VALU rows), GRU lstm_gru.hip (384); other sizes run on
+    // the column-split kernels only
+    h->rowtile_ok = cfg->sb_hidden == 384 || (cfg->sb_hidden == 256 && !h->gru);
     h->cost = default_costs();
     if (h->gru) h->cost.rowtile *= 0.75;   // three of the four gate tiles per k-group
+    if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) {     // the table is measured at 384: scale by the work per step
+        const double f = cfg->sb_hidden / 384.0;
+        for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] *= f; h->cost.ksplit[i][1] *= f; h->cost.ksplit1[i] *= f; }
+        for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] *= f; h->cost.coopn[i][1] *= f; }
+        h->cost.rowtile *= f * f;
+    }
     const char* ce = getenv("FSNP_CALIBRATE");
     if (ce && ce[0] == '1') h->calibrate = 1;
     const char* oe = getenv("FSNP_COOP_OCC");          // 1 = never plan two column-split workgroups per CU
@@ -1131,12 +1142,14 @@ int fsnp_commit_weights(fsnp_handle* h) {
     };
     const Rnn4 sbw = h->sb_tcn ? Rnn4{} : expand("sb_model.sequence_model.", H, h->NIN);
     size_t o_wpack = 0, o_wpack12 = 0, o_wpack_bf[2] = {0, 0};
-    if (!h->gru && !h->sb_tcn) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
+    if (!h->gru && !h->sb_tcn && (H == 384 || H == 256)) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
         o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
         lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
-        o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
-        lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
-        for (int i = 0; i < 2 && h->KX == 40; ++i) {      // the bf16-ih variant is built for the default input width only
+        if (H == 384) {
+            o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
+            lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
+        }
+        for (int i = 0; i < 2 && h->KX == 40 && H == 384; ++i) {      // the bf16-ih variant is built for the default input width only
             const int nw = i == 0 ? 4 : 12;
             o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
             lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
@@ -1144,12 +1157,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
         }
     }
     size_t o_wpack_bf3 = 0;
-    if (!h->gru && !h->sb_tcn && h->KX == 40) {      // optional split-bf16 variant of the one-tile-per-CU kernel
+    if (!h->gru && !h->sb_tcn && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
         o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
         lstm_bf3_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_bf3);
     }
     size_t o_wpack_gru = 0;
-    if (h->gru && !h->sb_tcn) {
+    if (h->gru && !h->sb_tcn && H == 384) {
         o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
         gru_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_gru);
     }
@@ -1731,7 +1744,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_lstm_profile: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_lstm_profile: weights not committed"); return 2; }
     if (num_stamps != (int64_t)steps * 8) { set_error("fsnp_debug_lstm_profile: need steps*8 stamps"); return 2; }
-    if (h->gru || h->sb_tcn) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM)"); return 2; }
+    if (h->gru || h->sb_tcn || h->H != 384) { set_error("fsnp_debug_lstm_profile: row-tile kernel only (LSTM, hidden 384)"); return 2; }
     FSNP_ON_DEVICE(h);
     const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
@@ -1755,6 +1768,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || ih_bf16 < 0 || ih_bf16 > 2) { set_error("fsnp_set_precision: 0 (fp32), 1 (bf16 ih-GEMM) or 2 (split-bf16 emulation of fp32)"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
+    if (ih_bf16 && h->H != 384) { set_error("fsnp_set_precision: the bf16 variants exist for sb_model_hidden_size = 384 only"); return 2; }
     if (ih_bf16 && h->KX != 40) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 40 features only"); return 2; }
     h->ih_bf16 = ih_bf16;
     h->lw.ih_bf16 = ih_bf16 == 1 ? 1 : 0;       // (launch_lstm's own switch: the bf16-ih variant of lstm.hip)

@@ -564,15 +564,15 @@ void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0,
                 }
 }
 
-template <int EX, int NW, bool BF, int KX>
+template <int EX, int NW, bool BF, int KX, int HID = 384>
 static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    constexpr int HID = 384, OUT = 2;
+    constexpr int OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
                         (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4 + (BF ? (size_t)(HID / 16) * 64 * 16 : 0);
     LstmWeights wv = w;
     wv.wpack = BF ? (NW == 12 ? w.wpack_bf[1] : w.wpack_bf[0]) : (NW == 12 ? w.wpack12 : w.wpack);
-    if constexpr (KX == 40) {          // the phase-profile variant exists for the default input width only
+    if constexpr (KX == 40 && HID == 384) {          // the phase-profile variant exists for the default sizes only
         if (a.prof != nullptr) {
             auto kern = lstm2_fc_kernel<HID, KX, OUT, EX, true, NW, BF>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -601,6 +601,11 @@ void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     // measured (profiles/r01_lstm_phase_ab.md): with VALU rows the 12-wave shape is 10 % faster, without them
     // both shapes tie and the 4-wave one needs no spills
     const int waves = w.waves != 0 ? w.waves : (a.ex > 0 ? 12 : 4);
+    if (w.H == 256) {                  // sb_model_hidden_size = 256: 4 waves x 64 units, fp32, no VALU rows (planner: ex = 0)
+        if (w.KX == 64) launch_lstm_ex<0, 4, false, 64, 256>(w, a, s);
+        else launch_lstm_ex<0, 4, false, 40, 256>(w, a, s);
+        return;
+    }
     if (w.KX == 64) {                  // sub-band inputs of 41..64 features (fb_num_neighbors >= 2, ...): fp32 only
         if (waves == 12) launch_lstm_nw<12, false, 64>(w, a, s);
         else launch_lstm_nw<4, false, 64>(w, a, s);

@@ -853,7 +853,19 @@ static void launch_coop_units(const LstmWeights& w, const LstmArgs& a, hipStream
 }
 
 // sub-band model: H = 384, x gathered (or dense [seq][t][NIN]), fused Linear(384, 2); w.gru selects nn.GRU
+template <int HID>
+static void dispatch_lstm_coop_h(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {   // other hidden sizes: K = 40 / 64
+    if (w.KX == 64) {
+        if (w.gru) launch_coop_units<HID, 64, false, true>(w, a, s, occ);
+        else launch_coop_units<HID, 64, false, false>(w, a, s, occ);
+        return;
+    }
+    if (w.gru) launch_coop_units<HID, 40, false, true>(w, a, s, occ);
+    else launch_coop_units<HID, 40, false, false>(w, a, s, occ);
+}
 static void dispatch_lstm_coop(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
+    if (w.H == 256) { dispatch_lstm_coop_h<256>(w, a, s, occ); return; }      // sb_model_hidden_size 256 / 512
+    if (w.H == 512) { dispatch_lstm_coop_h<512>(w, a, s, occ); return; }
     if (w.KX == 64) {                  // sub-band inputs of 41..64 features
         if (w.gru) launch_coop_units<384, 64, false, true>(w, a, s, occ);
         else launch_coop_units<384, 64, false, false>(w, a, s, occ);

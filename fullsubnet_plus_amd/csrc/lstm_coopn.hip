@@ -371,9 +371,8 @@ int lstm_coopn_plan(int H, int row_tiles, int num_cus, int* groups) {
     return R;
 }
 
-template <int R, bool GRU, int KX>
+template <int R, bool GRU, int KX, int HID = 384>
 static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
-    constexpr int HID = 384;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coopn;
     if (occ) {        // do not launch: how many workgroups of this instantiation fit one CU at once
@@ -384,18 +383,25 @@ static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream
     hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(grid), dim3(256), 0, s, wv, a);
 }
 
-template <int KX>
+template <int KX, int HID = 384>
 static void launch_coopn_kx(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     if (w.gru) {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true, KX>(w, a, s, occ);
-        else launch_coopn_inst<2, true, KX>(w, a, s, occ);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, true, KX, HID>(w, a, s, occ);
+        else launch_coopn_inst<2, true, KX, HID>(w, a, s, occ);
     } else {
-        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false, KX>(w, a, s, occ);
-        else launch_coopn_inst<2, false, KX>(w, a, s, occ);
+        if (a.coop_rows_per_group == 1) launch_coopn_inst<1, false, KX, HID>(w, a, s, occ);
+        else launch_coopn_inst<2, false, KX, HID>(w, a, s, occ);
     }
+}
+template <int HID>
+static void launch_coopn_h(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
+    if (w.KX == 64) launch_coopn_kx<64, HID>(w, a, s, occ);
+    else launch_coopn_kx<40, HID>(w, a, s, occ);
 }
 
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (w.H == 256) { launch_coopn_h<256>(w, a, s, nullptr); return; }      // sb_model_hidden_size 256 / 512
+    if (w.H == 512) { launch_coopn_h<512>(w, a, s, nullptr); return; }
     if (w.KX == 64) launch_coopn_kx<64>(w, a, s, nullptr);       // sub-band inputs of 41..64 features
     else launch_coopn_kx<40>(w, a, s, nullptr);
 }
@@ -403,7 +409,9 @@ int lstm_coopn_occupancy(const LstmWeights& w, int rows_per_group) {
     LstmArgs a{};
     a.coop_rows_per_group = rows_per_group;
     int occ = 0;
-    if (w.KX == 64) launch_coopn_kx<64>(w, a, nullptr, &occ);
+    if (w.H == 256) launch_coopn_h<256>(w, a, nullptr, &occ);
+    else if (w.H == 512) launch_coopn_h<512>(w, a, nullptr, &occ);
+    else if (w.KX == 64) launch_coopn_kx<64>(w, a, nullptr, &occ);
     else launch_coopn_kx<40>(w, a, nullptr, &occ);
     return occ;
 }

@@ -82,9 +82,10 @@ typedef struct fsnp_config {
                                    (recurrent kernels are instantiated for K = 40 and K = 64 input columns) */
     int32_t tcn_hidden;         /* 512: TCNBlock hidden_channel (causal_conv.py:68) */
     int32_t num_tcn_blocks;     /* 8, dilations 1,2,5,9,1,2,5,9 (sequence_model.py:48-57) */
-    int32_t sb_hidden;          /* 384: sb_model_hidden_size.  ONLY 384 is built for the recurrent sub-band models (the MFMA tilings
-                                   of csrc/lstm*.hip are instantiated for it; anything else is rejected by fsnp_create, never
-                                   mis-computed).  Ignored for FSNP_SEQ_TCN. */
+    int32_t sb_hidden;          /* 384: sb_model_hidden_size.  256, 384 and 512 are built for the recurrent sub-band models (the MFMA
+                                   tilings of csrc/lstm*.hip are instantiated for them: 384 on every kernel, 256 on the column-split
+                                   kernels + the one-tile-per-CU LSTM kernel, 512 on the column-split kernels only; anything else
+                                   is rejected by fsnp_create, never mis-computed).  Ignored for FSNP_SEQ_TCN. */
     int32_t output_size;        /* 2 */
     int32_t norm_type;          /* FSNP_NORM_* */
     int32_t fb_act;             /* FSNP_ACT_* : fb_output_activate_function */

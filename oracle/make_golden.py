@@ -101,6 +101,11 @@ CASES = [
     dict(name="b3_t16_fbn2", wseed=31, profile="harsh", args={"fb_num_neighbors": 2}, inp=("spec", 3, 16, 31), stages=False),
     dict(name="gru_b1_t20_fbn3", wseed=32, profile="default", args={"fb_num_neighbors": 3, "sequence_model": "GRU"},
          inp=("spec", 1, 20, 32), stages=False),
+    # sb_model_hidden_size off its default (the H = 256 / 512 instantiations of the recurrent kernels)
+    dict(name="b3_t16_h256", wseed=33, profile="harsh", args={"sb_model_hidden_size": 256}, inp=("spec", 3, 16, 34), stages=False),
+    dict(name="b1_t20_h512", wseed=34, profile="default", args={"sb_model_hidden_size": 512}, inp=("spec", 1, 20, 35), stages=False),
+    dict(name="gru_b3_t16_h256", wseed=35, profile="default", args={"sb_model_hidden_size": 256, "sequence_model": "GRU"},
+         inp=("spec", 3, 16, 36), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -147,7 +152,8 @@ def run_case(case, FullSubNet_Plus):
     model = FullSubNet_Plus(**args).eval()
     sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"],
                          sequence_model=args["sequence_model"], fb_num_neighbors=args["fb_num_neighbors"],
-                         num_freqs=args["num_freqs"], sb_num_neighbors=args["sb_num_neighbors"], kersize=tuple(args["kersize"]))
+                         num_freqs=args["num_freqs"], sb_num_neighbors=args["sb_num_neighbors"], kersize=tuple(args["kersize"]),
+                         sb_hidden=args["sb_model_hidden_size"])
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]

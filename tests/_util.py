@@ -43,7 +43,8 @@ class Golden:
                                fb_num_neighbors=self.args.get("fb_num_neighbors", 0),
                                num_freqs=self.args.get("num_freqs", 257),
                                sb_num_neighbors=self.args.get("sb_num_neighbors", 15),
-                               kersize=tuple(self.args.get("kersize", (3, 5, 10))))
+                               kersize=tuple(self.args.get("kersize", (3, 5, 10))),
+                               sb_hidden=self.args.get("sb_model_hidden_size", 384))
 
     def inputs(self):
         inp = self.meta["inp"]

@@ -145,6 +145,31 @@ def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
         assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), skew)
 
 
+@pytest.mark.parametrize("seq", ["LSTM", "GRU"])
+@pytest.mark.parametrize("hidden", [256, 512])
+def test_other_hidden_sizes_on_every_kernel(hidden, seq):
+    """sb_model_hidden_size = 256 / 512 (fullsubnet_plus.py:25, sequence_model.py:31-46): the column-split kernels are
+    instantiated for both, the one-tile-per-CU LSTM kernel for 256; 70 sequences run K-split, 2100 the three-way split,
+    9000 a chip-filling round of the one-tile-per-CU kernel + remainder (LSTM, 256) or consecutive column-split launches."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": seq, "sb_model_hidden_size": hidden}
+    sd = make_state_dict(41, "harsh", sequence_model=seq, sb_hidden=hidden)
+    m = _model(args, sd)
+    for n, steps in ((70, 9), (2100, 5), (9000, 3)):
+        rng = np.random.Generator(np.random.PCG64(17 * n + hidden))
+        x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+        want = fsnp_torch.lstm2_fc(x, sd).numpy()
+        got = m.lstm2_fc(x.cuda()).cpu().numpy()
+        m.check_errors()
+        err = rel_err(got, want)
+        _record(f"hidden{hidden}_{seq}_{n}x{steps}", rel=err)
+        assert err < 2e-5, (n, err)
+        assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+    plan = [c["kernel"] for c in m.describe_plan(35)]       # 8995 sequences
+    assert any("one 32-row tile per CU" in k for k in plan) == (hidden == 256 and seq == "LSTM")
+    with pytest.raises(RuntimeError, match="384 only|LSTM sub-band model only"):
+        m.set_precision("bf16_ih")
+
+
 CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55]   # a table in which two workgroups per CU pay
 
 

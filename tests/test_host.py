@@ -43,7 +43,7 @@ def test_create_fails_loudly_without_gpu():
                                              ("sb_num_neighbors", -1, b"neighbors"), ("fb_num_neighbors", 6, b"64"),
                                              ("subband_num", 2, b"ECA"), ("subband_num", -1, b"subband_num"),
                                              ("num_groups_in_drop_band", 0, b"num_groups_in_drop_band"),
-                                             ("output_size", 3, b"output_size"), ("sb_hidden", 256, b"384"),
+                                             ("output_size", 3, b"output_size"), ("sb_hidden", 320, b"256, 384 or 512"),
                                              ("norm_type", 7, b"norm_type"), ("attention", 9, b"attention"),
                                              ("model", 5, b"model"), ("sequence_model", 3, b"sequence_model")])
 def test_create_validates_the_config_before_touching_the_device(field, value, msg):

@@ -23,8 +23,9 @@ def analyse(flags=("-fno-slp-vectorize",)):
     res = {}
     for m in re.finditer(r"^(_ZN4fsnp15lstm2_fc_kernelI\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
-        tag = re.search(r"Li384ELi(\d+)ELi2ELi(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
-        key = f"KX{tag.group(1)}_EX{tag.group(2)}_PROF{tag.group(3)}_NW{tag.group(4)}_BF{tag.group(5)}"
+        tag = re.search(r"Li(\d+)ELi(\d+)ELi2ELi(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
+        key = (f"H{tag.group(1)}_" if tag.group(1) != "384" else "") + \
+            f"KX{tag.group(2)}_EX{tag.group(3)}_PROF{tag.group(4)}_NW{tag.group(5)}_BF{tag.group(6)}"
         loops = []
         for i, l in enumerate(body):
             if "Inner Loop Header: Depth=2" not in l:
