@@ -222,6 +222,35 @@ def test_planner_cost_table_has_not_drifted_from_the_kernels():
     assert 0.7 * t2["rowtile_us"] < g2["rowtile_us"] < 1.3 * t2["rowtile_us"] and g2["rowtile_us"] < 0.85 * got["rowtile_us"]
 
 
+def test_measured_cost_table_can_be_adopted(tmp_path):
+    """FSNP_CALIBRATE=1 (fsnp.h): a handle adopts the cost table measured on the device at its first planning call.  Run in a
+    subprocess (the switch is read at fsnp_create): the table is flagged calibrated, the headline plan is unchanged and the
+    forward agrees with the default-table one."""
+    import subprocess
+    import sys
+    code = (
+        "import json, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fullsubnet_plus_amd import FullSubNet_Plus\n"
+        "from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_inputs, make_state_dict\n"
+        "m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS); m.load_state_dict(make_state_dict(0, 'default'), strict=True)\n"
+        "m = m.to('cuda').eval(); m.batch_mode = 'full'\n"
+        "out = m(*[t.cuda() for t in make_inputs(2, 0.5, 5)])\n"
+        "c = m.planner_costs()\n"
+        "print(json.dumps({'calibrated': c['calibrated'], 'rowtile': c['rowtile_us'], 'plan': [k['kernel'] for k in m.describe_plan(32)],\n"
+        "                  'sum': float(out.double().sum())}))\n" % ROOT)
+    res = {}
+    for cal in ("0", "1"):
+        env = dict(os.environ, FSNP_CALIBRATE=cal)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[cal] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert not res["0"]["calibrated"] and res["1"]["calibrated"]
+    assert 120.0 < res["1"]["rowtile"] < 320.0 and res["0"]["rowtile"] == 208.0
+    assert res["1"]["plan"][0].startswith("lstm2_fc") and res["0"]["plan"] == res["1"]["plan"]
+    assert abs(res["0"]["sum"] - res["1"]["sum"]) <= 1e-4 * abs(res["0"]["sum"])
+
+
 def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle():
     """B = 8 (65 row tiles -> lstm_coopn.hip, one row tile per group) through the whole forward, cumulative norm
     (per-row (m, d) tables) included."""
