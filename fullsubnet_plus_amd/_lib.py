@@ -48,9 +48,9 @@ SYMBOLS = {
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),
     "fsnp_get_timing": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 4), ctypes.POINTER(c_i64 * 4), c_i32]),
     "fsnp_describe_plan": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 18), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 20), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fsnp_debug_plan_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 18)]),
+    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 20)]),
     "fsnp_debug_set_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), c_i32]),
     "fsnp_debug_plan_rows2": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(c_i32), c_i32]),
@@ -75,7 +75,7 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 4          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 5          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

@@ -59,6 +59,7 @@ struct CostTable {
     double ksplit1[4];         // the same with ONE row tile (the exchange traffic, hence a step, grows with the tiles in flight)
     double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
+    double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
     int calibrated;
 };
 
@@ -100,6 +101,7 @@ struct fsnp_handle {
     int model = FSNP_MODEL_FULLSUBNET_PLUS;
     int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
     int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
+    bool lstm16_ok = false;      // the half-tile kernel (lstm16.hip) exists for this handle (LSTM, H = 384, K = 40) and is enabled
     bool rowtile_ok = true;      // a one-tile-per-CU kernel (lstm.hip / lstm_gru.hip) exists for this handle's sub-band model
     CostTable cost{};            // per-step costs the planner minimises (defaults, then measured on the device)
     int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (FSNP_COOP_OCC; 1 or 2) ...
@@ -386,7 +388,7 @@ static void launch_coop_chained(int dev, hipStream_t s, F launch) {
 // chunks of <= 170 tiles.  Every chunk owns a slice of the row descriptors / per-row norm tables (slot0) and, if it is
 // column-split, of the exchange images and barrier counters (coop_tile0).
 struct SbChunk {
-    int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn
+    int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn, 4 = half tile (lstm16.hip: 16-row tiles, rps = 16)
     int row0, nrows;           // sequences [row0, row0 + nrows)
     int num_tiles, ex, rps;    // tiles, VALU rows per tile, slots per tile (32 + ex)
     int units, groups, rpg;    // column-split parameters
@@ -410,7 +412,7 @@ static CostTable default_costs() {
     const double ks[4] = {14.4, 16.5, 26.0, 48.5}, k1[4] = {8.7, 14.0, 22.5, 42.0}, cn[2] = {78.0, 157.0};
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 208.0; t.rowtile_ex = 0.11;
+    t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 120.0;
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
@@ -428,6 +430,7 @@ static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
         return h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
     }
     if (c.kind == 2) return h->cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
+    if (c.kind == 4) return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile16;
     return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
@@ -494,7 +497,7 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
         c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind != 0) p.coop_tiles += c.num_tiles;
+        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2) p.coop_tiles += c.num_tiles;
         p.chunks.push_back(c);
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
@@ -527,6 +530,24 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
             }
         }
     }
+    // half tiles (lstm16.hip, LSTM at the default sizes, fp32): 16 CUs-worth of sequences per round in about half the time of a
+    // 32-row round - the cheapest shape between the column-split kernels' range and a chip-filling round (parity-mode B = 32:
+    // 4096 sequences = 256 half tiles, one launch), alone or as one full round + a column-split remainder
+    if (h->lstm16_ok && h->ih_bf16 == 0) {
+        const int per_round = h->num_cus * 16;
+        const SbChunk all16{4, 0, num_rows, cdiv(num_rows, 16), 0, 16, 0, 0, 0, 0, 0};
+        const double c_all = est_step_us(h, all16);
+        if (c_all < best_cost) { best = {all16}; best_cost = c_all; }
+        if (num_rows > per_round) {
+            std::vector<SbChunk> comp{SbChunk{4, 0, per_round, h->num_cus, 0, 16, 0, 0, 0, 0, 0}};
+            const std::vector<SbChunk> rc = plan_columns(h, per_round, num_rows - per_round);
+            if (!rc.empty()) {
+                comp.insert(comp.end(), rc.begin(), rc.end());
+                const double cc = cost_of(comp);
+                if (cc < best_cost) { best = comp; best_cost = cc; }
+            }
+        }
+    }
     for (const SbChunk& c : best) push(c);                     // empty = "this device cannot run the model"
     return p;
 }
@@ -550,6 +571,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             else launch_lstm(h->lw, ca, s);
             continue;
         }
+        if (c.kind == 4) { launch_lstm16(h->lw, ca, s); continue; }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
@@ -775,9 +797,9 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     }
     // one shape: returns its per-step cost in microseconds (< 0 on failure)
     auto time_shape = [&](SbChunk c) -> double {
-        c.row0 = 0; c.nrows = c.num_tiles * 32; c.slot0 = 0; c.coop_tile0 = 0;
+        c.row0 = 0; c.nrows = c.num_tiles * c.rps; c.slot0 = 0; c.coop_tile0 = 0;
         SbPlan plan;
-        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = c.kind != 0 ? c.num_tiles : 0;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2) ? c.num_tiles : 0;
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
@@ -820,6 +842,10 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         const double us0 = time_shape(SbChunk{0, 0, 0, h->num_cus_real, 0, 32, 0, 0, 0, 0, 0});
         if (us0 < 0) rc = 4;
         else t.rowtile = us0;           // the VALU-row surcharge keeps its measured ratio (0.11 per row)
+    }
+    if (rc == 0 && h->lstm16_ok) {
+        const double us16 = time_shape(SbChunk{4, 0, 0, h->num_cus_real, 0, 16, 0, 0, 0, 0, 0});
+        if (us16 < 0) rc = 4; else t.rowtile16 = us16;
     }
     cleanup();
 #undef FSNP_CAL_CHECK
@@ -911,6 +937,10 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     // one-tile-per-CU kernels: LSTM lstm.hip (H = 384, and 256 without VALU rows), GRU lstm_gru.hip (384); other sizes run on
     // the column-split kernels only
     h->rowtile_ok = cfg->sb_hidden == 384 || (cfg->sb_hidden == 256 && !h->gru);
+    {
+        const char* e16 = getenv("FSNP_LSTM16");           // 0 = never plan the half-tile kernel
+        h->lstm16_ok = !(e16 && e16[0] == '0') && !h->gru && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384 && nin <= 40;
+    }
     h->cost = default_costs();
     if (h->gru) h->cost.rowtile *= 0.75;   // three of the four gate tiles per k-group
     if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) {     // the table is measured at 384: scale by the work per step
@@ -1156,6 +1186,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
                                      blob.data() + o_wpack_bf[i]);
         }
     }
+    size_t o_wpack16 = 0;
+    if (h->lstm16_ok) {
+        o_wpack16 = alloc(lstm16_pack_floats(H, h->KX));
+        lstm16_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack16);
+    }
     size_t o_wpack_bf3 = 0;
     if (!h->gru && !h->sb_tcn && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
         o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
@@ -1230,6 +1265,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack_bf3 = d + o_wpack_bf3;
+    h->lw.wpack16 = d + o_wpack16;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
     if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
@@ -1420,9 +1456,10 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     // pipelined mode: column-split remainder chunks behind a row-tile chunk go to the side stream (after the row-tile
     // chunk: next to it they would only fight for its CUs), where they overlap the next forward's full-band stages
     int ndefer = 0;
-    if (h->pipeline && plan.chunks.size() > 1 && plan.chunks[0].kind == 0) {
+    auto fills_chip = [](const SbChunk& c) { return c.kind == 0 || c.kind == 4; };       // one (half) tile per CU, no exchange
+    if (h->pipeline && plan.chunks.size() > 1 && fills_chip(plan.chunks[0])) {
         ndefer = 1;
-        while (ndefer < (int)plan.chunks.size() && plan.chunks[ndefer].kind == 0) ++ndefer;
+        while (ndefer < (int)plan.chunks.size() && fills_chip(plan.chunks[ndefer])) ++ndefer;
         if (ndefer == (int)plan.chunks.size()) ndefer = 0;
     }
     if (ndefer == 0) {
@@ -1671,7 +1708,9 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
         for (int i = 0; i < 2; ++i) { h.cost.coopn[i][0] = costs[8 + 2 * i]; h.cost.coopn[i][1] = costs[9 + 2 * i]; }
         h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
         for (int i = 0; i < 4; ++i) h.cost.ksplit1[i] = costs[14 + i];
+        h.cost.rowtile16 = costs[18];
     }
+    h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
     if (gru == 2) h.cost.rowtile *= 0.75;
@@ -1687,18 +1726,19 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     return n;
 }
 
-int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, int32_t* occ) {
+int fsnp_get_costs(const fsnp_handle* h, double out[20], int32_t* calibrated, int32_t* occ) {
     if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
     for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
     out[12] = h->cost.rowtile; out[13] = h->cost.rowtile_ex;
     for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
+    out[18] = h->cost.rowtile16; out[19] = 0.0;
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
     return 0;
 }
 
-int fsnp_measure_costs(fsnp_handle* h, double out[18]) {
+int fsnp_measure_costs(fsnp_handle* h, double out[20]) {
     if (!h || !out) { set_error("fsnp_measure_costs: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_measure_costs: weights not committed"); return 2; }
     if (h->sb_tcn) { set_error("fsnp_measure_costs: the sub-band model of this handle is a TCN (no recurrent kernels)"); return 2; }
@@ -1707,7 +1747,7 @@ int fsnp_measure_costs(fsnp_handle* h, double out[18]) {
     if (calibrate_costs(h, false, &t)) return 4;
     for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
-    out[12] = t.rowtile; out[13] = t.rowtile_ex;
+    out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16; out[19] = 0.0;
     return 0;
 }
 
@@ -1720,6 +1760,7 @@ int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups
         for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] = costs[8 + 2 * i]; h->cost.coopn[i][1] = costs[9 + 2 * i]; }
         h->cost.rowtile = costs[12]; h->cost.rowtile_ex = costs[13];
         for (int i = 0; i < 4; ++i) h->cost.ksplit1[i] = costs[14 + i];
+        h->cost.rowtile16 = costs[18];
     }
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
@@ -1733,7 +1774,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind; out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
+        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind;       // (4 = half-tile kernel) out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
     return n;

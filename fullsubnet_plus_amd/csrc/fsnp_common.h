@@ -149,6 +149,7 @@ struct LstmWeights {
     int ih_bf16;                // 1 = use them; 2 = the split-bf16 variant (wpack_bf3, lstm_bf3.hip)
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
+    const float* wpack16;       // half-tile kernel (lstm16.hip): [wave][k-group of 16][24 tiles of 16 columns][lane][4]
     const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
@@ -197,6 +198,10 @@ struct LstmArgs {
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
 LstmPlan plan_lstm_tiles(int num_rows, int num_cus);
 void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+// lstm16.hip: the same decomposition on 16-row tiles (v_mfma_f32_16x16x4_f32): 4096 sequences per round of 256 workgroups
+void launch_lstm16(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+size_t lstm16_pack_floats(int H, int KX);
+void lstm16_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack);
 // lstm_bf3.hip: the same decomposition with every fp32 product emulated by three bf16 MFMAs (optional precision mode 2)
 void launch_lstm_bf3(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_bf3_pack_floats(int H, int KX, int NW);

@@ -455,33 +455,34 @@ class _HipModel(nn.Module):
             raise RuntimeError(_lib.last_error())
         names = {0: ("gru2_fc_kernel" if self.sequence_model == "GRU" else "lstm2_fc_kernel") + " (one 32-row tile per CU)",
                  1: "lstm2_coop_kernel (K split)",
-                 2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN"}
+                 2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
+                 4: "lstm2_fc16_kernel (one 16-row tile per CU)"}
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
-        """Test hook: pin the planner's cost table (18 values, fsnp_get_costs order; None = built-in) and whether it may put
+        """Test hook: pin the planner's cost table (20 values, fsnp_get_costs order; None = built-in) and whether it may put
         two column-split workgroups on a CU (fsnp_debug_set_costs)."""
         lib = self._ensure_handle(_resolve_device(device))
-        arr = (ctypes.c_double * 18)(*costs) if costs is not None else None
+        arr = (ctypes.c_double * 20)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
     @staticmethod
     def _cost_dict(v):
         return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
-                "rowtile_us": v[12], "valu_row_surcharge": v[13]}
+                "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18]}
 
     def measure_costs(self):
         """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""
-        buf = (ctypes.c_double * 18)()
+        buf = (ctypes.c_double * 20)()
         with torch.cuda.device(self._hip.device):
             _lib.check(_lib.load().fsnp_measure_costs(self._handle, ctypes.byref(buf)), "fsnp_measure_costs")
         return self._cost_dict(list(buf))
 
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
-        buf, cal, occ = (ctypes.c_double * 18)(), ctypes.c_int32(), ctypes.c_int32()
+        buf, cal, occ = (ctypes.c_double * 20)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
         return {**self._cost_dict(list(buf)), "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 

@@ -194,7 +194,8 @@ int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t n
 int fsnp_set_timing(fsnp_handle* h, int32_t enable);
 int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
- * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN),
+ * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
+ *  half-tile: 16-row tiles, csrc/lstm16.hip),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
@@ -210,8 +211,8 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
  * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
  * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
  * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
-int fsnp_get_costs(const fsnp_handle* h, double out[18], int32_t* calibrated, int32_t* occ);
-int fsnp_measure_costs(fsnp_handle* h, double out[18]);
+int fsnp_get_costs(const fsnp_handle* h, double out[20], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel */
+int fsnp_measure_costs(fsnp_handle* h, double out[20]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
  * (kernel 1) or groups (kernel 2), row tiles per group, first slot}.  Used by the CPU tests. */
@@ -313,7 +314,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 4
+#define FSNP_ABI_VERSION 5
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

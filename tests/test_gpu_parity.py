@@ -170,7 +170,40 @@ def test_other_hidden_sizes_on_every_kernel(hidden, seq):
         m.set_precision("bf16_ih")
 
 
-CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55]   # a table in which two workgroups per CU pay
+@pytest.mark.parametrize("n,steps", [(16, 3), (3855, 6), (4096, 9), (4112, 5), (4500, 4)])
+def test_half_tile_kernel(n, steps):
+    """csrc/lstm16.hip: the one-tile-per-CU decomposition on 16-row tiles (v_mfma_f32_16x16x4_f32), planned where one round of
+    256 half tiles beats the column-split launches (3700...4096 sequences, e.g. the reference's literal drop-band call at
+    B = 32: 4096 sequences) and as a full round + column-split remainder just above; ragged last tile, 16 sequences alone
+    (forced through the cost table)."""
+    sd = make_state_dict(12, "harsh")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    rng = np.random.Generator(np.random.PCG64(1000 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    m.lstm2_fc(x[:1].cuda())
+    if n < 3000:                                   # make the half-tile kernel the cheapest shape for any size
+        m.debug_set_costs([900] * 8 + [900] * 4 + [900, 0.11] + [900] * 4 + [10, 0], 1)
+    plan = m.describe_plan(1)                      # (the plan of lstm2_fc depends on n, not on this)
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    err = rel_err(got, want)
+    _record(f"lstm16_{n}x{steps}", rel=err)
+    assert err < 2e-5, err
+    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+    m.debug_set_lstm_coop(0)
+    assert rel_err(m.lstm2_fc(x.cuda()).cpu().numpy(), got) < 1e-5      # the 32-row kernel: same rows, other summation order
+    del plan
+
+
+def test_parity_b32_runs_on_half_tiles(b32):
+    sd, (mag, real, imag), m, full = b32
+    m.batch_mode = "parity"
+    plan = m.describe_plan(32, parity=True)
+    m.batch_mode = "full"
+    assert plan[0]["kernel"].startswith("lstm2_fc16_kernel") and plan[0]["sequences"] == 4096 and len(plan) == 1
+
+
+CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000, 0]   # a table in which two workgroups per CU pay
 
 
 @pytest.mark.parametrize("n,steps", [(257, 40), (514, 20), (1285, 12), (2700, 9), (4112, 7), (5440, 6), (8000, 5), (10870, 4)])

@@ -365,9 +365,12 @@ def test_subband_plans_cover_every_sequence_and_fit_the_chip(rows, gru):
     for c in chunks:
         assert c["row0"] == nxt and c["slot0"] == slot and c["rows"] > 0
         nxt += c["rows"]
-        slot += c["tiles"] * (32 + c["ex"])
-        assert c["tiles"] * (32 + c["ex"]) >= c["rows"]
-        if c["kind"] == 1:
+        per_tile = 16 if c["kind"] == 4 else 32 + c["ex"]             # kind 4 = half tiles (csrc/lstm16.hip)
+        slot += c["tiles"] * per_tile
+        assert c["tiles"] * per_tile >= c["rows"]
+        if c["kind"] == 4:
+            assert not gru and c["ex"] == 0
+        elif c["kind"] == 1:
             assert c["par"] in (8, 16, 32, 64) and c["tiles"] * (384 // c["par"]) <= 256
         elif c["kind"] == 2:
             assert c["rpg"] in (1, 2) and c["par"] * 3 <= 256 and c["par"] * c["rpg"] >= c["tiles"]
@@ -385,10 +388,13 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(257) == [(1, 257)] and _plan(257)[0]["par"] == 16                 # B = 1: K split, 16 units
     assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
     assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
-    p = _plan(4096)                                                                 # parity-mode B = 32: 128 tiles = one per group
-    assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # + 42 + a few (76 + 55 + 9 us)
+    assert kinds(4096) == [(4, 4096)] and _plan(4096)[0]["tiles"] == 256            # parity-mode B = 32: one round of 256 half tiles
+    assert kinds(4112) == [(4, 4096), (1, 16)]                                      # B = 16: a half-tile round + 16 sequences K split
+    p = _plan(4096, gru=1)                                                          # GRU has no half-tile kernel: 128 tiles = one per
+    assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # group + 42 + 1
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert seq(4256) == [2, 1, 1]                                                   # 133 tiles: 85 + 42 + 6 (78 + 48.5 + ~15 us < 157)
+    assert kinds(3500)[0][0] == 2 and kinds(3855) == [(4, 3855)]                    # the half tiles pay from ~115 row tiles up
+    assert seq(4256) == [4, 1]                                                      # 133 tiles: half-tile round + 5 tiles K split
     assert kinds(5397) == [(2, 5397)] and _plan(5397)[0]["rpg"] == 2                # B = 21, 169 tiles: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
@@ -404,7 +410,7 @@ def test_subband_plan_choices_match_the_design():
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
     p = _plan(3084)                                                                 # B = 12: 97 tiles = one per group + the rest K split
     assert [c["kind"] for c in p] == [2, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 32 and sum(c["rows"] for c in p) == 3084
-    assert seq(4112) == [2, 1, 1]                                                   # B = 16: 129 tiles = 85 + 42 + 2
+    assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2
     p = _plan(1376)                                                                 # 43 tiles: a full K-split launch + a tiny one
     assert [c["kind"] for c in p] == [1, 1] and p[0]["par"] == 64 and p[1]["par"] == 8 and sum(c["rows"] for c in p) == 1376
 
@@ -419,13 +425,13 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
 
     def plan(rows, occ, costs=None, gru=0):
         buf = (ct.c_int32 * (8 * 64))()
-        arr = (ct.c_double * 18)(*costs) if costs else None
+        arr = (ct.c_double * 20)(*costs) if costs else None
         n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
         assert n > 0, lib.fsnp_last_error()
         keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
         return [dict(zip(keys, buf[8 * i:8 * i + 8])) for i in range(n)]
 
-    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55]
+    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000, 0]
     p = plan(257, 2, cheap2)
     assert len(p) == 1 and p[0]["kind"] == 1 and p[0]["par"] == 8 and 9 * 48 <= 512
     p = plan(4112, 2, cheap2)                    # 129 tiles
@@ -437,7 +443,7 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
             for c in plan(rows, 2, cheap2, gru):
                 wgs = c["tiles"] * (384 // c["par"]) if c["kind"] == 1 else c["par"] * 3 if c["kind"] == 2 else 0
                 assert wgs <= 512 and (c["kind"] != 2 or c["par"] * c["rpg"] >= c["tiles"])
-    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100]      # K split suddenly slow: 9 tiles move
+    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100, 1000, 0]      # K split suddenly slow: 9 tiles move
     p = plan(257, 1, slow_k)
     assert p[0]["kind"] == 2
 
