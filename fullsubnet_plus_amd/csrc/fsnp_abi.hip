@@ -1774,7 +1774,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind;       // (4 = half-tile kernel) out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
+        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind; out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;   // (kind 4 = half-tile kernel)
         ++n;
     }
     return n;

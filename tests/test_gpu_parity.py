@@ -200,7 +200,7 @@ def test_parity_b32_runs_on_half_tiles(b32):
     m.batch_mode = "parity"
     plan = m.describe_plan(32, parity=True)
     m.batch_mode = "full"
-    assert plan[0]["kernel"].startswith("lstm2_fc16_kernel") and plan[0]["sequences"] == 4096 and len(plan) == 1
+    assert plan[0]["kernel"].startswith("lstm2_fc16_kernel") and plan[0]["sequences"] == 4096 and len(plan) == 1, plan
 
 
 CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000, 0]   # a table in which two workgroups per CU pay
