@@ -412,7 +412,7 @@ static CostTable default_costs() {
     const double ks[4] = {14.4, 16.5, 26.0, 48.5}, k1[4] = {8.7, 14.0, 22.5, 42.0}, cn[2] = {78.0, 157.0};
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 120.0;
+    t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 108.0;
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }

@@ -42,13 +42,19 @@ __device__ __forceinline__ void groups16(f32x4 (&acc)[NT], float4 (&b)[NT], cons
     float4 a = A[0];
     for (int g = 0; g < ngroups; ++g) {
         const float4 an = A[(g + 1 < ngroups ? g + 1 : g) * 64];
+        // two tiles at a time with their MFMAs interleaved, so no MFMA reads the accumulator the one before it wrote
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int n = 0; n < NT; n += 2) {
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[n].x, acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[n + 1].x, acc[n + 1], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[n].y, acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[n + 1].y, acc[n + 1], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[n].z, acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[n + 1].z, acc[n + 1], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[n].w, acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[n + 1].w, acc[n + 1], 0, 0, 0);
             b[n] = w16load<NT>(ws, gnext, n);
+            b[n + 1] = w16load<NT>(ws, gnext, n + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
@@ -200,7 +206,11 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[n][r] = bias_l0[n * 16];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
         groups16<NT>(acc, breg, Xs + lane, KGX, ws, gnext, KGT);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
         groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
         cell16<SB, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
@@ -215,7 +225,12 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[n][r] = bias_l1[n * 16];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));   // pin the tiles to AGPRs: left alone, hipcc moves them to VGPRs and back
+                                                                        // inside one of the k-loops (124 v_accvgpr moves per k-group)
         groups16<NT>(acc, breg, H1s + lane, KGH, ws, gnext, KGT);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
         groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
         cell16<SB, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);

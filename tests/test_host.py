@@ -223,6 +223,22 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
                 assert l["drain"] == 0, (key, l)
 
 
+def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
+    """lstm2_fc16_kernel (csrc/lstm16.hip): every k-group loop is 96 MFMAs + 24 weight loads, no scratch, no drain and no
+    AGPR<->VGPR shuttling of the 24 accumulator tiles (the asm pins in the kernel exist for exactly that)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_half_tile()
+    assert len(res) >= 1
+    for key, loops in res.items():
+        assert len(loops) >= 3, (key, loops)
+        for l in loops:
+            assert l["mfma"] == 96 and l["gload"] == 24, (key, l)
+            assert l["scratch"] == 0 and l["drain"] == 0 and l["acc_moves"] == 0, (key, l)
+
+
 # ---------------------------------------------------------------- cooperative kernel weight stream (csrc/lstm_coop.hip)
 @pytest.mark.parametrize("H,NIN,KX,units", [(384, 34, 40, 8), (384, 34, 40, 16), (384, 32, 40, 32), (384, 34, 40, 64),
                                             (512, 257, 264, 8), (512, 257, 264, 32)])
@@ -393,9 +409,10 @@ def test_subband_plan_choices_match_the_design():
     p = _plan(4096, gru=1)                                                          # GRU has no half-tile kernel: 128 tiles = one per
     assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # group + 42 + 1
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert kinds(3500)[0][0] == 2 and kinds(3855) == [(4, 3855)]                    # the half tiles pay from ~115 row tiles up
+    assert kinds(3200)[0][0] == 2 and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~107 row tiles up
     assert seq(4256) == [4, 1]                                                      # 133 tiles: half-tile round + 5 tiles K split
-    assert kinds(5397) == [(2, 5397)] and _plan(5397)[0]["rpg"] == 2                # B = 21, 169 tiles: two per group
+    assert kinds(5397) == [(4, 4096), (1, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles K split
+    assert kinds(5397, gru=1) == [(2, 5397)] and _plan(5397, gru=1)[0]["rpg"] == 2  # (108 + 48.5 us against 157 for two per group); GRU: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles

@@ -68,7 +68,41 @@ def analyse_column_split(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_half_tile(flags=("-fno-slp-vectorize",)):
+    """k-group loops of lstm2_fc16_kernel (lstm16.hip): MFMAs, weight loads, scratch, drains and AGPR<->VGPR moves per loop
+    (hipcc once shuttled the 24 accumulator tiles through VGPRs inside one of the loops: 124 moves per k-group)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "lstm16.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp17lstm2_fc16_kernelI\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        loops = []
+        for i, l in enumerate(body):
+            if "Inner Loop Header: Depth=2" not in l:
+                continue
+            lab = None
+            for k in range(i, max(i - 4, 0), -1):
+                mm = re.match(r"^(\.LBB\d+_\d+):", body[k])
+                if mm:
+                    lab = mm.group(1)
+                    break
+            end = next(k for k in range(i, len(body)) if re.search(r"s_cbranch_\w+ " + re.escape(lab) + r"\b", body[k]))
+            seg = body[i:end]
+            cnt = lambda pat: sum(1 for x in seg if re.search(pat, x))
+            loops.append(dict(mfma=cnt(r"v_mfma"), scratch=cnt(r"scratch_"), drain=cnt(r"vmcnt\(0\)"),
+                              gload=cnt(r"buffer_load_dwordx4"), acc_moves=cnt(r"v_accvgpr"), lines=len(seg)))
+        res[name] = [l for l in loops if l["mfma"] > 0]
+    return res
+
+
 if __name__ == "__main__":
+    for k, loops in analyse_half_tile().items():
+        for l in loops:
+            print(k, l)
     r = analyse()
     bad = 0
     for k in sorted(r):
