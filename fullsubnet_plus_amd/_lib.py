@@ -65,6 +65,7 @@ SYMBOLS = {
     "fsnp_abi_version": (c_i32, []),
     "fsnp_config_size": (c_i32, []),
     "fsnp_debug_set_lstm_coop": (c_i32, [c_vp, c_i32]),
+    "fsnp_debug_set_gemm_dma": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_graph": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_inject_error": (c_i32, [c_vp]),
     "fsnp_debug_set_lstm_waves": (c_i32, [c_vp, c_i32]),
@@ -75,7 +76,7 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 5          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 6          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

@@ -155,6 +155,7 @@ struct fsnp_handle {
     // `side_stream`, so that they overlap the full-band stages of the NEXT forward (which leave most CUs idle); the
     // workspace is double buffered because forward i+1 rebuilds att / fb while the remainder of forward i still reads them
     int pipeline = 0;
+    int defer_small = 1;         // pipelined mode: plans that start with a column-split launch run on the side stream whole (FSNP_DEFER_SMALL=0: off)
     int ws_slots = 1, ws_slot = 0;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
@@ -576,6 +577,11 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
         ca.coop_skew = h->coop_skew;
+        // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
+        // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
+        // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)
+        static const int own_cu = [] { const char* e = getenv("FSNP_OWN_CU"); return e && e[0] == '0' ? 0 : 1; }();
+        ca.coop_own_cu = (own_cu && h->side_stream && s == h->side_stream) ? 160 * 1024 - 256 : 0;
         ca.coop_err = h->d_err;
         ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
@@ -969,6 +975,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
+    const char* dsm = getenv("FSNP_DEFER_SMALL");
+    if (dsm && dsm[0] == '0') h->defer_small = 0;
     const char* sk = getenv("FSNP_COOP_SKEW");
     if (sk && sk[0] == '0') h->coop_skew = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&h->d_err), 256, hipHostMallocMapped) != hipSuccess) {
@@ -1083,7 +1091,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     // ---- TCN stacks (SequenceModel(sequence_model="TCN"), sequence_model.py:47-58,80-81): zero-padded row-major
     // [N pad 384][K pad 16] GEMM operands, [model][block] major.  `cin` channels in / out of every TCNBlock, `fc_out` rows of
     // the final Linear(cin, fc_out).  Used for the three full-band models and for a sub-band TCN.
-    struct TcnOff { size_t w1, b1, a1, g1w, g1b, dw, db, a2, g2w, g2b, w2, b2, wf, bf; int NB, N1P, K1P, N2P, K2P; };
+    struct TcnOff { size_t w1, b1, a1, g1w, g1b, dw, db, a2, g2w, g2b, w2, b2, w2g, c1, c2, wf, bf; int NB, N1P, K1P, N2P, K2P; };
     auto pack_tcn = [&](const std::vector<std::string>& models, int nb, int cin, int fc_out) {
         TcnOff t{};
         const size_t nm = models.size() ? models.size() : 1;
@@ -1093,6 +1101,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         t.dw = alloc(nm * nb * 3 * CH); t.db = alloc(nm * nb * CH); t.a2 = alloc(nm * nb + 1);
         t.g2w = alloc(nm * nb * CH); t.g2b = alloc(nm * nb * CH);
         t.w2 = alloc(nm * nb * t.N2P * t.K2P); t.b2 = alloc(nm * nb * t.N2P);
+        t.w2g = alloc(nm * nb * t.N2P * t.K2P); t.c1 = alloc(nm * nb * t.N2P); t.c2 = alloc(nm * nb * t.N2P);
         t.wf = alloc(nm * t.N2P * t.K1P); t.bf = alloc(nm * t.N2P);
         for (size_t b = 0; b < models.size(); ++b) {
             for (int i = 0; i < nb; ++i) {
@@ -1116,6 +1125,22 @@ int fsnp_commit_weights(fsnp_handle* h) {
                 for (int n = 0; n < cin; ++n)
                     for (int k = 0; k < CH; ++k) blob[t.w2 + (bi * t.N2P + n) * t.K2P + k] = w2[(size_t)n * CH + k];
                 std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + t.b2 + bi * t.N2P);
+                // GroupNorm 2 folded into the sconv GEMM (tcn.hip tcn_gemm_dma_kernel): weights times gamma, and the two
+                // per-output constants of  sum_k ((a - m) r g_k + b_k) W[n][k] = r sum_k a g_k W[n][k] + c1[n] - r m c2[n]
+                const auto& g2 = W(p + ".norm2.weight");
+                const auto& be2 = W(p + ".norm2.bias");
+                const auto& sb2 = W(p + ".sconv.bias");
+                for (int n = 0; n < cin; ++n) {
+                    double s1 = sb2[n], s2 = 0.0;
+                    for (int k = 0; k < CH; ++k) {
+                        const double wv = w2[(size_t)n * CH + k];
+                        blob[t.w2g + (bi * t.N2P + n) * t.K2P + k] = (float)(wv * (double)g2[k]);
+                        s1 += (double)be2[k] * wv;
+                        s2 += (double)g2[k] * wv;
+                    }
+                    blob[t.c1 + bi * t.N2P + n] = (float)s1;
+                    blob[t.c2 + bi * t.N2P + n] = (float)s2;
+                }
             }
             const auto& wf = W(models[b] + ".fc_output_layer.weight");   // [fc_out][cin]: top rows of a zero-padded [N2P][K1P]
             for (int n = 0; n < fc_out; ++n)
@@ -1129,8 +1154,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
         t.w1 = d + o.w1; t.b1 = d + o.b1; t.a1 = d + o.a1; t.g1w = d + o.g1w; t.g1b = d + o.g1b;
         t.dw = d + o.dw; t.db = d + o.db; t.a2 = d + o.a2; t.g2w = d + o.g2w; t.g2b = d + o.g2b;
         t.w2 = d + o.w2; t.b2 = d + o.b2; t.wf = d + o.wf; t.bf = d + o.bf;
+        t.w2g = d + o.w2g; t.c1 = d + o.c1; t.c2 = d + o.c2;
         t.num_cus = h->num_cus; t.NB = o.NB; t.N1P = o.N1P; t.K1P = o.K1P; t.N2P = o.N2P; t.K2P = o.K2P;
         for (int i = 0; i < o.NB; ++i) t.dilation[i] = kDilations[i];
+        const char* de = getenv("FSNP_GEMM_DMA");          // 0 = the general GEMM kernel everywhere (tuning / A-B)
+        t.gemm_dma = de && de[0] == '0' ? 0 : 1;
     };
     std::vector<std::string> fb_models;
     for (int b = 0; b < nbr_w; ++b) fb_models.push_back(kFb[b]);
@@ -1455,14 +1483,26 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     unsigned* abort_word = reinterpret_cast<unsigned*>(base + w.coop_abort);
     // pipelined mode: column-split remainder chunks behind a row-tile chunk go to the side stream (after the row-tile
     // chunk: next to it they would only fight for its CUs), where they overlap the next forward's full-band stages
+    // A plan that STARTS with a column-split launch (small batches) goes to the side stream whole: those launches leave CUs
+    // idle too (B = 1: 216 of 256 busy, latency-bound), and the next forward's full-band stages fit beside them.
     int ndefer = 0;
+    bool defer_all = false;
     auto fills_chip = [](const SbChunk& c) { return c.kind == 0 || c.kind == 4; };       // one (half) tile per CU, no exchange
     if (h->pipeline && plan.chunks.size() > 1 && fills_chip(plan.chunks[0])) {
         ndefer = 1;
         while (ndefer < (int)plan.chunks.size() && fills_chip(plan.chunks[ndefer])) ++ndefer;
         if (ndefer == (int)plan.chunks.size()) ndefer = 0;
+    } else if (h->pipeline && h->defer_small && !fills_chip(plan.chunks[0])) {
+        defer_all = true;
     }
-    if (ndefer == 0) {
+    if (defer_all) {
+        FSNP_HIP_CHECK(hipEventRecord(h->ev_main, s));
+        FSNP_HIP_CHECK(hipStreamWaitEvent(h->side_stream, h->ev_main, 0));
+        launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, h->side_stream, h->timing ? rec.e[3] : nullptr);
+        if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], h->side_stream));
+        FSNP_HIP_CHECK(hipEventRecord(h->ev_side[slot], h->side_stream));
+        h->side_used[slot] = true;
+    } else if (ndefer == 0) {
         launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, s, h->timing ? rec.e[3] : nullptr);
         if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
     } else {
@@ -1888,6 +1928,13 @@ int fsnp_debug_inject_error(fsnp_handle* h) {
 int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_graph: mode must be 0 (plain launches), 1 or 2 (hipGraph replay)"); return 1; }
     h->use_graph = mode;
+    return 0;
+}
+
+int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel) or 1 (DMA kernel where it applies)"); return 1; }
+    h->tw.gemm_dma = mode;
+    drop_graphs(h);          // a captured full-band chain holds the other kernels
     return 0;
 }
 

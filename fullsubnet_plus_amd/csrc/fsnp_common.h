@@ -81,11 +81,15 @@ struct TcnWeights {
     const float* g2b;    // [3][NB][CH]
     const float* w2;     // [3][NB][N2P][K2P]  sconv  (N2P = F padded to 64, K2P = CH padded to 16)
     const float* b2;     // [3][NB][N2P]
+    const float* w2g;    // [3][NB][N2P][K2P]  sconv weights times norm2.weight[k]  (GroupNorm folded: tcn_gemm_dma_kernel)
+    const float* c1;     // [3][NB][N2P]       sconv.bias[n] + sum_k norm2.bias[k] W2[n][k]
+    const float* c2;     // [3][NB][N2P]       sum_k norm2.weight[k] W2[n][k]
     const float* wf;     // [3][N2P][K1P]      fc_output_layer
     const float* bf;     // [3][N2P]
     int NB, N1P, K1P, N2P, K2P;
     int num_cus;         // for the per-launch column-tile choice (N1P, N2P are multiples of 384: any BN fits)
     int dilation[16];
+    int gemm_dma;        // 1 = the full-band GEMMs run on tcn_gemm_dma_kernel where its requirements hold (fsnp_debug_set_gemm_dma)
 };
 
 struct TcnBuffers {
@@ -191,6 +195,8 @@ struct LstmArgs {
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
     int coop_xcd;              // > 0 = CUs per XCD: place the workgroups that share a row tile on one XCD (lstm_common.h)
+    int coop_own_cu;           // lstm_coop.hip: > 0 = claim this many bytes of dynamic LDS (the whole CU's) so that no workgroup of a
+                               // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
     int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2
 };

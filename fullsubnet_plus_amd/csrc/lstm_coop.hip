@@ -801,18 +801,22 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles) {
     return (size_t)row_tiles * (size_t)coop_tile_f4(H) * 16;
 }
 
+// dynamic LDS a launch may claim to keep a CU to itself (LstmArgs::coop_own_cu): 160 KiB per CU minus the static __shared__ words
+constexpr size_t kOwnCuLds = 160 * 1024 - 256;
+
 // occ != nullptr: do not launch; report how many workgroups of this instantiation fit one CU at once
 template <int HID, int KX, int UNITS, bool SEQ, bool GRU>
 static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     constexpr int S = HID / UNITS, NT = UNITS / 8;
-    const size_t smem = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
+    const size_t smem_need = (size_t)coop_kgxp(KX) * 64 * 16 + (size_t)4 * NT * 16 * 64 * 4 + 32 * sizeof(RowDesc);
     auto kern = lstm2_coop_kernel<HID, KX, UNITS, SEQ, GRU>;
     static PerDeviceOnce attr_once;            // the attribute is per device: one process may drive several GPUs
-    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds); });
     if (occ) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess) *occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, reinterpret_cast<const void*>(kern), 256, smem_need) != hipSuccess) *occ = 0;
         return;
     }
+    const size_t smem = a.coop_own_cu > 0 && (size_t)a.coop_own_cu > smem_need ? (size_t)a.coop_own_cu : smem_need;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
     const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(S, a.num_tiles, a.coop_xcd) : a.num_tiles * S;
@@ -823,7 +827,7 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
         if (a.coop_skew && UNITS >= 16) {
             auto skew = lstm2_coop_skew_kernel<HID, KX, UNITS, GRU>;
             static PerDeviceOnce skew_once;
-            skew_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+            skew_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds); });
             hipLaunchKernelGGL(skew, dim3(grid), dim3(256), smem, s, wv, a);
             return;
         }

@@ -380,7 +380,18 @@ static void launch_coopn_inst(const LstmWeights& w, const LstmArgs& a, hipStream
         return;
     }
     const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(HID / 128, a.coop_groups, a.coop_xcd) : a.coop_groups * (HID / 128);
-    hipLaunchKernelGGL((lstm2_coopn_kernel<HID, KX, R, GRU>), dim3(grid), dim3(256), 0, s, wv, a);
+    // LstmArgs::coop_own_cu: claim the rest of the CU's LDS as (unused) dynamic LDS so that no LDS-using workgroup of a
+    // concurrent kernel shares the CU (pipelined loop: the next forward's full-band GEMMs)
+    auto kern = lstm2_coopn_kernel<HID, KX, R, GRU>;
+    static PerDeviceOnce attr_once;
+    static int static_lds = 0;
+    attr_once.run([&] {
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess) static_lds = (int)fa.sharedSizeBytes;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds);
+    });
+    const int pad = a.coop_own_cu > 0 ? a.coop_own_cu - static_lds : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pad > 0 ? pad : 0, s, wv, a);
 }
 
 template <int KX, int HID = 384>

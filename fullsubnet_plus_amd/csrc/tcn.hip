@@ -13,6 +13,7 @@
 // fp64 slot with one atomic pair per workgroup (row tiles never straddle utterances); the consuming
 // kernel applies the per-utterance scalars + per-channel affine while it loads its operand, so no
 // normalised tensor is ever written.
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 
@@ -41,6 +42,7 @@ struct GemmArgs {
     double gn_count;                           // elements per GroupNorm plane (PRO_GN)
     float gn_eps;
     int ntiles_n, row_tiles, row_tiles_all;    // launch geometry: column tiles, row tiles per branch, row tiles of all branches
+    const float* c2; long c2_bs;               // tcn_gemm_dma_kernel<EPI_RESIDUAL>: [branch][Npad] sum_k gamma_k W[n][k] (GroupNorm folded)
 };
 
 // XCD-aware workgroup order (cdna_hip_programming.md T1).  The dispatcher places workgroup id L on XCD L % 8, and every XCD
@@ -272,6 +274,184 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tcn_gemm_dma_kernel: the two GEMMs of a TCNBlock with the k-loop stripped to what the matrix pipe needs.
+// tcn_gemm_kernel above issues ~200 VALU/SALU instructions per 16 MFMAs (bounds checks, the GroupNorm prologue, the
+// fragment-order shuffle, LDS stores): on this chip they do not overlap a wave's fp32 MFMAs, so it ran at 45 % of the
+// matrix pipe (profiles/r02_tcn_gemm.md).  Here
+//  * operands go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, no VALU): three
+//    16-byte pieces per lane and k-tile with loop-invariant per-lane offsets and the k position in the scalar offset;
+//    rows beyond the plane and k beyond the row are out of the descriptor's range (-> zeros), so there are no bounds checks;
+//  * the LDS image is plain row-major [row][16 k], XOR-swizzled on BOTH sides (the DMA destination is lane-linear: lane l of a
+//    piece fetches the k-quad that belongs in slot l; readers apply the same involution): ds_read_b128 is conflict-free;
+//  * a lane's float4 is 4 consecutive k, i.e. MFMA j multiplies k = k0 + 8 kg + j (lanes 0-31) and + 4 (lanes 32-63) - a
+//    permutation of the 16 k of the tile that A and B share, so no fragment shuffle is needed;
+//  * GroupNorm on the sconv operand is folded out of the loop: sum_k ((a - m) r g_k + b_k) W[n][k] =
+//    r (sum_k a g_k W[n][k]) + c1[n] - r m c2[n] with W pre-scaled by gamma and c1 = bias + sum_k b_k W, c2 = sum_k g_k W
+//    packed at fsnp_create (fp64 sums); m, r are per-plane scalars and a row tile never straddles planes.
+// Requirements (checked by launch_gemm_dma, else the general kernel runs): lda % 4 == 0, 16-byte aligned planes, K padded
+// to 16 with W zero-padded, ldw - lda < 16, pad columns [K, lda) of A finite (zero: this kernel's epilogue writes them).
+template <int EPI>
+__global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
+    constexpr int BN = 64;
+    constexpr int A_SLOTS = BM * 4, B_SLOTS = BN * 4, STAGE = A_SLOTS + B_SLOTS;      // float4 slots per stage (12 KiB)
+    __shared__ __attribute__((aligned(16))) float4 smem[2 * STAGE];
+    __shared__ double red[8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int row_tile_all, ntile;
+    if (!xcd_decode(blockIdx.x, g.ntiles_n, g.row_tiles_all, row_tile_all, ntile)) return;
+    const int branch = row_tile_all / g.row_tiles, row_tile = row_tile_all % g.row_tiles;
+    const int tiles_per_utt = cdiv(g.Tp, BM);
+    const int utt = row_tile / tiles_per_utt;
+    const int t0 = (row_tile % tiles_per_utt) * BM;
+    const int n0 = ntile * BN;
+    const int rows_valid = min(BM, g.Tp - t0);
+
+    const float* A = g.A + branch * g.a_bs + ((long)utt * g.Tp + t0) * g.lda;
+    const float* W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
+    const int a_bytes = rows_valid * g.lda * 4, w_bytes = BN * g.ldw * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, w_bytes, 0x00020000);
+
+    // DMA pieces: wave w moves A slots [128 w, 128 w + 128) (two pieces) and B slots [64 w, 64 w + 64).  Slot s holds row
+    // s >> 2, k-quad (s & 3) ^ swz(row); swz(row) = (row >> 2) & 3 spreads 16 consecutive rows of one k-quad over all banks.
+    const int ktiles = g.ldw / BK;
+    int va[2], va_last[2], vb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = (wave * 2 + i) * 64 + lane, row = s >> 2, kq = (s & 3) ^ ((row >> 2) & 3);
+        va[i] = row * g.lda * 4 + kq * 16;                                    // rows >= rows_valid: beyond a_bytes -> zeros
+        va_last[i] = ((ktiles - 1) * BK + kq * 4 < g.lda) ? va[i] : a_bytes;   // last k-tile: k-quads beyond the row -> zeros
+    }
+    {
+        const int s = wave * 64 + lane, n = s >> 2, kq = (s & 3) ^ ((n >> 2) & 3);
+        vb = n * g.ldw * 4 + kq * 16;
+    }
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    auto issue = [&](int kt, int stage) {
+        float4* st = smem + stage * STAGE;
+        const bool last = kt == ktiles - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + 0) * 64), 16, last ? va_last[0] : va[0], kt * (BK * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + 1) * 64), 16, last ? va_last[1] : va[1], kt * (BK * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(st + A_SLOTS + wave * 64), 16, vb, kt * (BK * 4), 0, 0);
+    };
+    // readers: lane = (r = lane & 31, kh = lane >> 5) takes k-quad 2 kg + kh of row 32 wave + r (A) / column 32 jn + r (B)
+    const int r = lane & 31, kh = lane >> 5, sw = (r >> 2) & 3;
+    int aoff[2], boff[2][2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        aoff[kg] = (wave * 32 + r) * 4 + ((kg * 2 + kh) ^ sw);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) boff[kg][jn] = A_SLOTS + (jn * 32 + r) * 4 + ((kg * 2 + kh) ^ sw);
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    // one k-tile out of `stage`: ALL fragment reads first, then the DMA of the next tile into the other stage (hipcc waits
+    // vmcnt(0) before any ds_read that follows a DMA in program order - issued before the reads, the DMA would be waited for
+    // at once), then the 16 MFMAs that cover its flight, then the barrier (which carries the vmcnt(0)).
+    auto k_tile = [&](int stage, int kt_next) {
+        const float4* st = smem + stage * STAGE;
+        float4 a4[2], b4[2][2];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            a4[kg] = st[aoff[kg]];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) b4[kg][jn] = st[boff[kg][jn]];
+        }
+        if (kt_next < ktiles) issue(kt_next, stage ^ 1);
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].x, b4[kg][jn].x, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].y, b4[kg][jn].y, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].z, b4[kg][jn].z, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].w, b4[kg][jn].w, acc[jn], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);          // else hipcc hoists the vmcnt(0) + s_barrier above 15 of the 16 MFMAs
+        __syncthreads();
+    };
+    issue(0, 0);
+    __syncthreads();
+    asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));     // keep the accumulators in AGPRs across the loop (see lstm16.hip)
+    for (int kt = 0; kt < ktiles; kt += 2) {          // two k-tiles per trip: the stage is a compile-time constant
+        k_tile(0, kt + 1);
+        if (kt + 1 < ktiles) k_tile(1, kt + 2);
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5) ----
+    float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
+    double s = 0.0, q2 = 0.0;
+    float slope = 0.f, rstd = 1.f, mr = 0.f;
+    if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
+    if constexpr (EPI == EPI_RESIDUAL) {
+        const double* stt = g.gn_in + ((long)branch * g.B + utt) * 2;
+        const double m = stt[0] / g.gn_count;
+        const double var = stt[1] / g.gn_count - m * m;
+        const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
+        rstd = (float)rs;
+        mr = (float)(m * rs);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool col_ok = col < g.N;
+        const float bias = g.bias[branch * g.bias_bs + col];
+        float c2 = 0.f;
+        if constexpr (EPI == EPI_RESIDUAL) c2 = g.c2[branch * g.c2_bs + col];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int t = t0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (t < g.Tp && col_ok) {
+                float v;
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    v = acc[j][q] + bias;
+                    v = v >= 0.f ? v : slope * v;
+                    s += (double)v;
+                    q2 += (double)v * (double)v;
+                } else {
+                    v = rstd * acc[j][q] + (bias - mr * c2);
+                    v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
+                }
+                C[(long)t * g.ldc + col] = v;
+            } else if (t < g.Tp && col < g.ldc) {
+                C[(long)t * g.ldc + col] = 0.f;          // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
+            }
+        }
+    }
+    if constexpr (EPI == EPI_PRELU_STATS) {
+        s = wave_sum(s);
+        q2 = wave_sum(q2);
+        if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
+        __syncthreads();
+        if (tid == 0) {
+            double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+            atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
+            atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
+        }
+    }
+}
+
+// true (and launched) when the DMA kernel's requirements hold
+template <int EPI>
+static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, hipStream_t s, int branches) {
+    if (g.a_us || g.a_cols || g.lda % 4 || g.ldw % BK || g.ldw < g.K || g.lda < g.K) return false;
+    if (g.ldw - g.lda >= BK) return false;                 // only the LAST k-tile may reach beyond a row of A
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15 || (g.a_bs * 4) % 16 || (g.w_bs * 4) % 16) return false;
+    if ((long)BM * g.lda * 4 >= (1L << 31) || (long)64 * g.ldw * 4 >= (1L << 31)) return false;
+    GemmArgs ga = g;
+    ga.ntiles_n = cdiv(n, 64); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
+    hipLaunchKernelGGL((tcn_gemm_dma_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
+    return true;
+}
+
 // Column-tile width for one GEMM launch.  Workgroups are MFMA-bound, so the launch takes about
 // ceil(blocks / CUs) * BN; pick the BN in {64, 96, 128} that minimises it (ties -> the narrower tile: more,
 // smaller workgroups balance better).  Weights are zero-padded to a multiple of 384 rows so any choice is valid.
@@ -387,6 +567,8 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
     const int row_tiles = cdiv(d.Tp, BM) * d.B;
     const double gn_count = (double)d.CH * d.Tp;
     auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * branches) * d.B * 2; };
+    // DMA GEMMs: the full-band stacks only (their input `att` has zero pad columns; the sub-band TCN's buffers make no such promise)
+    const bool dma = branches == 3 && w.gemm_dma;
 
     for (int blk = 0; blk < w.NB; ++blk) {
         const float* xin = blk == 0 ? buf.att : buf.x;
@@ -399,7 +581,8 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gn_out = gn_slot(blk, 0);
             g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
             g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
-            launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s, branches);
+            if (!(dma && launch_gemm_dma<EPI_PRELU_STATS>(g, d.CH, row_tiles, s, branches)))
+                launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s, branches);
         }
         {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
             DwArgs g{};
@@ -425,7 +608,12 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gamma = w.g2w + (long)blk * d.CH; g.beta = w.g2b + (long)blk * d.CH; g.gb_bs = (long)w.NB * d.CH;
             g.K = d.CH; g.N = d.F; g.Tp = d.Tp; g.B = d.B;
             g.gn_count = gn_count; g.gn_eps = 1e-8f;
-            launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s, branches);
+            GemmArgs gf = g;                      // GroupNorm folded into the weights (tcn_gemm_dma_kernel)
+            gf.W = w.w2g + (long)blk * w.N2P * w.K2P;
+            gf.bias = w.c1 + (long)blk * w.N2P;
+            gf.c2 = w.c2 + (long)blk * w.N2P; gf.c2_bs = (long)w.NB * w.N2P;
+            if (!(dma && w.w2g && launch_gemm_dma<EPI_RESIDUAL>(gf, d.F, row_tiles, s, branches)))
+                launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s, branches);
         }
         if (blk == 0 && buf.dbg_tcn0)
             (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);

@@ -415,6 +415,12 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
 
+    def debug_set_gemm_dma(self, mode, device="cuda"):
+        """Tuning hook: 1 = full-band TCN GEMMs on the LDS-DMA kernel with GroupNorm folded into the weights (default),
+        0 = the general GEMM kernel."""
+        lib = self._ensure_handle(_resolve_device(device))
+        _lib.check(lib.fsnp_debug_set_gemm_dma(self._handle, int(mode)), "fsnp_debug_set_gemm_dma")
+
     def debug_set_graph(self, mode, device="cuda"):
         """Tuning hook: 1 / 2 = replay the full-band stages from a hipGraph, 0 = launch kernel by kernel (default)."""
         lib = self._ensure_handle(_resolve_device(device))

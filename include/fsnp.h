@@ -281,6 +281,11 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
                                                                   schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0) */
+/* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
+ * LDS DMA, GroupNorm folded into the sconv weights at fsnp_create; csrc/tcn.hip) where its layout requirements hold;
+ * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
+ * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it). */
+int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
 /* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
  * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph
  * and replayed on a private stream ordered by events (1) or straight into the caller's stream (2).  Off by default:
@@ -314,7 +319,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 5
+#define FSNP_ABI_VERSION 6
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

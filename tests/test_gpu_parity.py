@@ -537,6 +537,28 @@ def test_b32_full_vs_oracle(b32):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("profile,B,T", [("default", 3, 126), ("harsh", 2, 37), ("default", 2, 300), ("harsh", 1, 1)])
+def test_dma_gemm_equals_general_gemm(profile, B, T):
+    """csrc/tcn.hip: tcn_gemm_dma_kernel (operands by LDS DMA, XOR-swizzled image, GroupNorm folded into the sconv weights)
+    against the general tcn_gemm_kernel on the same handle, and both against the oracle: T' = 128 (one full row tile per
+    plane), 39 (ragged: rows beyond the plane are out of the DMA descriptor's range), 302 (three row tiles, ragged last), 3."""
+    sd = make_state_dict(21, profile)
+    m = _model(DEFAULT_MODEL_ARGS, sd, mode="full")
+    mag, real, imag = make_inputs(B, T, 77)
+    g = _cuda((mag, real, imag))
+    fast = m(*g).cpu().numpy()
+    m.debug_set_gemm_dma(0)
+    general = m(*g).cpu().numpy()
+    m.debug_set_gemm_dma(1)
+    again = m(*g).cpu().numpy()
+    want = fsnp_torch.forward_full(sd, mag, real, imag).numpy()
+    e_fast, e_gen, e_pair = rel_err(fast, want), rel_err(general, want), rel_err(fast, general)
+    _record(f"dma_gemm_{profile}_B{B}_T{T}", rel_dma=e_fast, rel_general=e_gen, rel_dma_vs_general=e_pair)
+    assert np.array_equal(fast, again)
+    assert e_fast < TOL and e_gen < TOL and e_pair < 1e-4, (e_fast, e_gen, e_pair)
+    assert not np.array_equal(fast, general)      # the two kernels really are different code paths
+
+
 def test_b32_10s_full_vs_oracle():
     """BASELINE configs[3] at its benchmarked shape (batch 32 x 10 s clips, T = 626, look-ahead 2): first and last
     utterance against the oracle (the last one again holds the remainder kernel's rows), plus batch independence of a
