@@ -266,8 +266,11 @@ int fsnp_poll_errors(fsnp_handle* h);
 /* Pipelined serving mode (off by default).  With 1, the column-split remainder chunks that follow a one-tile-per-CU
  * chunk in the sub-band plan (B = 32: the 32 sequences left over after 8192 fill the chip, 1.1 ms on 48 CUs) are
  * enqueued on a private stream after that chunk, so they overlap the full-band stages of the NEXT fsnp_forward on the
- * handle, which leave most CUs idle; the workspace is double buffered for it.  Contract: after fsnp_forward returns,
- * work enqueued on the caller's stream is NOT ordered after those remainder chunks (the rows of `out` they own are
+ * handle, which leave most CUs idle; the workspace is double buffered for it.  A plan that STARTS with a column-split
+ * launch (small batches: B = 1 is one K-split launch on 216 CUs) is deferred whole - every row of `out` is then pending.
+ * Deferred launches claim the whole LDS of their CUs, so no LDS-using workgroup of the overlapped kernels shares a CU with
+ * them.  Contract: after fsnp_forward returns,
+ * work enqueued on the caller's stream is NOT ordered after the deferred chunks (the rows of `out` they own are
  * still being written) until fsnp_flush(h, stream) has made `stream` wait for all deferred work - call it before
  * anything consumes `out`; a serving loop calls it once per batch it hands on, a benchmark once before its final
  * synchronisation.  Results are bit-identical to the non-pipelined call.  Switching the mode synchronises the device. */

@@ -883,6 +883,31 @@ def test_pipelined_mode_is_bit_identical(batch):
     assert torch.equal(m(*batches[1]), plain[1])
 
 
+@pytest.mark.parametrize("batch,mode", [(1, "full"), (3, "full"), (8, "full"), (16, "full"), (12, "parity")])
+def test_pipelined_small_batches_run_whole_on_the_side_stream(batch, mode):
+    """Plans that START with a column-split launch (B = 1: one K-split launch on 216 CUs; B = 8: three-way split) are sent to the
+    side stream whole in pipelined mode, so that the next forward's full-band stages run beside them (their workgroups claim
+    the CU's LDS: no GEMM workgroup shares a CU with them).  Bit-identical to the plain call over a loop of different inputs;
+    B = 16 (half-tile round + K-split remainder) takes the older deferred-remainder path."""
+    sd = make_state_dict(3, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd, mode)
+    m.error_check = "deferred"
+    batches = [_cuda(make_inputs(batch, 0.4, 1300 + i)) for i in range(4)]
+    plain = [m(*b).clone() for b in batches]
+    torch.cuda.synchronize()
+    m.set_pipeline(True)
+    piped = [m(*b) for b in batches] + [m(*batches[0]), m(*batches[2])]
+    m.flush()
+    torch.cuda.synchronize()
+    m.poll_errors()
+    for a, b in zip(piped, plain + [plain[0], plain[2]]):
+        assert torch.equal(a, b)
+    m.error_check = "sync"                     # the sync policy flushes + polls after every call
+    assert torch.equal(m(*batches[3]), plain[3])
+    m.set_pipeline(False)
+    assert torch.equal(m(*batches[1]), plain[1])
+
+
 # ---------------------------------------------------------------- SURVEY.md 8(f-3): STFT / iSTFT / waveform -> waveform
 @pytest.mark.parametrize("B,L", [(1, 32000), (3, 16000), (2, 12345), (1, 300)])
 def test_stft_istft_vs_torch(B, L):
