@@ -581,7 +581,8 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
         // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)
         static const int own_cu = [] { const char* e = getenv("FSNP_OWN_CU"); return e && e[0] == '0' ? 0 : 1; }();
-        ca.coop_own_cu = (own_cu && h->side_stream && s == h->side_stream) ? 160 * 1024 - 256 : 0;
+        // (never for a launch planned with two workgroups per CU: they would no longer be co-resident)
+        ca.coop_own_cu = (own_cu && h->side_stream && s == h->side_stream && chunk_workgroups(h, c) <= h->num_cus_real) ? 160 * 1024 - 256 : 0;
         ca.coop_err = h->d_err;
         ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
@@ -1493,7 +1494,11 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         while (ndefer < (int)plan.chunks.size() && fills_chip(plan.chunks[ndefer])) ++ndefer;
         if (ndefer == (int)plan.chunks.size()) ndefer = 0;
     } else if (h->pipeline && h->defer_small && !fills_chip(plan.chunks[0])) {
-        defer_all = true;
+        // ... if its launches leave room: they own their CUs, and the overlapped stages crawl on what is left (B = 5: 246 of 256
+        // CUs taken, full-band stage 0.5 -> 5.4 ms: no gain)
+        int busiest = 0;
+        for (const SbChunk& c : plan.chunks) busiest = std::max(busiest, chunk_workgroups(h, c));
+        defer_all = busiest <= h->num_cus_real - 32;
     }
     if (defer_all) {
         FSNP_HIP_CHECK(hipEventRecord(h->ev_main, s));

@@ -883,8 +883,9 @@ def test_pipelined_mode_is_bit_identical(batch):
     assert torch.equal(m(*batches[1]), plain[1])
 
 
-@pytest.mark.parametrize("batch,mode", [(1, "full"), (3, "full"), (8, "full"), (16, "full"), (12, "parity")])
-def test_pipelined_small_batches_run_whole_on_the_side_stream(batch, mode):
+@pytest.mark.parametrize("batch,mode,two_per_cu", [(1, "full", False), (3, "full", False), (8, "full", False), (16, "full", False),
+                                                   (12, "parity", False), (40, "full", True), (5, "full", False)])
+def test_pipelined_small_batches_run_whole_on_the_side_stream(batch, mode, two_per_cu):
     """Plans that START with a column-split launch (B = 1: one K-split launch on 216 CUs; B = 8: three-way split) are sent to the
     side stream whole in pipelined mode, so that the next forward's full-band stages run beside them (their workgroups claim
     the CU's LDS: no GEMM workgroup shares a CU with them).  Bit-identical to the plain call over a loop of different inputs;
@@ -893,6 +894,13 @@ def test_pipelined_small_batches_run_whole_on_the_side_stream(batch, mode):
     m = _model(DEFAULT_MODEL_ARGS, sd, mode)
     m.error_check = "deferred"
     batches = [_cuda(make_inputs(batch, 0.4, 1300 + i)) for i in range(4)]
+    if two_per_cu:        # a plan with TWO column-split workgroups per CU must not claim the CU's whole LDS (they would not be co-resident)
+        m(*batches[0])
+        table = list(CHEAP_TWO_PER_CU)
+        table[12] = 100.0                           # (a cheap row-tile round: B = 40 = 8192 sequences that fill the chip + a 66-tile
+        m.debug_set_costs(table, 2)                 #  remainder K split at 64 units = 396 workgroups, two per CU, deferred)
+        plan = m.describe_plan(batch)
+        assert plan[0]["kernel"].startswith("lstm2_fc_kernel") and len(plan) == 2 and plan[1]["tiles"] == 66 and "K split" in plan[1]["kernel"], plan
     plain = [m(*b).clone() for b in batches]
     torch.cuda.synchronize()
     m.set_pipeline(True)
