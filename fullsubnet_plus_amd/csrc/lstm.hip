@@ -138,24 +138,27 @@ __host__ __device__ __forceinline__ int a_frag_index_bf16(int row, int k) {
 }
 
 template <int ST, int UW>
-__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST], float* __restrict__ Hs, int wave,
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x2 (&c)[ST][8], float* __restrict__ Hs, int wave,
                                           int lane, unsigned short* __restrict__ Hb = nullptr) {
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
         const int k = wave * UW + s * 32 + (lane & 31);
         const int kbase = (((k >> 3) * 64) + ((k & 1) * 32)) * 4 + ((k >> 1) & 3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float ig = fast_sigmoid(acc[s][r]);
-            const float fg = fast_sigmoid(acc[ST + s][r]);
-            const float gg = fast_tanh(acc[2 * ST + s][r]);
-            const float og = fast_sigmoid(acc[3 * ST + s][r]);
-            const float cn = fg * c[s][r] + ig * gg;
-            c[s][r] = cn;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float h = og * fast_tanh(cn);
-            Hs[kbase + row * 4] = h;
-            if (Hb) Hb[a_frag_index_bf16(row, k)] = bf16_bits(h);
+        for (int r = 0; r < 16; r += 2) {                  // two cells per pass: packed fp32 math (lstm_common.h)
+            // element-wise AGPR reads: handed `f32x2{acc[..][r], acc[..][r + 1]}` hipcc copies whole 16-register tiles to VGPRs
+            // (ST > 1 = one wave per SIMD: the accumulators live in AGPRs; with 12 waves they are VGPRs already)
+            auto rd = [](float v) {
+                if constexpr (ST > 1) { float o; asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v)); return o; }
+                else return v;
+            };
+            const f32x2 h = lstm_cell_pair(f32x2{rd(acc[s][r]), rd(acc[s][r + 1])}, f32x2{rd(acc[ST + s][r]), rd(acc[ST + s][r + 1])},
+                                           f32x2{rd(acc[2 * ST + s][r]), rd(acc[2 * ST + s][r + 1])},
+                                           f32x2{rd(acc[3 * ST + s][r]), rd(acc[3 * ST + s][r + 1])}, c[s][r >> 1]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);     // (r even: r + 1 is the next row)
+            Hs[kbase + row * 4] = h.x;
+            Hs[kbase + (row + 1) * 4] = h.y;
+            if (Hb) { Hb[a_frag_index_bf16(row, k)] = bf16_bits(h.x); Hb[a_frag_index_bf16(row + 1, k)] = bf16_bits(h.y); }
         }
     }
 }
@@ -336,12 +339,12 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     // biases sit in LDS in (layer, wave, tile, column) order: Bs[((layer*NW + wave)*NT + n)*32 + col]
     const float* __restrict__ bias_l0 = Bs + ((0 * NW + wave) * NT) * 32 + (lane & 31);
     const float* __restrict__ bias_l1 = Bs + ((1 * NW + wave) * NT) * 32 + (lane & 31);
-    f32x16 c0[ST], c1[ST];
+    f32x2 c0[ST][8], c1[ST][8];          // cell state as register PAIRS (rows r, r + 1): operands of the packed cell update
     float cx0[EXA][ST], cx1[EXA][ST];
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { c0[s][r] = 0.0f; c1[s][r] = 0.0f; }
+        for (int r = 0; r < 8; ++r) { c0[s][r] = f32x2{0.0f, 0.0f}; c1[s][r] = f32x2{0.0f, 0.0f}; }
 #pragma unroll
         for (int e = 0; e < EXA; ++e) { cx0[e][s] = 0.0f; cx1[e][s] = 0.0f; }
     }

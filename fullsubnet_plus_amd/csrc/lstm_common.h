@@ -9,6 +9,42 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// ---- LSTM cell update on TWO cells at a time (packed fp32 VALU: v_pk_mul / v_pk_add / v_pk_fma) with 8 transcendentals
+// per cell instead of 10:   sigmoid(i) tanh(g) = (1 - eg) / ((1 + ei)(1 + eg)),   sigmoid(o) tanh(c') likewise - one v_rcp per
+// product.  e* = exp2(-x log2 e) (sigmoid) / exp2(-2 x log2 e) (tanh).  The tanh exponents are clamped to 2^64: (1 - e) then
+// stays finite (inf * 0 would be NaN) AND the product of the two denominators can only overflow when the sigmoid's own
+// e exceeds 2^64, i.e. when that sigmoid is < 6e-20 and the true product is 0 to fp32 anyway (a clamp at 2^126 let
+// (1 + eo)(1 + ec) overflow for ordinary gates next to a saturated cell: h = 0 instead of -sigmoid(o)); tanh is exactly
+// -+1 in fp32 from |x| = 9 on, the clamp acts at |x| = 22.  The cell phases are ~5 % of the row-tile kernel's time and cannot overlap its fp32
+// MFMAs (profiles/r01_lstm_phase_ab.md); v_exp / v_rcp issue at a quarter of the packed-math rate.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 exp2_pair(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ f32x2 rcp_pair(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ f32x2 min_pair(f32x2 x, float m) { return f32x2{fminf(x.x, m), fminf(x.y, m)}; }
+// c <- sigmoid(f) c + sigmoid(i) tanh(g);  returns h = sigmoid(o) tanh(c)
+__device__ __forceinline__ f32x2 lstm_cell_pair(f32x2 xi, f32x2 xf, f32x2 xg, f32x2 xo, f32x2& c) {
+    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+    const f32x2 ei = exp2_pair(xi * kS), ef = exp2_pair(xf * kS), eo = exp2_pair(xo * kS);
+    const f32x2 eg = exp2_pair(min_pair(xg * kT, 64.0f));
+    const f32x2 igg = (1.0f - eg) * rcp_pair((1.0f + ei) * (1.0f + eg));
+    const f32x2 cn = rcp_pair(1.0f + ef) * c + igg;
+    c = cn;
+    const f32x2 ec = exp2_pair(min_pair(cn * kT, 64.0f));
+    return (1.0f - ec) * rcp_pair((1.0f + eo) * (1.0f + ec));
+}
+
+// scalar form of the same update (one cell): 8 transcendentals instead of the 10 of sigmoid / tanh called one by one
+__device__ __forceinline__ float lstm_cell_one(float xi, float xf, float xg, float xo, float& c) {
+    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+    const float ei = __builtin_amdgcn_exp2f(xi * kS), ef = __builtin_amdgcn_exp2f(xf * kS), eo = __builtin_amdgcn_exp2f(xo * kS);
+    const float eg = __builtin_amdgcn_exp2f(fminf(xg * kT, 64.0f));
+    const float igg = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    const float cn = fmaf(__builtin_amdgcn_rcpf(1.0f + ef), c, igg);
+    c = cn;
+    const float ec = __builtin_amdgcn_exp2f(fminf(cn * kT, 64.0f));
+    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FSNP_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == FSNP_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);

@@ -56,9 +56,12 @@ def _cuda(ts):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("profile,n,steps", [("default", 70, 12), ("harsh", 33, 40), ("default", 256, 6)])
+@pytest.mark.parametrize("profile,n,steps", [("default", 70, 12), ("harsh", 33, 40), ("default", 256, 6), ("harsh", 96, 260)])
 def test_lstm2_fc_dense_vs_oracle(profile, n, steps):
-    """Fused LSTM kernel alone on dense inputs (ragged tile counts) vs torch.lstm + linear."""
+    """Fused LSTM kernel alone on dense inputs (ragged tile counts) vs torch.lstm + linear.  ("harsh", 96, 260): cell states
+    reach |c| ~ 40-60 - the packed cell update (lstm_common.h) forms sigmoid * tanh with ONE reciprocal of the product of
+    both denominators, which must not overflow next to a saturated tanh (a clamp at 2^126 instead of 2^64 returned h = 0
+    there: caught at B = 32 x 2 s by test_bf16x3_forward_b32, now pinned here)."""
     sd = make_state_dict(3, profile)
     m = _model(DEFAULT_MODEL_ARGS, sd)
     m.debug_set_lstm_coop(0)
@@ -517,22 +520,23 @@ def b32():
 
 
 def test_b32_full_vs_oracle(b32):
-    """BASELINE configs[1] at its benchmarked shape.  Utterances 0, 15 and 31 against the oracle: in "full" mode rows are
-    (utterance, bin) in order, so utterance 31's bins 225..256 are exactly the 32 sequences the planner hands to the
+    """BASELINE configs[1] at its benchmarked shape.  EVERY utterance against the oracle (round 2: a cell-update overflow that
+    only fired where |c| > 42 hit 8 of the 32 utterances and none of the three that used to be sampled): in "full" mode rows
+    are (utterance, bin) in order, so utterance 31's bins 225..256 are exactly the 32 sequences the planner hands to the
     remainder (K-split) kernel after the 8192 that fill the chip - all three kernels' rows are compared directly."""
     sd, (mag, real, imag), m, full = b32
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     plan = m.describe_plan(32)
     assert sum(c["sequences"] for c in plan) == 32 * 257
     errs = {}
-    for b in (0, 15, 31):
+    for b in range(32):
         want = fsnp_torch.forward_full(sd, mag[b:b + 1], real[b:b + 1], imag[b:b + 1]).numpy()
         errs[b] = rel_err(full[b:b + 1].numpy(), want)
         if b == 31 and len(plan) > 1:           # the remainder chunk's rows on their own
             n_rem = plan[-1]["sequences"]
             errs["remainder_rows"] = rel_err(full[31, :, 257 - n_rem:].numpy(), want[0, :, 257 - n_rem:])
-    _record("b32_2s_full_vs_oracle_utt_0_15_31", plan=[c["kernel"] + f" x{c['sequences']}" for c in plan],
-            **{f"rel_{k}": v for k, v in errs.items()})
+    _record("b32_2s_full_vs_oracle_all_utterances", plan=[c["kernel"] + f" x{c['sequences']}" for c in plan],
+            rel_max=max(errs.values()), rel_utt_0=errs[0], rel_utt_15=errs[15], rel_utt_31=errs[31], rel_remainder_rows=errs.get("remainder_rows"))
     assert full.shape == (32, 2, 257, 126)
     assert max(errs.values()) < TOL, errs
 
