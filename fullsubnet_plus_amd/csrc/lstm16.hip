@@ -69,14 +69,15 @@ __device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], flo
     for (int s = 0; s < SB; ++s) {
         const int k = wave * UW + s * 16 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ig = fast_sigmoid(acc[s][r]);
-            const float fg = fast_sigmoid(acc[SB + s][r]);
-            const float gg = fast_tanh(acc[2 * SB + s][r]);
-            const float og = fast_sigmoid(acc[3 * SB + s][r]);
-            const float cn = fg * c[s][r] + ig * gg;
-            c[s][r] = cn;
-            Hs[a16_index(4 * (lane >> 4) + r, k)] = og * fast_tanh(cn);
+        for (int r = 0; r < 4; r += 2) {                   // two cells per pass: packed fp32 math (lstm_common.h lstm_cell_pair)
+            auto rd = [](float v) { float o; asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v)); return o; };
+            f32x2 cc{c[s][r], c[s][r + 1]};
+            const f32x2 h = lstm_cell_pair(f32x2{rd(acc[s][r]), rd(acc[s][r + 1])}, f32x2{rd(acc[SB + s][r]), rd(acc[SB + s][r + 1])},
+                                           f32x2{rd(acc[2 * SB + s][r]), rd(acc[2 * SB + s][r + 1])},
+                                           f32x2{rd(acc[3 * SB + s][r]), rd(acc[3 * SB + s][r + 1])}, cc);
+            c[s][r] = cc.x; c[s][r + 1] = cc.y;
+            Hs[a16_index(4 * (lane >> 4) + r, k)] = h.x;
+            Hs[a16_index(4 * (lane >> 4) + r + 1, k)] = h.y;
         }
     }
 }
