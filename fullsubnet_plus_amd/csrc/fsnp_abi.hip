@@ -129,6 +129,9 @@ struct fsnp_handle {
     int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
     int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
+    int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
+    int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups
+                                 // per row tile), 0 = never, 2 = wherever it fits (FSNP_COOP_SPLIT, tuning)
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
                                  // so the NEXT call on the handle can fail loudly without a device synchronisation
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
@@ -417,15 +420,30 @@ static CostTable default_costs() {
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
+// per-step cost of the role-split K-split schedule relative to the one-set kernel of the same units and tile count
+// (lstm_coop.hip: lstm2_coop_split_kernel; measured, profiles/r02_column_split.md section 8: 1 tile at 8 units 11.06 -> 9.47 us,
+// 2 tiles 14.40 -> 11.32; from 16 units up it does not pay - a step is ONE hand-off on either schedule, the split only takes
+// the other layer's MFMA + cell time out of the chain)
+static const double kSplitRatio[4] = {0.85, 1.0, 1.1, 1.25};
 static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) {
-    if (c.kind == 1) return c.num_tiles * (h->H / c.units);
+    if (c.kind == 1) return c.num_tiles * (h->H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
     if (c.kind == 2) return c.groups * (h->H / 128);
     return c.num_tiles;
 }
 static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
     const int dbl = chunk_workgroups(h, c) > h->num_cus_real ? 1 : 0;
     if (c.kind == 1) {
-        const int ui = units_index(c.units), cap = h->num_cus_real / (h->H / c.units);
+        const int ui = units_index(c.units);
+        if (c.rpg) {             // role-split schedule: priced relative to the same shape on the one-set kernels (kSplitRatio)
+            const int cap = h->num_cus_real / (2 * (h->H / c.units));
+            const double r = h->coop_split == 2 ? 0.01 : kSplitRatio[ui];
+            // 8 units: measured directly (1 tile 8.2 us, 2 tiles 10.0 - the one-set kernel: 8.7 / 13.2), scaled with the table
+            if (ui == 0 && c.num_tiles <= 2 && h->coop_split != 2) return (c.num_tiles == 1 ? 8.2 : 10.0) * h->cost.ksplit1[0] / 8.7;
+            if (cap <= 1) return r * h->cost.ksplit1[ui];
+            const double f = (double)(c.num_tiles - 1) / (cap - 1);
+            return r * (h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0));
+        }
+        const int cap = h->num_cus_real / (h->H / c.units);
         if (dbl || cap <= 1) return h->cost.ksplit[ui][dbl];
         const double f = (double)(c.num_tiles - 1) / (cap - 1);              // 1 tile .. a full launch
         return h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
@@ -458,6 +476,11 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
                 shapes.push_back({1, u, 0, slots / (h->H / u), occ - 1});
         for (int rpg = 1; rpg <= 2; ++rpg)
             if (h->occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
+        // role-split K split: 2 S workgroups per row tile, LSTM only; not in the pipelined loop, where the chunk runs beside the
+        // next forward's full-band stages and twice the CUs for 15 % less time is a bad trade (auto mode)
+        if (occ == 1 && !h->gru && (h->coop_split == 2 || (h->coop_split == 1 && !h->pipeline)))
+            for (int u = 8; u <= 64; u *= 2)
+                if (h->H % u == 0 && slots / (2 * (h->H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h->H / u)), 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
         SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
@@ -577,6 +600,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
         ca.coop_skew = h->coop_skew;
+        ca.coop_split = c.kind == 1 && c.rpg ? 1 : 0;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
         // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)
@@ -589,7 +613,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
         static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
         {
-            const int S = c.kind == 1 ? h->H / c.units : h->H / 128, T = c.kind == 1 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
+            const int S = c.kind == 1 ? (h->H / c.units) * (c.rpg ? 2 : 1) : h->H / 128, T = c.kind == 1 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
             ca.coop_xcd = xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
@@ -976,6 +1000,9 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
+    const char* csp = getenv("FSNP_COOP_SPLIT");
+    if (csp && csp[0] >= '0' && csp[0] <= '2') h->coop_split = csp[0] - '0';
+    h->coop_split_cfg = h->coop_split;
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
     const char* sk = getenv("FSNP_COOP_SKEW");
@@ -1819,7 +1846,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        out[4 * n + 0] = h->sb_tcn ? 3 : c.kind; out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;   // (kind 4 = half-tile kernel)
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind); out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;   // (kind 4 = half-tile kernel)
         ++n;
     }
     return n;
@@ -1947,6 +1974,7 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto) or 2 (auto, serial K-split schedule)"); return 1; }
     h->lstm_coop = mode != 0;
     h->coop_skew = mode == 1;
+    h->coop_split = mode == 1 ? h->coop_split_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) { const int occ = h->coop_occ; h->cost = default_costs(); if (h->gru) h->cost.rowtile *= 0.75; h->coop_occ = occ; }
     return 0;

@@ -462,7 +462,8 @@ class _HipModel(nn.Module):
         names = {0: ("gru2_fc_kernel" if self.sequence_model == "GRU" else "lstm2_fc_kernel") + " (one 32-row tile per CU)",
                  1: "lstm2_coop_kernel (K split)",
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
-                 4: "lstm2_fc16_kernel (one 16-row tile per CU)"}
+                 4: "lstm2_fc16_kernel (one 16-row tile per CU)",
+                 5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)"}
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]
 

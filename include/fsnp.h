@@ -195,7 +195,8 @@ int fsnp_set_timing(fsnp_handle* h, int32_t enable);
 int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
- *  half-tile: 16-row tiles, csrc/lstm16.hip),
+ *  half-tile: 16-row tiles, csrc/lstm16.hip, 5 = lstm2_coop_split K-split with one workgroup set per layer: planned for 1-2 row
+ *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
