@@ -33,18 +33,6 @@ __device__ __forceinline__ f32x2 lstm_cell_pair(f32x2 xi, f32x2 xf, f32x2 xg, f3
     return (1.0f - ec) * rcp_pair((1.0f + eo) * (1.0f + ec));
 }
 
-// scalar form of the same update (one cell): 8 transcendentals instead of the 10 of sigmoid / tanh called one by one
-__device__ __forceinline__ float lstm_cell_one(float xi, float xf, float xg, float xo, float& c) {
-    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
-    const float ei = __builtin_amdgcn_exp2f(xi * kS), ef = __builtin_amdgcn_exp2f(xf * kS), eo = __builtin_amdgcn_exp2f(xo * kS);
-    const float eg = __builtin_amdgcn_exp2f(fminf(xg * kT, 64.0f));
-    const float igg = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
-    const float cn = fmaf(__builtin_amdgcn_rcpf(1.0f + ef), c, igg);
-    c = cn;
-    const float ec = __builtin_amdgcn_exp2f(fminf(cn * kT, 64.0f));
-    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
-}
-
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FSNP_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == FSNP_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
