@@ -17,6 +17,7 @@ seq = os.environ.get("SEQ", "LSTM")
 m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": seq})
 m.load_state_dict(make_state_dict(0, "default", sequence_model=seq), strict=True)
 m = m.to("cuda").eval()
+torch.manual_seed(1234 + n)
 x = torch.randn(n, 34, steps, device="cuda")
 out = m.lstm2_fc(x)
 if os.environ.get("PIN_R01"):
