@@ -223,6 +223,52 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
                 assert l["drain"] == 0, (key, l)
 
 
+def test_dma_gemm_lds_image_is_a_conflict_free_permutation():
+    """csrc/tcn.hip tcn_gemm_dma_kernel, index arithmetic restated: the DMA writes lane-linear (piece base + 16 bytes x lane), so
+    lane l of a piece FETCHES row s >> 2, k-quad (s & 3) ^ swz(row) for slot s; readers take slot row * 4 + (kq ^ swz(row)).
+    Checked here: every (row, k-quad) of the 128 x 16 A tile and the 64 x 16 B tile lands in exactly one slot, readers find
+    the k-quad they ask for, the 16 lanes of each quarter of a ds_read_b128 touch 64 distinct LDS banks, and the k
+    permutation (MFMA j of k-group kg multiplies k = 8 kg + j and 8 kg + 4 + j) is shared by A and B and covers the tile."""
+    swz = lambda row: (row >> 2) & 3
+    for rows, pieces_per_wave in ((128, 2), (64, 1)):                 # A tile, B tile
+        image = {}
+        for wave in range(4):
+            for piece in range(pieces_per_wave):
+                for lane in range(64):
+                    s = (wave * pieces_per_wave + piece) * 64 + lane  # lane-linear destination slot
+                    row, kq = s >> 2, (s & 3) ^ swz(s >> 2)           # what that lane fetches
+                    assert s not in image
+                    image[s] = (row, kq)
+        assert sorted(image.values()) == [(r, q) for r in range(rows) for q in range(4)]
+        for base in range(0, rows, 32):                               # a wave's 32 rows (A) / a 32-column accumulator (B)
+            for kg in range(2):
+                for quarter in range(4):                              # ds_read_b128: 16 lanes per pass
+                    banks = []
+                    for lane in range(quarter * 16, quarter * 16 + 16):
+                        r, kh = lane & 31, lane >> 5
+                        row, kq = base + r, kg * 2 + kh
+                        slot = row * 4 + (kq ^ swz(row))
+                        assert image[slot] == (row, kq)
+                        banks += [(slot * 4 + w) % 64 for w in range(4)]
+                    assert len(set(banks)) == 64, (rows, base, kg, quarter)
+    ks = sorted(8 * kg + 4 * kh + j for kg in range(2) for kh in range(2) for j in range(4))
+    assert ks == list(range(16))
+
+
+def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
+    """tcn_gemm_dma_kernel (csrc/tcn.hip): between its first and last MFMA the k-loop holds no LDS stores, no scratch, no
+    accumulator shuttling and only the offset selects as VALU work - the general kernel issues ~200 VALU/SALU per 16 MFMAs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_dma_gemm()
+    assert len(res) == 2
+    for key, l in res.items():
+        assert l["mfma"] >= 32 and l["dma"] >= 3 and l["ds_read"] >= 6, (key, l)
+        assert l["scratch"] == 0 and l["acc_moves"] == 0 and l["ds_write"] == 0 and l["valu"] <= 12, (key, l)
+
+
 def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
     """lstm2_fc16_kernel (csrc/lstm16.hip): every k-group loop is 96 MFMAs + 24 weight loads, no scratch, no drain and no
     AGPR<->VGPR shuttling of the 24 accumulator tiles (the asm pins in the kernel exist for exactly that)."""

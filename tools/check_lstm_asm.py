@@ -99,7 +99,29 @@ def analyse_half_tile(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_dma_gemm(flags=("-fno-slp-vectorize",)):
+    """k-loop of tcn_gemm_dma_kernel (tcn.hip), per instantiation: per k-tile 16 MFMAs, 6 ds_read_b128, 3 LDS-DMA loads and two
+    offset selects - no ds_write, no scratch, no AGPR<->VGPR moves (counts over the span between the first and the last MFMA)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "tcn.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp19tcn_gemm_dma_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), [l for l in m.group(2).split("\n") if l.strip() and not l.strip().startswith(";")]
+        idx = [i for i, l in enumerate(body) if "v_mfma" in l]            # the k-loop = everything between the first and the last MFMA
+        seg = body[idx[0] - 12:idx[-1] + 1]                               # (+ the fragment reads and DMA issue in front of the first)
+        cnt = lambda pat: sum(1 for x in seg if re.search(pat, x))
+        res[name] = dict(mfma=cnt(r"v_mfma"), ds_read=cnt(r"ds_read_b128"), dma=cnt(r"buffer_load_dwordx4 .* lds"), scratch=cnt(r"scratch_"),
+                         acc_moves=cnt(r"v_accvgpr"), valu=cnt(r"^\s+v_(?!mfma)"), ds_write=cnt(r"ds_write"))
+    return res
+
+
 if __name__ == "__main__":
+    for k, v in analyse_dma_gemm().items():
+        print(k, v)
     for k, loops in analyse_half_tile().items():
         for l in loops:
             print(k, l)
