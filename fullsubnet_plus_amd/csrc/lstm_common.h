@@ -33,6 +33,19 @@ __device__ __forceinline__ f32x2 lstm_cell_pair(f32x2 xi, f32x2 xf, f32x2 xg, f3
     return (1.0f - ec) * rcp_pair((1.0f + eo) * (1.0f + ec));
 }
 
+// nn.GRU cell on two cells at a time: r = s(a_r), z = s(a_z), n = tanh(a_nx + r a_nh), h' = (1 - z) n + z h.  With
+// e_z = exp2(-a_z log2 e), e_n = exp2(-2 (a_nx + r a_nh) log2 e):  h' = [e_z (1 - e_n) + h (1 + e_n)] / ((1 + e_z)(1 + e_n)) -
+// 5 transcendentals instead of 6, packed VALU math.  Both exponents are clamped to 2^60: numerator and denominator stay below
+// 2^121 (finite) and the clamped factors are exact to fp32 (z < 9e-19 counts as 0, tanh = -1).
+__device__ __forceinline__ f32x2 gru_cell_pair(f32x2 ar, f32x2 az, f32x2 anx, f32x2 anh, f32x2 h) {
+    constexpr float kS = -1.4426950408889634f, kT = -2.8853900817779268f;
+    const f32x2 r = rcp_pair(1.0f + exp2_pair(ar * kS));
+    const f32x2 ez = exp2_pair(min_pair(az * kS, 60.0f));
+    const f32x2 en = exp2_pair(min_pair((anx + r * anh) * kT, 60.0f));
+    const f32x2 num = ez * (1.0f - en) + h * (1.0f + en);
+    return num * rcp_pair((1.0f + ez) * (1.0f + en));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FSNP_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == FSNP_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);

@@ -65,14 +65,15 @@ __device__ __forceinline__ void gru_cell(f32x16 (&acc)[4 * ST], f32x16 (&hreg)[S
         const int k = wave * UW + s * 32 + (lane & 31);
         const int kbase = (((k >> 3) * 64) + ((k & 1) * 32)) * 4 + ((k >> 1) & 3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float rg = fast_sigmoid(acc[s][r]);
-            const float zg = fast_sigmoid(acc[ST + s][r]);
-            const float ng = fast_tanh(acc[2 * ST + s][r] + rg * acc[3 * ST + s][r]);
-            const float h = ng + zg * (hreg[s][r] - ng);
-            hreg[s][r] = h;
+        for (int r = 0; r < 16; r += 2) {                  // two cells per pass: packed fp32 math (lstm_common.h gru_cell_pair)
+            auto rd = [](float v) { float o; asm("v_accvgpr_read_b32 %0, %1" : "=v"(o) : "a"(v)); return o; };   // (see lstm.hip lstm_cell)
+            const f32x2 h = gru_cell_pair(f32x2{rd(acc[s][r]), rd(acc[s][r + 1])}, f32x2{rd(acc[ST + s][r]), rd(acc[ST + s][r + 1])},
+                                          f32x2{rd(acc[2 * ST + s][r]), rd(acc[2 * ST + s][r + 1])},
+                                          f32x2{rd(acc[3 * ST + s][r]), rd(acc[3 * ST + s][r + 1])}, f32x2{hreg[s][r], hreg[s][r + 1]});
+            hreg[s][r] = h.x; hreg[s][r + 1] = h.y;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            Hs[kbase + row * 4] = h;
+            Hs[kbase + row * 4] = h.x;
+            Hs[kbase + (row + 1) * 4] = h.y;
         }
     }
 }

@@ -723,6 +723,26 @@ def test_gru2_fc_dense_vs_oracle(n, steps):
     assert rel_err(tile, want) < 2e-5
 
 
+@pytest.mark.parametrize("scale,steps", [(40.0, 30), (400.0, 12)])
+def test_gru_rowtile_saturated_gates(scale, steps):
+    """gru2_fc_kernel's packed cell update (lstm_common.h gru_cell_pair) forms h' = [e_z (1 - e_n) + h (1 + e_n)] / ((1 + e_z)(1 + e_n))
+    with ONE reciprocal; inputs 40x / 400x the usual scale drive a_z, a_n to +-hundreds, where the clamped exponents (2^60)
+    must neither overflow the products nor change the result."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"}
+    sd = make_state_dict(31, "harsh", sequence_model="GRU")
+    m = _model(args, sd)
+    m.debug_set_lstm_coop(0)
+    rng = np.random.Generator(np.random.PCG64(4242))
+    x = torch.from_numpy((rng.standard_normal((200, 34, steps)) * scale).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    m.check_errors()
+    assert np.isfinite(got).all()
+    err = rel_err(got, want)
+    _record(f"gru2_fc_saturated_x{int(scale)}", rel=err)
+    assert err < 2e-5, err
+
+
 def test_gru_forward_b32_full_vs_oracle():
     args = {**DEFAULT_MODEL_ARGS, "sequence_model": "GRU"}
     sd = make_state_dict(32, "default", sequence_model="GRU")
