@@ -75,18 +75,20 @@ __device__ __forceinline__ void bf3_cell(f32x16 (&acc)[4 * ST], f32x16 (&c)[ST],
         const int k = wave * UW + s * 32 + (lane & 31);
         const int kbase = (((k >> 4) * 64) + (((k >> 3) & 1) * 32)) * 8 + (k & 7);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float ig = fast_sigmoid(acc[s][r]);
-            const float fg = fast_sigmoid(acc[ST + s][r]);
-            const float gg = fast_tanh(acc[2 * ST + s][r]);
-            const float og = fast_sigmoid(acc[3 * ST + s][r]);
-            const float cn = fg * c[s][r] + ig * gg;
-            c[s][r] = cn;
+        for (int r = 0; r < 16; r += 2) {                  // two cells per pass: packed fp32 math (lstm_common.h lstm_cell_pair)
+            f32x2 cc{c[s][r], c[s][r + 1]};
+            const f32x2 h = lstm_cell_pair(f32x2{acc[s][r], acc[s][r + 1]}, f32x2{acc[ST + s][r], acc[ST + s][r + 1]},
+                                           f32x2{acc[2 * ST + s][r], acc[2 * ST + s][r + 1]},
+                                           f32x2{acc[3 * ST + s][r], acc[3 * ST + s][r + 1]}, cc);
+            c[s][r] = cc.x; c[s][r + 1] = cc.y;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             unsigned short hi, lo;
-            bf3_split(og * fast_tanh(cn), hi, lo);
+            bf3_split(h.x, hi, lo);
             Hhi[kbase + row * 8] = hi;
             Hlo[kbase + row * 8] = lo;
+            bf3_split(h.y, hi, lo);
+            Hhi[kbase + (row + 1) * 8] = hi;
+            Hlo[kbase + (row + 1) * 8] = lo;
         }
     }
 }
