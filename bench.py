@@ -221,7 +221,7 @@ def main():
             return dt, tm, o
 
         pipelined = bool(args.pipeline) and not args.wave
-        alt_elapsed, _, _ = timed_loop(not pipelined) if not (args.wave or args.no_alt) else (None, None, None)
+        alt_elapsed, alt_timing, _ = timed_loop(not pipelined) if not (args.wave or args.no_alt) else (None, None, None)
         elapsed, timing, out = timed_loop(pipelined)
 
     rank_ms = None
@@ -288,6 +288,9 @@ def main():
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
+                     # the same stage in the OTHER loop (in the serving loop it runs beside the previous forward's remainder
+                     # chunk, which owns 48 CUs; back to back it has the chip to itself)
+                     "alt_fullband_ms": None if alt_timing is None else alt_timing["fullband_ms"] / max(alt_timing["count"], 1),
                      "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
     }
     if gather_ms is not None:

@@ -478,7 +478,7 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
             if (h->occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
         // role-split K split: 2 S workgroups per row tile, LSTM only; not in the pipelined loop, where the chunk runs beside the
         // next forward's full-band stages and twice the CUs for 15 % less time is a bad trade (auto mode)
-        if (occ == 1 && !h->gru && (h->coop_split == 2 || (h->coop_split == 1 && !h->pipeline)))
+        if (occ == 1 && !h->gru && (h->coop_split >= 2 || (h->coop_split == 1 && !h->pipeline)))      // (3 = auto, also when pipelined: tuning)
             for (int u = 8; u <= 64; u *= 2)
                 if (h->H % u == 0 && slots / (2 * (h->H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h->H / u)), 0});
     }
@@ -1001,7 +1001,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
     const char* csp = getenv("FSNP_COOP_SPLIT");
-    if (csp && csp[0] >= '0' && csp[0] <= '2') h->coop_split = csp[0] - '0';
+    if (csp && csp[0] >= '0' && csp[0] <= '3') h->coop_split = csp[0] - '0';
     h->coop_split_cfg = h->coop_split;
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
