@@ -207,6 +207,17 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
     }
     const float wfc0 = w.wfc[unit], wfc1 = w.wfc[HID + unit];
     const int rowbase = 4 * (lane >> 5);
+    // cells q, q + 1 of this lane (rows row, row + 1 of its unit): gate pre-activations = accumulator + bias; state in `c`
+    auto cell_pair = [&](const f32x16 (&acc)[4], int q, const float (&b)[4], float (&c)[16]) -> f32x2 {
+        const f32x2 x0 = f32x2{acc[0][q], acc[0][q + 1]} + b[0], x1 = f32x2{acc[1][q], acc[1][q + 1]} + b[1];
+        const f32x2 x2 = f32x2{acc[2][q], acc[2][q + 1]} + b[2], x3 = f32x2{acc[3][q], acc[3][q + 1]} + b[3];
+        f32x2 st{c[q], c[q + 1]};
+        f32x2 h;
+        if constexpr (GRU) { h = gru_cell_pair(x0, x1, x2, x3, st); st = h; }
+        else h = lstm_cell_pair(x0, x1, x2, x3, st);
+        c[q] = st.x; c[q + 1] = st.y;
+        return h;
+    };
 
     // returns false (to every thread) once the launch is aborted: a peer never arrived (lstm_common.h: xchg_wait)
     auto inter_wg_barrier = [&](unsigned target) -> bool {
@@ -258,24 +269,11 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             coopn_loop<KGH>(acc, ws, KGX, [&](int k) -> float4 { return nload_sc1(hs[r], prv * (HIMG * 16) + k * 1024); });
             float* img = reinterpret_cast<float*>(a.coop_hx + ((size_t)rt[r] * HXT + (size_t)cur * HIMG) * 4);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float hval;
-                if constexpr (GRU) {
-                    const float rg = fast_sigmoid(acc[0][q] + b0[0]);
-                    const float zg = fast_sigmoid(acc[1][q] + b0[1]);
-                    const float ng = fast_tanh(acc[2][q] + b0[2] + rg * (acc[3][q] + b0[3]));
-                    hval = ng + zg * (c0[r][q] - ng);
-                    c0[r][q] = hval;
-                } else {
-                    const float ig = fast_sigmoid(acc[0][q] + b0[0]);
-                    const float fg = fast_sigmoid(acc[1][q] + b0[1]);
-                    const float gg = fast_tanh(acc[2][q] + b0[2]);
-                    const float og = fast_sigmoid(acc[3][q] + b0[3]);
-                    const float cn = fg * c0[r][q] + ig * gg;
-                    c0[r][q] = cn;
-                    hval = og * fast_tanh(cn);
-                }
-                xchg_store(img + a_frag_index((q & 3) + 8 * (q >> 2) + rowbase, unit), hval);
+            for (int q = 0; q < 16; q += 2) {                  // two cells per pass: packed fp32 math (lstm_common.h)
+                const f32x2 h2 = cell_pair(acc, q, b0, c0[r]);
+                const int row = (q & 3) + 8 * (q >> 2) + rowbase;
+                xchg_store(img + a_frag_index(row, unit), h2.x);
+                xchg_store(img + a_frag_index(row + 1, unit), h2.y);
             }
             if (have_next) {      // the other parity: last read in step t-1, before that step's barrier
                 float* Xf = reinterpret_cast<float*>(Xs[prv][r]);
@@ -300,29 +298,18 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             float* img = reinterpret_cast<float*>(a.coop_hx + ((size_t)rt[r] * HXT + (size_t)(2 + cur) * HIMG) * 4);
             float* part = a.coop_hx + ((size_t)rt[r] * HXT + 4 * HIMG) * 4 + ((size_t)cur * (4 * S) + ub) * 64;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float hval;
-                if constexpr (GRU) {
-                    const float rg = fast_sigmoid(acc[0][q] + b1[0]);
-                    const float zg = fast_sigmoid(acc[1][q] + b1[1]);
-                    const float ng = fast_tanh(acc[2][q] + b1[2] + rg * (acc[3][q] + b1[3]));
-                    hval = ng + zg * (c1[r][q] - ng);
-                    c1[r][q] = hval;
-                } else {
-                    const float ig = fast_sigmoid(acc[0][q] + b1[0]);
-                    const float fg = fast_sigmoid(acc[1][q] + b1[1]);
-                    const float gg = fast_tanh(acc[2][q] + b1[2]);
-                    const float og = fast_sigmoid(acc[3][q] + b1[3]);
-                    const float cn = fg * c1[r][q] + ig * gg;
-                    c1[r][q] = cn;
-                    hval = og * fast_tanh(cn);
-                }
-                const int row = (q & 3) + 8 * (q >> 2) + rowbase;
-                xchg_store(img + a_frag_index(row, unit), hval);
-                float p0 = hval * wfc0, p1 = hval * wfc1;        // partial Linear over this wave's 32 units
+            for (int q = 0; q < 16; q += 2) {
+                const f32x2 h2 = cell_pair(acc, q, b1, c1[r]);
 #pragma unroll
-                for (int m = 16; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
-                if ((lane & 31) == 0) { xchg_store(part + row, p0); xchg_store(part + 32 + row, p1); }
+                for (int e = 0; e < 2; ++e) {
+                    const float hval = e == 0 ? h2.x : h2.y;
+                    const int row = (q & 3) + 8 * (q >> 2) + rowbase + e;
+                    xchg_store(img + a_frag_index(row, unit), hval);
+                    float p0 = hval * wfc0, p1 = hval * wfc1;        // partial Linear over this wave's 32 units
+#pragma unroll
+                    for (int m = 16; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
+                    if ((lane & 31) == 0) { xchg_store(part + row, p0); xchg_store(part + 32 + row, p1); }
+                }
             }
         }
     }
