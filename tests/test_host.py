@@ -223,6 +223,31 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
                 assert l["drain"] == 0, (key, l)
 
 
+def test_groupnorm_fold_algebra_of_the_dma_sconv_gemm():
+    """The identity csrc/tcn.hip's tcn_gemm_dma_kernel<EPI_RESIDUAL> relies on (weights and constants packed by fsnp_create in
+    fsnp_abi.hip pack_tcn):  sum_k ((a_k - m) r g_k + b_k) W[n][k] + bias[n] = r * sum_k a_k (g_k W[n][k]) + c1[n] - r m c2[n]
+    with c1 = bias + sum_k b_k W, c2 = sum_k g_k W.  In fp32 with fp64-summed constants the two sides agree to < 1e-6 of the
+    output scale for a plane whose mean is a fraction of its standard deviation (what PReLU outputs look like) and the
+    cancellation in r (acc - m c2) costs ~3e-7 per unit of |mean| / sigma: still < 1e-5 at ten standard deviations."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    K, N, T = 512, 257, 128
+    for mean, bar in ((0.3, 1e-6), (10.0, 1e-5)):
+        a = (rng.standard_normal((T, K)) + mean).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        g = (1.0 + 0.3 * rng.standard_normal(K)).astype(np.float32)
+        b = (0.2 * rng.standard_normal(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        m = np.float32(a.astype(np.float64).mean())
+        r = np.float32(1.0 / np.sqrt(a.astype(np.float64).var() + 1e-8))
+        direct = (((a.astype(np.float64) - m) * r * g + b) @ W.astype(np.float64).T + bias)          # the reference's order, fp64
+        Wg = (W.astype(np.float64) * g).astype(np.float32)                                           # packed at create time
+        c1 = (bias + W.astype(np.float64) @ b).astype(np.float32)
+        c2 = (W.astype(np.float64) @ g).astype(np.float32)
+        acc = a @ Wg.T                                                                               # the GEMM, fp32
+        folded = r * acc + (c1 - (m * r) * c2)
+        assert np.abs(folded - direct).max() / np.abs(direct).max() < bar, mean
+
+
 def test_dma_gemm_lds_image_is_a_conflict_free_permutation():
     """csrc/tcn.hip tcn_gemm_dma_kernel, index arithmetic restated: the DMA writes lane-linear (piece base + 16 bytes x lane), so
     lane l of a piece FETCHES row s >> 2, k-quad (s & 3) ^ swz(row) for slot s; readers take slot row * 4 + (kq ^ swz(row)).
