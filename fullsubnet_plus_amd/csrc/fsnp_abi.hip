@@ -692,6 +692,10 @@ static int ensure_workspace(fsnp_handle* h, size_t bytes) {
     drop_graphs(h);
     if (h->ws) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes * h->ws_slots));
+    // a fresh workspace is all zeros: tcn_gemm_dma_kernel DMAs the pad columns [K, lda) of its operand planes (they meet zero
+    // weights, but NaN bit patterns left by an earlier owner of the memory would survive that); every kernel that writes a
+    // plane writes its pad columns as zeros too, so this only matters for the very first use of a region
+    FSNP_HIP_CHECK(hipMemset(h->ws, 0, bytes * h->ws_slots));
     h->ws_bytes = bytes;
     h->side_used[0] = h->side_used[1] = false;     // the synchronise above drained the side stream
     return 0;
