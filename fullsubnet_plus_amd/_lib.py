@@ -48,15 +48,18 @@ SYMBOLS = {
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),
     "fsnp_get_timing": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 4), ctypes.POINTER(c_i64 * 4), c_i32]),
     "fsnp_describe_plan": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 20), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "fsnp_reserve": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "fsnp_dump_config": (ctypes.c_int64, [c_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 24), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fsnp_debug_plan_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 20)]),
+    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 24)]),
     "fsnp_debug_set_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), c_i32]),
     "fsnp_debug_plan_rows2": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(c_i32), c_i32]),
     "fsnp_forward_flops": (ctypes.c_double, [c_vp, c_i32, c_i32, c_i32]),
     "fsnp_lstm_flops": (ctypes.c_double, [c_vp, c_i64, c_i32]),
     "fsnp_debug_lstm_profile": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64]),
+    "fsnp_debug_pp_profile": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64]),
     "fsnp_set_precision": (c_i32, [c_vp, c_i32]),
     "fsnp_check_errors": (c_i32, [c_vp]),
     "fsnp_poll_errors": (c_i32, [c_vp]),
@@ -76,7 +79,7 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 6          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 7          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

@@ -60,6 +60,7 @@ struct CostTable {
     double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
     double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
+    double pp[4];                 // ping-pong K split at 8 units (lstm_pp.hip) with 1 / 2 / 3 / 4 row tiles per group
     int calibrated;
 };
 
@@ -130,6 +131,8 @@ struct fsnp_handle {
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
     int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
     int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
+    bool pp_ok = false;          // the ping-pong K-split kernel (lstm_pp.hip) exists for this handle's sub-band model
+    int coop_pp = 0, coop_pp_cfg = 0;   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
     int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups
                                  // per row tile), 0 = never, 2 = wherever it fits (FSNP_COOP_SPLIT, tuning)
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
@@ -164,6 +167,9 @@ struct fsnp_handle {
     hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
     bool side_used[2] = {false, false};
     unsigned char* last_base = nullptr;   // workspace half of the last forward (fsnp_read_stage)
+    hipEvent_t ev_done = nullptr;         // end of the last forward on its stream: a forward on another stream waits for it
+    hipStream_t done_stream = nullptr;
+    bool done_valid = false;
 };
 
 namespace fsnp {
@@ -417,6 +423,21 @@ static CostTable default_costs() {
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
     t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 108.0;
+    // round 3 (profiles/r03_column_split.md): ping-pong K split, a full launch of 5 groups with 1 / 2 / 3 / 4 row tiles each (measured)
+    const double pp[4] = {9.1, 15.5, 22.9, 30.4};
+    for (int i = 0; i < 4; ++i) t.pp[i] = pp[i];
+    return t;
+}
+// the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
+static CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
+    CostTable t = default_costs();
+    if (gru) t.rowtile *= 0.75;   // three of the four gate tiles per k-group
+    if (sb_hidden != 384 && !sb_tcn) {     // scale by the work per step
+        const double f = sb_hidden / 384.0;
+        for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; t.pp[i] *= f; }
+        for (int i = 0; i < 2; ++i) { t.coopn[i][0] *= f; t.coopn[i][1] *= f; }
+        t.rowtile *= f * f;
+    }
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
@@ -428,6 +449,7 @@ static const double kSplitRatio[4] = {0.85, 1.0, 1.1, 1.25};
 static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) {
     if (c.kind == 1) return c.num_tiles * (h->H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
     if (c.kind == 2) return c.groups * (h->H / 128);
+    if (c.kind == 6) return cdiv(c.num_tiles, c.rpg) * (h->H / 8);
     return c.num_tiles;
 }
 static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
@@ -449,6 +471,7 @@ static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
         return h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
     }
     if (c.kind == 2) return h->cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
+    if (c.kind == 6) return h->cost.pp[(c.num_tiles < c.rpg ? c.num_tiles : c.rpg) - 1];      // a step lasts as long as the fullest group's turn
     if (c.kind == 4) return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile16;
     return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
 }
@@ -481,9 +504,12 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
         if (occ == 1 && !h->gru && (h->coop_split >= 2 || (h->coop_split == 1 && !h->pipeline)))      // (3 = auto, also when pipelined: tuning)
             for (int u = 8; u <= 64; u *= 2)
                 if (h->H % u == 0 && slots / (2 * (h->H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h->H / u)), 0});
+        // ping-pong K split (lstm_pp.hip): groups of H / 8 workgroups, 1..4 row tiles per group
+        if (occ == 1 && h->pp_ok && h->coop_pp && slots / (h->H / 8) > 0)
+            for (int rpg = 1; rpg <= 4; ++rpg) shapes.push_back({6, 8, rpg, (slots / (h->H / 8)) * rpg, 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
-        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
+        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
         return est_step_us(h, c) + 1.2;                         // + a launch (prologue / drain, amortised over ~100 steps): fewer chunks win near-ties
     };
     std::vector<double> best(T + 1, 0.0);
@@ -510,7 +536,7 @@ static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nro
     for (const auto& tk : taken) {
         const Shape& sh = shapes[tk.second];
         const int rows = tk.first * 32 < left ? tk.first * 32 : left;
-        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
+        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
         out.push_back(c);
         r0 += rows; left -= rows;
     }
@@ -521,7 +547,7 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
         c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2) p.coop_tiles += c.num_tiles;
+        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 6) p.coop_tiles += c.num_tiles;
         p.chunks.push_back(c);
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
@@ -614,10 +640,11 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
         {
             const int S = c.kind == 1 ? (h->H / c.units) * (c.rpg ? 2 : 1) : h->H / 128, T = c.kind == 1 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
-            ca.coop_xcd = xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
+            ca.coop_xcd = c.kind != 6 && xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
-            if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
+            if (c.kind == 6) launch_lstm_pp(h->lw, ca, s);
+            else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
         });
     }
@@ -685,19 +712,41 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     return w;
 }
 
-// h->ws holds h->ws_slots (1, or 2 in pipelined mode) halves of h->ws_bytes each
-static int ensure_workspace(fsnp_handle* h, size_t bytes) {
+// h->ws holds h->ws_slots (1, or 2 in pipelined mode) halves of h->ws_bytes each.  Growth is STREAM-ORDERED on the caller's
+// stream (hipMallocAsync / hipFreeAsync from the device's default pool): no device-wide synchronisation, so a serving loop
+// whose clip lengths vary never stalls other streams while it climbs to its high-water mark (fsnp_reserve jumps there at once).
+// The old buffer is released behind everything that may still read it: earlier forwards on `s` (in order), their deferred
+// chunks on the side stream (an event), forwards on another stream (forward_impl orders `s` behind them before it gets here).
+static int ensure_workspace(fsnp_handle* h, size_t bytes, hipStream_t s) {
     bytes = align_up(bytes, 4096);
     if (bytes <= h->ws_bytes) return 0;
     drop_graphs(h);
-    if (h->ws) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws), bytes * h->ws_slots));
+    unsigned char* nw = nullptr;
+    FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&nw), bytes * h->ws_slots, s));
     // a fresh workspace is all zeros: tcn_gemm_dma_kernel DMAs the pad columns [K, lda) of its operand planes (they meet zero
     // weights, but NaN bit patterns left by an earlier owner of the memory would survive that); every kernel that writes a
     // plane writes its pad columns as zeros too, so this only matters for the very first use of a region
-    FSNP_HIP_CHECK(hipMemset(h->ws, 0, bytes * h->ws_slots));
+    FSNP_HIP_CHECK(hipMemsetAsync(nw, 0, bytes * h->ws_slots, s));
+    if (h->ws) {
+        for (int k = 0; k < 2; ++k)
+            if (h->side_used[k]) FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_side[k], 0));
+        FSNP_HIP_CHECK(hipFreeAsync(h->ws, s));
+    }
+    h->ws = nw;
     h->ws_bytes = bytes;
-    h->side_used[0] = h->side_used[1] = false;     // the synchronise above drained the side stream
+    h->side_used[0] = h->side_used[1] = false;     // `s` is ordered behind the side stream's work on the old buffer
+    h->have_last = false;
+    return 0;
+}
+// Orders `s` behind the last forward of this handle if that ran on ANOTHER stream (the workspace is shared by all of them)
+static int order_after_last_forward(fsnp_handle* h, hipStream_t s) {
+    if (h->done_valid && h->done_stream != s) FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_done, 0));
+    return 0;
+}
+static int mark_forward_done(fsnp_handle* h, hipStream_t s) {
+    if (!h->ev_done) FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    FSNP_HIP_CHECK(hipEventRecord(h->ev_done, s));
+    h->done_stream = s; h->done_valid = true;
     return 0;
 }
 
@@ -753,7 +802,8 @@ static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, fl
     const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
     const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 2 * 4, 256);
     const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
-    if (ensure_workspace(h, coop_off + coop_bytes)) return 4;
+    if (order_after_last_forward(h, s)) return 4;
+    if (ensure_workspace(h, coop_off + coop_bytes, s)) return 4;
     if (h->pipeline && h->side_stream) FSNP_HIP_CHECK(hipStreamSynchronize(h->side_stream));   // slot 0 may still be read
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
@@ -766,7 +816,7 @@ static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, fl
                    reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes),
                    reinterpret_cast<unsigned*>(h->ws + coop_off + coop_hx_bytes + coop_bar_bytes), s);
     FSNP_HIP_CHECK(hipGetLastError());
-    return 0;
+    return mark_forward_done(h, s);
 }
 
 // ---- calibration of the planner's cost table: once per process and (device, cell, sizes), on the first call that plans.
@@ -797,10 +847,13 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         auto it = g_cal_cache.find(key);
         if (it != g_cal_cache.end()) {
             if (measured) *measured = it->second;
-            if (adopt) h->cost = it->second;
+            if (adopt) { h->cost = it->second; drop_graphs(h); }
             return 0;
         }
     }
+    // the timing launches overwrite the handle's workspace from a private stream: nothing of an earlier forward may still be
+    // in flight on the caller's streams (ensure_workspace only synchronises when it grows)
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
     const int S3 = h->H / 128, occ = h->coop_occ >= 2 ? 2 : 1;
     const int steps_a = 8, steps_b = 40;
     const int max_tiles = std::max(h->num_cus_real, (h->num_cus_real * occ / S3) * 2);
@@ -834,7 +887,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     auto time_shape = [&](SbChunk c) -> double {
         c.row0 = 0; c.nrows = c.num_tiles * c.rps; c.slot0 = 0; c.coop_tile0 = 0;
         SbPlan plan;
-        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2) ? c.num_tiles : 0;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 6) ? c.num_tiles : 0;
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
@@ -878,6 +931,12 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         if (us0 < 0) rc = 4;
         else t.rowtile = us0;           // the VALU-row surcharge keeps its measured ratio (0.11 per row)
     }
+    for (int rpg = 1; rpg <= 4 && rc == 0 && h->pp_ok; ++rpg) {
+        const int groups = h->num_cus_real / (h->H / 8);
+        if (groups <= 0) break;
+        const double us = time_shape(SbChunk{6, 0, 0, groups * rpg, 0, 32, 8, groups, rpg, 0, 0});
+        if (us < 0) rc = 4; else t.pp[rpg - 1] = us;
+    }
     if (rc == 0 && h->lstm16_ok) {
         const double us16 = time_shape(SbChunk{4, 0, 0, h->num_cus_real, 0, 16, 0, 0, 0, 0, 0});
         if (us16 < 0) rc = 4; else t.rowtile16 = us16;
@@ -893,7 +952,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     }
     t.calibrated = 1;
     if (measured) *measured = t;
-    if (adopt) h->cost = t;
+    if (adopt) { h->cost = t; drop_graphs(h); }
     std::lock_guard<std::mutex> lk(g_cal_mu);
     g_cal_cache[key] = t;
     return 0;
@@ -976,14 +1035,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         const char* e16 = getenv("FSNP_LSTM16");           // 0 = never plan the half-tile kernel
         h->lstm16_ok = !(e16 && e16[0] == '0') && !h->gru && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384 && nin <= 40;
     }
-    h->cost = default_costs();
-    if (h->gru) h->cost.rowtile *= 0.75;   // three of the four gate tiles per k-group
-    if (cfg->sb_hidden != 384 && cfg->sequence_model != FSNP_SEQ_TCN) {     // the table is measured at 384: scale by the work per step
-        const double f = cfg->sb_hidden / 384.0;
-        for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] *= f; h->cost.ksplit[i][1] *= f; h->cost.ksplit1[i] *= f; }
-        for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] *= f; h->cost.coopn[i][1] *= f; }
-        h->cost.rowtile *= f * f;
-    }
+    h->cost = initial_costs(cfg->sb_hidden, h->gru, cfg->sequence_model == FSNP_SEQ_TCN);
     const char* ce = getenv("FSNP_CALIBRATE");
     if (ce && ce[0] == '1') h->calibrate = 1;
     const char* oe = getenv("FSNP_COOP_OCC");          // 1 = never plan two column-split workgroups per CU
@@ -1007,6 +1059,15 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     const char* csp = getenv("FSNP_COOP_SPLIT");
     if (csp && csp[0] >= '0' && csp[0] <= '3') h->coop_split = csp[0] - '0';
     h->coop_split_cfg = h->coop_split;
+    {
+        // The ping-pong K-split kernel (lstm_pp.hip) is OPT-IN (FSNP_COOP_PP=1): measured (profiles/r03_column_split.md) it only
+        // beats the round-2 kernels at exactly 10 row tiles (15.7 vs 16.7 us per step); everywhere else its fixed cost per
+        // tile-phase (cell phase 1.0 us, operand fetch issue 1.1 us, barriers 0.5 us on top of 4.4 us of MFMAs) loses
+        const char* pe = getenv("FSNP_COOP_PP");
+        h->coop_pp = pe && pe[0] == '1' ? 1 : 0;
+        h->coop_pp_cfg = h->coop_pp;
+        h->pp_ok = cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
+    }
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
     const char* sk = getenv("FSNP_COOP_SKEW");
@@ -1037,8 +1098,10 @@ void fsnp_destroy(fsnp_handle* h) {
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     if (h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); }
-    if (h->ws) (void)hipFree(h->ws);
-    if (h->io) (void)hipFree(h->io);
+    if (h->ws) (void)hipFreeAsync(h->ws, nullptr);        // (allocated from the stream-ordered pool; the device is idle here)
+    if (h->io) (void)hipFreeAsync(h->io, nullptr);
+    (void)hipDeviceSynchronize();
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->d_stft) (void)hipFree(h->d_stft);
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_err) (void)hipHostFree(h->d_err);
@@ -1393,7 +1456,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         return 2;
     }
     const Workspace w = plan_workspace(h, batch, frames, mode);
-    if (ensure_workspace(h, w.total)) return 4;
+    if (order_after_last_forward(h, s)) return 4;
+    if (ensure_workspace(h, w.total, s)) return 4;
     // pipelined mode: alternate between the two workspace halves; the half about to be rebuilt was last read by the
     // deferred remainder chunks of the forward before the previous one
     const int slot = h->pipeline ? h->ws_slot : 0;
@@ -1499,7 +1563,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         }
         FSNP_HIP_CHECK(hipGetLastError());
         h->last_ws = w; h->last_dims = d; h->have_last = true; h->last_base = base;
-        return 0;
+        return mark_forward_done(h, s);
     }
     LstmArgs a{};
     a.att_mag = fptr(w.att); a.fb = fptr(w.fb);
@@ -1553,7 +1617,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     }
     FSNP_HIP_CHECK(hipGetLastError());
     h->last_ws = w; h->last_dims = d; h->have_last = true; h->last_base = base;
-    return 0;
+    return mark_forward_done(h, s);
 }
 
 int fsnp_forward(fsnp_handle* h, const float* mag, const float* real, const float* imag,
@@ -1600,10 +1664,13 @@ static int ensure_stft(fsnp_handle* h) {
     FSNP_HIP_CHECK(hipMemcpy(h->d_stft, host.data(), p.total * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
-static int ensure_io(fsnp_handle* h, size_t bytes) {
+static int ensure_io(fsnp_handle* h, size_t bytes, hipStream_t s) {      // stream-ordered, like ensure_workspace
     if (bytes <= h->io_bytes) return 0;
-    if (h->io) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->io)); h->io = nullptr; h->io_bytes = 0; }
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->io), bytes));
+    if (order_after_last_forward(h, s)) return 4;
+    unsigned char* nio = nullptr;
+    FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&nio), bytes, s));
+    if (h->io) FSNP_HIP_CHECK(hipFreeAsync(h->io, s));
+    h->io = nio;
     h->io_bytes = bytes;
     return 0;
 }
@@ -1631,6 +1698,33 @@ static void istft_from(fsnp_handle* h, const StftPlan& p, const float* spec, flo
 }
 }  // namespace fsnp
 
+int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t mode, int32_t max_samples, void* hip_stream) {
+    if (!h || max_batch <= 0 || max_frames <= 0 || max_samples < 0) { set_error("fsnp_reserve: bad argument"); return 1; }
+    if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
+    if (!h->committed) { set_error("fsnp_reserve: weights not committed (the plan depends on the kernels' occupancy)"); return 2; }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    FSNP_ON_DEVICE(h);
+    if (order_after_last_forward(h, s)) return 4;
+    // every batch size up to max_batch plans its own launches (the exchange region of a column-split plan can exceed the one of
+    // the chip-filling batch): take the largest workspace over all of them - host arithmetic only
+    size_t need = 0;
+    for (int b = 1; b <= max_batch; ++b) {
+        if (mode == FSNP_MODE_PARITY && b <= h->cfg.num_groups_in_drop_band) continue;
+        need = std::max(need, plan_workspace(h, b, max_frames, mode).total);
+    }
+    if (ensure_workspace(h, need, s)) return 4;
+    if (max_samples > 0) {
+        if (ensure_stft(h)) return 2;
+        const StftPlan p = stft_plan(h);
+        const int T = 1 + max_samples / p.hop;
+        const long xs = (long)align_up((size_t)max_samples + p.n_fft, 4);
+        const size_t xp_b = align_up((size_t)max_batch * xs * 4, 256), spec_b = align_up((size_t)max_batch * T * p.sp * 4 + 256, 256);
+        const size_t mask_b = align_up((size_t)max_batch * 2 * p.F * T * 4, 256), fr_b = (size_t)max_batch * T * p.n_fft * 4;
+        if (ensure_io(h, xp_b + 2 * spec_b + mask_b + fr_b, s)) return 4;
+    }
+    return mark_forward_done(h, s);
+}
+
 int fsnp_stft(fsnp_handle* h, const float* wav, int64_t wav_stride, float* spec, int32_t batch, int32_t samples, void* hip_stream) {
     if (!h || !wav || !spec) { set_error("fsnp_stft: null argument"); return 1; }
     if (batch <= 0) { set_error("fsnp_stft: empty input"); return 2; }
@@ -1640,10 +1734,11 @@ int fsnp_stft(fsnp_handle* h, const float* wav, int64_t wav_stride, float* spec,
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_ON_DEVICE(h);
     const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
-    if (ensure_io(h, (size_t)batch * xs * 4)) return 4;
+    if (order_after_last_forward(h, s)) return 4;
+    if (ensure_io(h, (size_t)batch * xs * 4, s)) return 4;
     stft_into(h, p, wav, wav_stride, reinterpret_cast<float*>(h->io), xs, spec, p.N2, batch, samples, s);
     FSNP_HIP_CHECK(hipGetLastError());
-    return 0;
+    return mark_forward_done(h, s);
 }
 
 int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], float* wav, int64_t wav_stride, int32_t batch,
@@ -1656,7 +1751,8 @@ int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], floa
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_ON_DEVICE(h);
     const size_t spec_b = align_up((size_t)batch * frames * p.sp * 4 + 256, 256), fr_b = (size_t)batch * frames * p.n_fft * 4;
-    if (ensure_io(h, spec_b + fr_b)) return 4;
+    if (order_after_last_forward(h, s)) return 4;
+    if (ensure_io(h, spec_b + fr_b, s)) return 4;
     float* sp = reinterpret_cast<float*>(h->io);
     float* fr = reinterpret_cast<float*>(h->io + spec_b);
     const long n = (long)batch * frames * (p.sp / 2);
@@ -1664,7 +1760,7 @@ int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], floa
                        (long)strides[0], (long)strides[1], (long)strides[2], reinterpret_cast<float2*>(sp), batch, p.F, frames, p.sp / 2);
     istft_from(h, p, sp, fr, wav, wav_stride, batch, frames, samples, s);
     FSNP_HIP_CHECK(hipGetLastError());
-    return 0;
+    return mark_forward_done(h, s);
 }
 
 int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, float* out, int64_t out_stride, int32_t batch,
@@ -1681,7 +1777,8 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
     const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
     const size_t xp_b = align_up((size_t)batch * xs * 4, 256), spec_b = align_up((size_t)batch * T * p.sp * 4 + 256, 256);
     const size_t mask_b = align_up((size_t)batch * 2 * p.F * T * 4, 256), fr_b = (size_t)batch * T * p.n_fft * 4;
-    if (ensure_io(h, xp_b + 2 * spec_b + mask_b + fr_b)) return 4;
+    if (order_after_last_forward(h, s)) return 4;
+    if (ensure_io(h, xp_b + 2 * spec_b + mask_b + fr_b, s)) return 4;
     float* xp = reinterpret_cast<float*>(h->io);
     float* noisy = reinterpret_cast<float*>(h->io + xp_b);
     float* enh = reinterpret_cast<float*>(h->io + xp_b + spec_b);
@@ -1692,12 +1789,15 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
     const int64_t cst[3] = {(int64_t)T * (p.sp / 2), 1, p.sp / 2};       // complex-element strides of [B][T][sp/2] as (b, f, t)
     const int rc = fsnp_forward_complex(h, noisy, cst, mask, batch, T, FSNP_MODE_FULL, 0, batch, hip_stream);
     if (rc) return rc;
+    // pipelined mode: the forward left chunks of the sub-band plan on the side stream (at B = 1 the whole plan); `mask` is read
+    // right here and lives in the single-buffered io area, so `s` waits for them now (fsnp_flush) - nothing of this call is deferred
+    if (h->pipeline && fsnp_flush(h, hip_stream)) return 4;
     // the pad column of every row of `enh` is never written by apply_cirm and multiplies zero weights: clear it once
     FSNP_HIP_CHECK(hipMemsetAsync(enh, 0, spec_b, s));
     launch_apply_cirm(mask, noisy, cst, enh, cst, batch, p.F, T, s);
     istft_from(h, p, enh, fr, out, out_stride, batch, T, samples, s);
     FSNP_HIP_CHECK(hipGetLastError());
-    return 0;
+    return mark_forward_done(h, s);
 }
 
 int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
@@ -1785,7 +1885,10 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
         h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
         for (int i = 0; i < 4; ++i) h.cost.ksplit1[i] = costs[14 + i];
         h.cost.rowtile16 = costs[18];
+        for (int i = 0; i < 4; ++i) h.cost.pp[i] = costs[20 + i];
     }
+    h.pp_ok = gru == 0 && (hidden == 384 || hidden == 256);
+    h.coop_pp = costs != nullptr;          // (a caller's table prices the ping-pong launches in or out; the built-in plans do not use them)
     h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
@@ -1795,26 +1898,27 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
         int32_t* o = out + 8 * n;
-        o[0] = c.kind; o[1] = c.row0; o[2] = c.nrows; o[3] = c.num_tiles; o[4] = c.ex; o[5] = c.kind == 1 ? c.units : c.groups;
+        o[0] = c.kind; o[1] = c.row0; o[2] = c.nrows; o[3] = c.num_tiles; o[4] = c.ex; o[5] = c.kind == 1 ? c.units : c.groups;      // (kind 6: groups)
         o[6] = c.rpg; o[7] = c.slot0;
         ++n;
     }
     return n;
 }
 
-int fsnp_get_costs(const fsnp_handle* h, double out[20], int32_t* calibrated, int32_t* occ) {
+int fsnp_get_costs(const fsnp_handle* h, double out[24], int32_t* calibrated, int32_t* occ) {
     if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
     for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
     out[12] = h->cost.rowtile; out[13] = h->cost.rowtile_ex;
     for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
     out[18] = h->cost.rowtile16; out[19] = 0.0;
+    for (int i = 0; i < 4; ++i) out[20 + i] = h->cost.pp[i];
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
     return 0;
 }
 
-int fsnp_measure_costs(fsnp_handle* h, double out[20]) {
+int fsnp_measure_costs(fsnp_handle* h, double out[24]) {
     if (!h || !out) { set_error("fsnp_measure_costs: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_measure_costs: weights not committed"); return 2; }
     if (h->sb_tcn) { set_error("fsnp_measure_costs: the sub-band model of this handle is a TCN (no recurrent kernels)"); return 2; }
@@ -1824,19 +1928,21 @@ int fsnp_measure_costs(fsnp_handle* h, double out[20]) {
     for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
     out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16; out[19] = 0.0;
+    for (int i = 0; i < 4; ++i) out[20 + i] = t.pp[i];
     return 0;
 }
 
 int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups_per_cu) {
     if (!h || (workgroups_per_cu != 1 && workgroups_per_cu != 2)) { set_error("fsnp_debug_set_costs: bad argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_set_costs: commit the weights first (the kernels' occupancy is checked then)"); return 2; }
-    h->cost = default_costs();
+    h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
     if (costs) {
         for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] = costs[2 * i]; h->cost.ksplit[i][1] = costs[2 * i + 1]; }
         for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] = costs[8 + 2 * i]; h->cost.coopn[i][1] = costs[9 + 2 * i]; }
         h->cost.rowtile = costs[12]; h->cost.rowtile_ex = costs[13];
         for (int i = 0; i < 4; ++i) h->cost.ksplit1[i] = costs[14 + i];
         h->cost.rowtile16 = costs[18];
+        for (int i = 0; i < 4; ++i) h->cost.pp[i] = costs[20 + i];
     }
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
@@ -1850,7 +1956,9 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind); out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;   // (kind 4 = half-tile kernel)
+        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind);
+        out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
     return n;
@@ -1866,7 +1974,8 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     const LstmPlan lp = plan_lstm_tiles(num_seq, h->num_cus);
     const int num_slots = lp.num_tiles * lp.rows_per_slot_tile;
     const size_t stamp_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
-    if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8)) return 4;
+    if (ensure_workspace(h, stamp_off + ((size_t)num_stamps + (size_t)lp.num_tiles * 256) * 8, nullptr)) return 4;
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
     h->have_last = false;
@@ -1880,6 +1989,37 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     FSNP_HIP_CHECK(hipDeviceSynchronize());
     FSNP_HIP_CHECK(hipMemcpy(host_stamps, dprof, (size_t)num_stamps * 8, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
+                          uint64_t* host_stamps, int64_t num_stamps) {
+    if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_pp_profile: null argument"); return 1; }
+    if (!h->committed || !h->pp_ok) { set_error("fsnp_debug_pp_profile: no ping-pong K-split kernel for this handle"); return 2; }
+    if (tiles_per_group < 1 || tiles_per_group > 4 || num_stamps != (int64_t)steps * tiles_per_group * 8) { set_error("fsnp_debug_pp_profile: need steps * tiles_per_group * 8 stamps"); return 2; }
+    const int tiles = cdiv(num_seq, 32), groups = cdiv(tiles, tiles_per_group);
+    if (num_seq <= 0 || groups * (h->H / 8) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
+    FSNP_ON_DEVICE(h);
+    SbPlan plan;
+    plan.chunks = {SbChunk{6, 0, num_seq, tiles, 0, 32, 8, groups, tiles_per_group, 0, 0}};
+    plan.total_slots = tiles * 32; plan.coop_tiles = tiles;
+    const size_t rows_b = align_up((size_t)plan.total_slots * sizeof(RowDesc), 256), hx_b = align_up(lstm_coop_exchange_bytes(h->H, tiles), 256);
+    const size_t bar_b = align_up((size_t)tiles * 2 * 4, 256), st_b = (size_t)num_stamps * 8;
+    if (order_after_last_forward(h, nullptr)) return 4;
+    if (ensure_workspace(h, rows_b + hx_b + bar_b + 256 + st_b, nullptr)) return 4;
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
+    h->have_last = false;
+    RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
+    FSNP_HIP_CHECK(hipMemsetAsync(h->ws + rows_b, 0, hx_b + bar_b + 256 + st_b, nullptr));
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, nullptr);
+    LstmArgs a{};
+    a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
+    a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
+    a.prof = reinterpret_cast<unsigned long long*>(h->ws + rows_b + hx_b + bar_b + 256);
+    launch_sb_lstm(h, plan, a, reinterpret_cast<float*>(h->ws + rows_b), reinterpret_cast<unsigned*>(h->ws + rows_b + hx_b),
+                   reinterpret_cast<unsigned*>(h->ws + rows_b + hx_b + bar_b), nullptr);
+    FSNP_HIP_CHECK(hipDeviceSynchronize());
+    FSNP_HIP_CHECK(hipMemcpy(host_stamps, a.prof, st_b, hipMemcpyDeviceToHost));
+    return fsnp_check_errors(h);
 }
 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
@@ -1922,7 +2062,7 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable) {
         for (auto& e : h->ev_side) FSNP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     drop_graphs(h);
-    if (h->ws) { FSNP_HIP_CHECK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    if (h->ws) { FSNP_HIP_CHECK(hipFreeAsync(h->ws, nullptr)); FSNP_HIP_CHECK(hipDeviceSynchronize()); h->ws = nullptr; h->ws_bytes = 0; }
     h->have_last = false;
     h->pipeline = enable;
     h->ws_slots = enable ? 2 : 1;
@@ -1955,6 +2095,51 @@ int fsnp_check_errors(fsnp_handle* h) {
     return 0;
 }
 
+int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
+    if (!h) { set_error("null handle"); return -1; }
+    auto env = [](const char* n) { const char* e = getenv(n); return e ? e : "(unset)"; };
+    std::string o;
+    char line[512];
+    auto add = [&](const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(line, sizeof(line), fmt, ap);
+        va_end(ap);
+        o += line;
+    };
+    add("%s, ABI %d, device %d (%d CUs; planner sees %d)\n", fsnp_version(), FSNP_ABI_VERSION, h->device, h->num_cus_real, h->num_cus);
+    add("model=%s num_freqs=%d look_ahead=%d sb_hidden=%d tcn_hidden=%d sub-band inputs=%d (kernels instantiated for K=%d) sequence_model=%s norm_type=%d attention=%d subband_num=%d\n",
+        h->model == FSNP_MODEL_FULLSUBNET ? "FullSubNet" : "FullSubNet+", h->F, h->cfg.look_ahead, h->H, h->CH, h->NIN, h->KX,
+        h->sb_tcn ? "TCN" : h->gru ? "GRU" : "LSTM", h->cfg.norm_type, h->cfg.attention, h->cfg.subband_num > 0 ? h->cfg.subband_num : 1);
+    add("weights committed=%d precision=%d (0 fp32, 1 bf16 ih-GEMM, 2 split-bf16) pipeline=%d timing=%d workspace=%zu bytes x %d\n",
+        (int)h->committed, h->ih_bf16, h->pipeline, (int)h->timing, h->ws_bytes, h->ws_slots);
+    add("effective settings (environment variable as read at fsnp_create = value in force):\n");
+    add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
+    add("  FSNP_COOP_PP=%s -> ping-pong K split (lstm_pp.hip) %s\n", env("FSNP_COOP_PP"), !h->pp_ok ? "not built for this model" : h->coop_pp ? "planned" : "never");
+    add("  FSNP_COOP_SKEW=%s -> K-split schedule %s\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed from 16 units up" : "serial");
+    add("  FSNP_COOP_SPLIT=%s -> role-split K split mode %d (0 never, 1 auto outside the pipelined loop, 2 wherever it fits, 3 auto also pipelined)\n", env("FSNP_COOP_SPLIT"), h->coop_split);
+    add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
+    add("  FSNP_COOP_XCD=%s (0 = no XCD-local workgroup placement)  FSNP_OWN_CU=%s (0 = deferred chunks do not claim their CUs' LDS)\n", env("FSNP_COOP_XCD"), env("FSNP_OWN_CU"));
+    add("  FSNP_LSTM16=%s -> half-tile kernel %s\n", env("FSNP_LSTM16"), h->lstm16_ok ? "planned" : "not used");
+    add("  FSNP_LSTM_WAVES=%s -> %d (0 = auto)\n", env("FSNP_LSTM_WAVES"), h->lstm_waves);
+    add("  FSNP_CALIBRATE=%s -> cost table %s\n", env("FSNP_CALIBRATE"), h->cost.calibrated ? "measured / pinned" : h->calibrate ? "to be measured at the first plan" : "built-in");
+    add("  FSNP_COMPOSITE_GAIN=%s -> %.3f\n", env("FSNP_COMPOSITE_GAIN"), h->composite_gain);
+    add("  FSNP_DEFER_SMALL=%s -> %d  FSNP_SIDE_PRIO=%s\n", env("FSNP_DEFER_SMALL"), h->defer_small, env("FSNP_SIDE_PRIO"));
+    add("  FSNP_GRAPH=%s -> %d (0 plain launches, 1 / 2 hipGraph replay of the full-band stages)\n", env("FSNP_GRAPH"), h->use_graph);
+    add("  FSNP_GEMM_DMA=%s -> %d  FSNP_GEMM_BN=%s FSNP_GEMM_PF=%s (tuning of the general GEMM kernel)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma, env("FSNP_GEMM_BN"), env("FSNP_GEMM_PF"));
+    add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
+    add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, ping-pong %.1f / %.1f / %.1f / %.1f\n",
+        h->cost.ksplit[0][0], h->cost.ksplit[1][0], h->cost.ksplit[2][0], h->cost.ksplit[3][0], h->cost.ksplit1[0], h->cost.ksplit1[1],
+        h->cost.ksplit1[2], h->cost.ksplit1[3], h->cost.coopn[0][0], h->cost.coopn[1][0], h->cost.rowtile, h->cost.rowtile_ex, h->cost.rowtile16,
+        h->cost.pp[0], h->cost.pp[1], h->cost.pp[2], h->cost.pp[3]);
+    if (buf && cap > 0) {
+        const size_t n = o.size() < (size_t)cap - 1 ? o.size() : (size_t)cap - 1;
+        memcpy(buf, o.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)o.size() + 1;
+}
+
 int fsnp_debug_inject_error(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
     *reinterpret_cast<volatile unsigned*>(h->d_err) = 1u;
@@ -1975,12 +2160,14 @@ int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto) or 2 (auto, serial K-split schedule)"); return 1; }
+    if (!h || mode < 0 || mode > 3) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule) or 3 (auto + the ping-pong K split)"); return 1; }
     h->lstm_coop = mode != 0;
-    h->coop_skew = mode == 1;
-    h->coop_split = mode == 1 ? h->coop_split_cfg : 0;
+    h->coop_skew = mode == 1 || mode == 3;
+    h->coop_split = mode == 1 || mode == 3 ? h->coop_split_cfg : 0;
+    h->coop_pp = mode == 3 ? 1 : mode == 1 ? h->coop_pp_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
-    if (!h->cost.calibrated) { const int occ = h->coop_occ; h->cost = default_costs(); if (h->gru) h->cost.rowtile *= 0.75; h->coop_occ = occ; }
+    if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
+    drop_graphs(h);            // a captured chain holds row descriptors / a zero region laid out for the old plan
     return 0;
 }
 

@@ -199,7 +199,7 @@ struct LstmArgs {
     int coop_own_cu;           // lstm_coop.hip: > 0 = claim this many bytes of dynamic LDS (the whole CU's) so that no workgroup of a
                                // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
-    int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2
+    int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2; lstm_pp.hip: 1..4 row tiles per group
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
@@ -226,6 +226,10 @@ size_t lstm_coop_pack_floats(int H, int KX, int units);
 void lstm_coop_pack_weights(int H, int NIN, int KX, int units, const float* wih0, const float* whh0, const float* wih1,
                             const float* whh1, float* wpack);
 size_t lstm_coop_exchange_bytes(int H, int row_tiles);
+// lstm_pp.hip: K split at 8 units per workgroup, fused two-layer phase, a.coop_rows_per_group (1..4) independent row tiles per
+// group of H / 8 workgroups worked on in turn (hand-off latency of one tile hidden behind the others); weights = wpack_coop[0]
+void launch_lstm_pp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+bool lstm_pp_available(const LstmWeights& w);
 // lstm_coopn.hip: 3 workgroups x 128 hidden units share 1-2 row tiles (43..170 row tiles)
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_coopn_pack_floats(int H, int KX);

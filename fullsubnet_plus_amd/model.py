@@ -164,7 +164,18 @@ class _HipModel(nn.Module):
         self._hip = _HipState()
 
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # (storage pointer, version) of every parameter: changes on load_state_dict, .to(), in-place updates.  The parameter
+        # LIST is cached - walking the module tree (340 parameters) was 0.56 ms per forward, a quarter of a B = 1 step - and
+        # rebuilt whenever _apply (.to / .float / .cuda ...) may have replaced Parameter objects.
+        plist = self.__dict__.get("_fsnp_plist")
+        if plist is None:
+            plist = list(self.parameters())
+            self.__dict__["_fsnp_plist"] = plist
+        return tuple([(p.data_ptr(), p._version) for p in plist])
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_fsnp_plist", None)
+        return super()._apply(fn, *args, **kwargs)
 
     def _ensure_handle(self, device):
         lib = _lib.load()
@@ -265,13 +276,16 @@ class _HipModel(nn.Module):
         msg = _lib.last_error()
         import warnings
         warnings.warn(f"fullsubnet_plus_amd: {msg}; re-running this batch on the one-tile-per-CU kernel", RuntimeWarning)
+        prev = self.__dict__.get("_lstm_coop_mode", 1)
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, 0), "fsnp_debug_set_lstm_coop")
         try:
             out = run()
+            if self._pipeline:
+                self.flush()        # a model without a one-tile-per-CU kernel still defers its column-split chunks
             torch.cuda.current_stream(device).synchronize()
             _lib.check(lib.fsnp_poll_errors(self._handle), "fsnp_forward (retry)")
         finally:
-            lib.fsnp_debug_set_lstm_coop(self._handle, 1)
+            lib.fsnp_debug_set_lstm_coop(self._handle, prev)      # the mode the caller had set (debug_set_lstm_coop), not always 1
         return out
 
     def poll_errors(self):
@@ -284,6 +298,18 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_set_pipeline(self._handle, int(bool(enable))), "fsnp_set_pipeline")
         self._pipeline = bool(enable)
+
+    def reserve(self, max_batch, max_frames, max_samples=0, device="cuda"):
+        """Grow the handle's workspace once to what any forward of <= max_batch utterances x max_frames frames needs (and the
+        STFT / iSTFT area of enhance_wave for max_samples samples per utterance): a serving loop with varying clip lengths then
+        never re-allocates (fsnp_reserve; stream-ordered on the current stream, no device synchronisation)."""
+        dev = _resolve_device(device)
+        lib = self._ensure_handle(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        mode = _lib.MODE_PARITY if (self.batch_mode == "parity" and max_batch > 1 and self.num_groups_in_drop_band > 1) else _lib.MODE_FULL
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsnp_reserve(self._handle, int(max_batch), int(max_frames), mode, int(max_samples), ctypes.c_void_p(stream)),
+                       "fsnp_reserve")
 
     def flush(self):
         """Order the current stream after every deferred launch of earlier forwards (fsnp_flush)."""
@@ -311,6 +337,8 @@ class _HipModel(nn.Module):
             mask = self.forward_complex(noisy_complex)
         finally:
             self.batch_mode = mode
+        if self._pipeline:
+            self.flush()            # the mask's deferred rows (pipelined mode) are complete on this stream only after a flush
         return self._apply_cirm(mask, noisy_complex)
 
     # ------------------------------------------------------------------ STFT / iSTFT in HIP
@@ -411,9 +439,11 @@ class _HipModel(nn.Module):
 
     def debug_set_lstm_coop(self, mode, device="cuda"):
         """Tuning hook: 1 = use the column-split LSTM kernels for small batches (default), 0 = never, 2 = as 1 with the
-        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one."""
+        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one, 3 = as 1 + the opt-in ping-pong
+        K split (csrc/lstm_pp.hip) where the cost table prefers it."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
+        self.__dict__["_lstm_coop_mode"] = int(mode)
 
     def debug_set_gemm_dma(self, mode, device="cuda"):
         """Tuning hook: 1 = full-band TCN GEMMs on the LDS-DMA kernel with GroupNorm folded into the weights (default),
@@ -463,33 +493,52 @@ class _HipModel(nn.Module):
                  1: "lstm2_coop_kernel (K split)",
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
-                 5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)"}
+                 5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
+                 **{6 + r: f"lstm2_coop_pp_kernel (K split, fused phase, {r} row tile{'s' if r > 1 else ''} per group in turn)" for r in (1, 2, 3, 4)}}
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
-        """Test hook: pin the planner's cost table (20 values, fsnp_get_costs order; None = built-in) and whether it may put
-        two column-split workgroups on a CU (fsnp_debug_set_costs)."""
+        """Test hook: pin the planner's cost table (24 values, fsnp_get_costs order; None = built-in) and whether it may put
+        two column-split workgroups on a CU (fsnp_debug_set_costs).  A 20-value table (the round-2 layout) prices the
+        ping-pong K-split launches (values 20..23) out of every plan."""
         lib = self._ensure_handle(_resolve_device(device))
-        arr = (ctypes.c_double * 20)(*costs) if costs is not None else None
+        if costs is not None and len(costs) == 20:
+            costs = list(costs) + [1e9] * 4
+        arr = (ctypes.c_double * 24)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
     @staticmethod
     def _cost_dict(v):
         return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
-                "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18]}
+                "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18],
+                "pingpong_us": {r: v[19 + r] for r in (1, 2, 3, 4)}}
 
     def measure_costs(self):
         """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""
-        buf = (ctypes.c_double * 20)()
+        buf = (ctypes.c_double * 24)()
         with torch.cuda.device(self._hip.device):
             _lib.check(_lib.load().fsnp_measure_costs(self._handle, ctypes.byref(buf)), "fsnp_measure_costs")
         return self._cost_dict(list(buf))
 
+    def dump_config(self):
+        """-> text: the handle's configuration and every effective FSNP_* setting (fsnp_dump_config), for bug reports."""
+        lib = _lib.load()
+        n = lib.fsnp_dump_config(self._handle, None, 0)
+        buf = ctypes.create_string_buffer(int(n))
+        lib.fsnp_dump_config(self._handle, buf, n)
+        return buf.value.decode()
+
+    def planner_costs_raw(self):
+        """-> the 24 values of fsnp_get_costs (the layout debug_set_costs takes)."""
+        buf = (ctypes.c_double * 24)()
+        _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), None, None), "fsnp_get_costs")
+        return list(buf)
+
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
-        buf, cal, occ = (ctypes.c_double * 20)(), ctypes.c_int32(), ctypes.c_int32()
+        buf, cal, occ = (ctypes.c_double * 24)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
         return {**self._cost_dict(list(buf)), "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 

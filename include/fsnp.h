@@ -121,6 +121,13 @@ int fsnp_weight_info(const fsnp_handle* h, int index, const char** name, int64_t
 
 /* Device workspace (owned by the handle, grown on demand) needed for a [B,T] forward. */
 size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
+/* Grows the workspace ONCE to what any forward of up to max_batch utterances x max_frames frames needs (and, if max_samples
+ * > 0, the STFT / iSTFT area of fsnp_enhance_wave for that many samples per utterance), so that a serving loop with varying
+ * clip lengths never re-allocates.  The reference has no counterpart (torch's caching allocator plays this role for
+ * `self.model(...)`, inferencer.py:150).  Like every growth of the workspace inside fsnp_forward it is STREAM-ORDERED on
+ * `hip_stream` (hipMallocAsync / hipFreeAsync): no device-wide synchronisation, other streams keep running.  Needs
+ * committed weights. */
+int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t mode, int32_t max_samples, void* hip_stream);
 
 /* Replaces `self.model(noisy_mag, noisy_real, noisy_imag)` (inferencer.py:150;
  * FullSubNet_Plus.forward fullsubnet_plus.py:122-209).
@@ -193,10 +200,16 @@ int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t n
  * see fsnp_describe_plan). */
 int fsnp_set_timing(fsnp_handle* h, int32_t enable);
 int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t reset);
+/* For bug reports: a text dump of the handle's configuration and of EVERY effective FSNP_* setting (the environment variables
+ * are read at fsnp_create; the value in force is printed next to each).  Writes at most cap bytes (NUL-terminated) into buf
+ * and returns the size the full text needs (call with buf = NULL to ask); < 0 on error. */
+int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
  *  half-tile: 16-row tiles, csrc/lstm16.hip, 5 = lstm2_coop_split K-split with one workgroup set per layer: planned for 1-2 row
- *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never),
+ *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never, 7..10 = lstm2_coop_pp K-split at 8 units
+ *  with the two layers fused into one phase and 1..4 row tiles per group of H / 8 workgroups worked on in turn, csrc/lstm_pp.hip;
+ *  FSNP_COOP_PP=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
@@ -212,11 +225,12 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
  * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
  * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
  * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
-int fsnp_get_costs(const fsnp_handle* h, double out[20], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel */
-int fsnp_measure_costs(fsnp_handle* h, double out[20]);
+int fsnp_get_costs(const fsnp_handle* h, double out[24], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel,
+                                                                                                out[20..23] = ping-pong K split, 1..4 row tiles per group */
+int fsnp_measure_costs(fsnp_handle* h, double out[24]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
- * (kernel 1) or groups (kernel 2), row tiles per group, first slot}.  Used by the CPU tests. */
+ * (kernel 1) or groups (kernel 2, 6), row tiles per group, first slot}; kernel 6 = the ping-pong K split.  Used by the CPU tests. */
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks);
 
@@ -234,6 +248,12 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 
+/* Profiling hook of the ping-pong K-split kernel (csrc/lstm_pp.hip): num_seq sequences as ONE launch with tiles_per_group row
+ * tiles per group; workgroup 0 stamps the 100 MHz wall clock at 7 points of every tile-phase (0 pass start, 1 MFMA pass done,
+ * 2 past the barrier, 3 partial tiles in LDS, 4 cell phase done, 5 past the barrier, 6 published / next operands issued) and
+ * [7] = 1 if the next tile-phase's operands were fetched early.  host_stamps: steps * tiles_per_group * 8 values.  Synchronises. */
+int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
+                          uint64_t* host_stamps, int64_t num_stamps);
 /* Profiling hook: fsnp_lstm2_fc on the default stream + s_memtime stamps of workgroup 0 at 8 points of
  * every step (0 step start, 1 layer-0 MFMA done, 2 past barrier, 3 cell-0/x/FC done, 4 past barrier,
  * 5 layer-1 MFMA done, 6 past barrier, 7 cell-1 done).  host_stamps receives steps*8 values. Synchronises. */
@@ -284,7 +304,9 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * cut); 0 = the one-tile-per-CU kernel only (also FSNP_LSTM_COOP=0 at fsnp_create time; use it when the GPU is shared
  * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
-                                                                  schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0) */
+                                                                  schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0);
+                                                                  3 = as 1 + the planner may use the opt-in ping-pong K split (csrc/lstm_pp.hip,
+                                                                  also FSNP_COOP_PP=1 at fsnp_create time) */
 /* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
  * LDS DMA, GroupNorm folded into the sconv weights at fsnp_create; csrc/tcn.hip) where its layout requirements hold;
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
@@ -323,7 +345,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 6
+#define FSNP_ABI_VERSION 7
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

@@ -64,3 +64,44 @@ def test_forward_sharded_two_ranks_equals_single_process(mode, tmp_path):
     assert got.shape == want.shape == ((5, 2, 257, want.shape[-1]) if mode == "full" else (5, 2, 128, want.shape[-1]))
     # shards of 3 + 2 utterances run other sub-band kernel plans than the batch of 5: same rows, other summation order
     assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+
+
+# ---- RCCL itself (SURVEY.md 8(e) caveat: with one GPU per box, validate the "nccl" path at world_size = 1)
+def test_bench_under_torchrun_initialises_rccl_at_world_size_1():
+    """The driver's multi-GPU launch line with N = 1: `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`.
+    A real init_process_group("nccl", device_id=...), barrier, all_gather of the per-rank times and all_gather_into_tensor of
+    the [32, 2, 257, 126] masks over RCCL; `bench.py --gpus 8` differs from this run only in N."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "1", "--dist-backend", "nccl", "--steps", "3", "--warmup", "1",
+                "--no-cpu-baseline", "--no-alt"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["dist"]["world_size_seen"] == 1 and r["dist"]["backend"].startswith("nccl")
+    assert r["dist"]["gathered_shape"] == [32, 2, 257, 126] and r["gather_ms"] > 0
+    assert r["config"]["global_batch"] == 32 and r["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["full", "parity"])
+def test_forward_sharded_over_rccl_world_size_1(mode, tmp_path):
+    """forward_sharded(gather=True) on the nccl (= RCCL) backend: all_gather_into_tensor in "full" mode, the all_reduce that
+    merges the zero-initialised global tensor in "parity" mode - bit-identical to the plain forward (one rank = the same plan)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "rccl.npy"
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(ROOT, "tests", "multirank_worker.py"), mode, str(out), "nccl"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert open(str(out) + ".info").read().split() == ["nccl", "1"]
+    got = np.load(out)
+    from fullsubnet_plus_amd import FullSubNet_Plus
+    from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_inputs, make_state_dict
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    m.load_state_dict(make_state_dict(0, "default"), strict=True)
+    m = m.to("cuda").eval()
+    m.batch_mode = mode
+    want = m(*[t.cuda() for t in make_inputs(5, 0.5, 77)]).cpu().numpy()
+    assert np.array_equal(got, want)

@@ -515,7 +515,7 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
 
     def plan(rows, occ, costs=None, gru=0):
         buf = (ct.c_int32 * (8 * 64))()
-        arr = (ct.c_double * 20)(*costs) if costs else None
+        arr = (ct.c_double * 24)(*(list(costs) + [1e9] * (24 - len(costs)))) if costs else None      # (ping-pong launches priced out unless given)
         n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
         assert n > 0, lib.fsnp_last_error()
         keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
@@ -536,6 +536,18 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100, 1000, 0]      # K split suddenly slow: 9 tiles move
     p = plan(257, 1, slow_k)
     assert p[0]["kind"] == 2
+    # the opt-in ping-pong K split (kernel 6: groups of 48 workgroups, 1..4 row tiles per group): planned where the table says
+    # it pays, never beyond 5 groups x tiles-per-group row tiles per launch
+    cheap_pp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 9, 11, 15, 19]
+    p = plan(257, 1, cheap_pp)                   # 9 tiles: two per group on 5 groups
+    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["rpg"] == 2 and p[0]["par"] == 5 and p[0]["tiles"] == 9
+    p = plan(32, 1, cheap_pp)
+    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["tiles"] == 1
+    p = plan(640, 1, cheap_pp)                   # 20 tiles: one launch of 5 groups x 4
+    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["rpg"] == 4 and p[0]["par"] == 5
+    for c in plan(1285, 1, cheap_pp):            # 41 tiles: several launches, each within its capacity
+        assert c["kind"] != 6 or (c["par"] <= 5 and c["par"] * c["rpg"] >= c["tiles"])
+    assert all(c["kind"] != 6 for rows in (32, 257, 640, 8224) for c in plan(rows, 1))      # built-in plans: never
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the ping-pong K-split kernel (csrc/lstm_pp.hip) from wall-clock stamps (fsnp_debug_pp_profile).
+usage: python tools/pp_phase_profile.py <sequences> <steps> <tiles per group>"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fullsubnet_plus_amd import FullSubNet_Plus, _lib  # noqa: E402
+from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_state_dict  # noqa: E402
+
+
+def main():
+    n, steps, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    m.load_state_dict(make_state_dict(0, "default"))
+    m = m.cuda().eval()
+    x = torch.randn(n, steps, 34, device="cuda")
+    out = torch.empty(n, 2, steps, device="cuda")
+    m.lstm2_fc(x.permute(0, 2, 1)[:8])          # creates the handle
+    lib = _lib.load()
+    stamps = np.zeros(steps * r * 8, dtype=np.uint64)
+    for _ in range(2):
+        _lib.check(lib.fsnp_debug_pp_profile(m._handle, x.data_ptr(), out.data_ptr(), n, steps, r, stamps.ctypes.data, stamps.size), "profile")
+    s = stamps.reshape(steps * r, 8).astype(np.int64)[4 * r:]          # skip warm-up steps; 10 ns ticks
+    names = ["MFMA pass", "barrier 1 (+flags)", "early fetch + partial tiles -> LDS, barrier 2", "cell phase", "barrier 3", "publish (+ wait / late fetch)"]
+    d = np.diff(s[:, :7], axis=1) * 0.01
+    res = {"sequences": n, "steps": steps, "tiles_per_group": r, "us_per_tile_phase": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01),
+           "early_fetch_fraction": float(s[:, 7].mean())}
+    for i, nm in enumerate(names):
+        res[f"{i}: {nm}"] = round(float(d[:, i].mean()), 3)
+    res["gap to the next pass"] = round(float((s[1:, 0] - s[:-1, 6]).mean() * 0.01), 3)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
