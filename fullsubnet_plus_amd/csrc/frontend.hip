@@ -278,29 +278,59 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         }
         return;
     }
-    // fc1 + ReLU, fc2 + sigmoid: one thread per output over TRANSPOSED weights (coalesced, independent loads);
-    // a wave-per-output dot product is a chain of dependent L2 round trips here (measured 120 us vs a few us).
+    // fc1 + ReLU, fc2 + sigmoid over TRANSPOSED weights (coalesced, independent loads; a wave-per-output dot product is a chain of
+    // dependent L2 round trips here: measured 120 us).  Round 3: the kernel is latency-bound (one workgroup per utterance and
+    // branch), so every thread works - fc1's K is cut into 256 / (F / 2) slices per output - and every chain keeps 16 loads in
+    // flight on 4 independent accumulators (31.8 -> ~10 us at B = 32).
+    auto dot = [&](const float* wT, long stride, const float* x, int k0, int k1) -> float {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = k0;
+        for (; k + 16 <= k1; k += 16) {
+            float wv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wv[j] = wT[(long)(k + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                a0 += wv[j] * x[k + j]; a1 += wv[j + 1] * x[k + j + 1]; a2 += wv[j + 2] * x[k + j + 2]; a3 += wv[j + 3] * x[k + j + 3];
+            }
+        }
+        for (; k < k1; ++k) a0 += wT[(long)k * stride] * x[k];
+        return (a0 + a1) + (a2 + a3);
+    };
+    float* part = edge;                                      // [slices][Fr] partial sums (the staged edge frames are no longer needed;
+    float* part2 = edge + 256;                               //  CBAM keeps its max vector in edge[0, FP): its partials sit behind it)
+    if (att == FSNP_ATT_CBAM) { part = edge + FP; part2 = edge + FP + 256; }
+    const int ns1 = Fr >= 256 ? 1 : 256 / Fr, chunk = cdiv(F, ns1);
+    __syncthreads();                                         // every thread is done with `edge`
+    for (int item = tid; item < Fr * ns1; item += 256) {
+        const int o = item % Fr, sl = item / Fr;
+        const int k0 = sl * chunk, k1 = min(F, k0 + chunk);
+        part[sl * Fr + o] = dot(g.w.fc1_wT[branch] + o, Fr, sq, k0, k1);
+        if (att == FSNP_ATT_CBAM) part2[sl * Fr + o] = dot(g.w.fc1_wT[branch] + o, Fr, sqmax, k0, k1);
+    }
+    __syncthreads();
     for (int o = tid; o < Fr; o += 256) {
-        const float* wT = g.w.fc1_wT[branch] + o;
         float acc = g.w.fc1_b[branch][o];
-#pragma unroll 8
-        for (int f = 0; f < F; ++f) acc += wT[(long)f * Fr] * sq[f];
+        for (int sl = 0; sl < ns1; ++sl) acc += part[sl * Fr + o];
         float h = fmaxf(acc, 0.f);
         if (att == FSNP_ATT_CBAM) {                          // relu(fc1(mean)) + relu(fc1(max))
             float acc2 = g.w.fc1_b[branch][o];
-#pragma unroll 8
-            for (int f = 0; f < F; ++f) acc2 += wT[(long)f * Fr] * sqmax[f];
+            for (int sl = 0; sl < ns1; ++sl) acc2 += part2[sl * Fr + o];
             h += fmaxf(acc2, 0.f);
         }
         hid[o] = h;
     }
     __syncthreads();
-    for (int o = tid; o < F; o += 256) {
-        const float* wT = g.w.fc2_wT[branch] + o;
-        float acc = g.w.fc2_b[branch][o];
-#pragma unroll 8
-        for (int f = 0; f < Fr; ++f) acc += wT[(long)f * F] * hid[f];
+    const int Fmain = F / 256 * 256;                         // outputs in whole passes of the workgroup: one chain each ...
+    for (int o = tid; o < Fmain; o += 256) {
+        const float acc = g.w.fc2_b[branch][o] + dot(g.w.fc2_wT[branch] + o, F, hid, 0, Fr);
         g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
+    }
+    for (int o = Fmain + wave; o < F; o += 4) {              // ... the few left over (F = 257: one): a wave each, K across the lanes
+        float acc = 0.f;
+        for (int k = lane; k < Fr; k += 64) acc += g.w.fc2_wT[branch][(long)k * F + o] * hid[k];
+        acc = wave_sum_f(acc) + g.w.fc2_b[branch][o];
+        if (lane == 0) g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
     }
 }
 

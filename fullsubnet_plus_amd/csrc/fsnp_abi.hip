@@ -131,6 +131,9 @@ struct fsnp_handle {
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
     int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
     int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
+    bool generic_sb = false;     // the sub-band recurrent model runs on the runtime-sized kernel (lstm_generic.hip): a hidden size or an
+                                 // input width no tuned kernel is instantiated for
+    bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
     bool pp_ok = false;          // the ping-pong K-split kernel (lstm_pp.hip) exists for this handle's sub-band model
     int coop_pp = 0, coop_pp_cfg = 0;   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
     int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups
@@ -551,6 +554,11 @@ static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
         p.chunks.push_back(c);
     };
     if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
+    if (h->generic_sb) {                                        // the runtime-sized kernel: workgroups of rg sequences, one launch
+        const int rg = lstm_generic_rows_per_group(h->H, h->NIN, num_rows, h->num_cus_real);
+        if (rg > 0) push(SbChunk{7, 0, num_rows, cdiv(num_rows, rg), 0, rg, 0, 0, rg, 0, 0});
+        return p;
+    }
     auto cost_of = [&](const std::vector<SbChunk>& v) { double c = 0; for (const SbChunk& k : v) c += est_step_us(h, k); return c; };
     const bool rowtile_ok = h->rowtile_ok;                     // a one-tile-per-CU kernel exists for this cell / size
     const bool coop_on = h->lstm_coop != 0 || !rowtile_ok;     // (without one the column-split kernels are the only path)
@@ -622,6 +630,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             continue;
         }
         if (c.kind == 4) { launch_lstm16(h->lw, ca, s); continue; }
+        if (c.kind == 7) { ca.coop_rows_per_group = c.rpg; launch_lstm_generic(h->lw, ca, false, s); continue; }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
         ca.coop_bar = bar + c.coop_tile0;
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
@@ -675,7 +684,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
     const size_t nbr = fsn ? 1 : 3;
     const size_t xb = nbr * B * Tp * h->FP * 4;
-    const size_t yb = nbr * B * Tp * h->CH * 4;
+    const size_t yb = nbr * B * Tp * align_up(h->CH, 4) * 4;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     w.att = take(xb);                     // FullSubNet: the padded raw magnitude lives here (no attention stage)
@@ -836,7 +845,7 @@ static std::map<CalKey, CostTable> g_cal_cache;
 
 static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measured = nullptr) {
     if (adopt && (h->cost.calibrated || !h->calibrate)) return 0;
-    if (h->sb_tcn || !h->committed) return 0;
+    if (h->sb_tcn || h->generic_sb || !h->committed) return 0;
     int occ_sig = h->coop_occ;
     for (int i = 0; i < 4; ++i) occ_sig = occ_sig * 4 + h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) occ_sig = occ_sig * 4 + h->occ_coopn[i];
@@ -975,10 +984,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->sb_num_neighbors < 0 || cfg->fb_num_neighbors < 0) { set_error("sb_num_neighbors / fb_num_neighbors must be >= 0"); return 2; }
     if (cfg->num_groups_in_drop_band < 1) { set_error("num_groups_in_drop_band must be >= 1"); return 2; }
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
-    if (cfg->sb_hidden != 384 && cfg->sb_hidden != 256 && cfg->sb_hidden != 512 && cfg->sequence_model != FSNP_SEQ_TCN) {
-        set_error("sb_model_hidden_size must be 256, 384 or 512 (the instantiations of the recurrent kernels)");
-        return 2;
-    }
+    if (cfg->sb_hidden < 1 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be >= 1"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
     if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
@@ -995,10 +1001,14 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     }
     if (subband_num > 1 && subband_num - cfg->num_freqs % subband_num >= cfg->num_freqs) { set_error("subband_num too large for num_freqs (reflect pad)"); return 2; }
     if (fsn && cfg->sequence_model == FSNP_SEQ_TCN) { set_error("FullSubNet only supports GRU and LSTM"); return 2; }
-    if (fsn && cfg->tcn_hidden != 512) { set_error("fb_model_hidden_size must be 512 (full-band LSTM kernel instantiation)"); return 2; }
-    if (fsn && cfg->num_freqs > 264) { set_error("num_freqs must be <= 264 (full-band LSTM kernel instantiation)"); return 2; }
+    if (fsn && cfg->tcn_hidden < 1) { set_error("fb_model_hidden_size must be >= 1"); return 2; }
     const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3) * (2 * cfg->fb_num_neighbors + 1);
-    if (nin > 64) { set_error("sb_num_neighbors / fb_num_neighbors too large: the sub-band input has %d features, the widest (KX=64) kernel instantiation takes 64", nin); return 2; }
+    // sizes without a tuned (MFMA) instantiation run on the runtime-sized kernel (lstm_generic.hip) - as long as one sequence's
+    // state fits a CU's LDS
+    const bool generic_sb = cfg->sequence_model != FSNP_SEQ_TCN && ((cfg->sb_hidden != 384 && cfg->sb_hidden != 256 && cfg->sb_hidden != 512) || nin > 64);
+    const bool generic_fb = fsn && (cfg->tcn_hidden != 512 || cfg->num_freqs > 264);
+    if (generic_sb && lstm_generic_rows_per_group(cfg->sb_hidden, nin, 1, 1) == 0) { set_error("sb_model_hidden_size %d is too large for the runtime-sized kernel (LDS)", cfg->sb_hidden); return 2; }
+    if (generic_fb && lstm_generic_rows_per_group(cfg->tcn_hidden, cfg->num_freqs, 1, 1) == 0) { set_error("fb_model_hidden_size %d is too large for the runtime-sized kernel (LDS)", cfg->tcn_hidden); return 2; }
     if (cfg->num_freqs <= cfg->sb_num_neighbors || cfg->num_freqs <= cfg->fb_num_neighbors) { set_error("num_freqs must exceed the neighbour counts (reflect pad)"); return 2; }
     for (int c = 0; c < 3; ++c)
         if (cfg->kersize[c] < 1 || cfg->kersize[c] > 16) { set_error("kersize must be in [1,16]"); return 2; }
@@ -1020,7 +1030,9 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->device = dev;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->num_cus_real = h->num_cus;
-    if (cfg->sequence_model != FSNP_SEQ_TCN && h->num_cus_real < cfg->sb_hidden / 8) {
+    h->generic_sb = generic_sb;
+    h->generic_fb = generic_fb;
+    if (cfg->sequence_model != FSNP_SEQ_TCN && !generic_sb && h->num_cus_real < cfg->sb_hidden / 8) {
         // the column-split kernels need at least one group of workgroups resident (GRU has no other kernel)
         set_error("device %d exposes %d compute units; the sub-band recurrent kernels need at least %d", dev, h->num_cus_real, cfg->sb_hidden / 8);
         delete h;
@@ -1030,10 +1042,10 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     h->gru = cfg->sequence_model == FSNP_SEQ_GRU;
     // one-tile-per-CU kernels: LSTM lstm.hip (H = 384, and 256 without VALU rows), GRU lstm_gru.hip (384); other sizes run on
     // the column-split kernels only
-    h->rowtile_ok = cfg->sb_hidden == 384 || (cfg->sb_hidden == 256 && !h->gru);
+    h->rowtile_ok = !generic_sb && (cfg->sb_hidden == 384 || (cfg->sb_hidden == 256 && !h->gru));
     {
         const char* e16 = getenv("FSNP_LSTM16");           // 0 = never plan the half-tile kernel
-        h->lstm16_ok = !(e16 && e16[0] == '0') && !h->gru && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384 && nin <= 40;
+        h->lstm16_ok = !(e16 && e16[0] == '0') && !generic_sb && !h->gru && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384 && nin <= 40;
     }
     h->cost = initial_costs(cfg->sb_hidden, h->gru, cfg->sequence_model == FSNP_SEQ_TCN);
     const char* ce = getenv("FSNP_CALIBRATE");
@@ -1066,7 +1078,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         const char* pe = getenv("FSNP_COOP_PP");
         h->coop_pp = pe && pe[0] == '1' ? 1 : 0;
         h->coop_pp_cfg = h->coop_pp;
-        h->pp_ok = cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
+        h->pp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
     }
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
@@ -1294,8 +1306,14 @@ int fsnp_commit_weights(fsnp_handle* h) {
         return r;
     };
     const Rnn4 sbw = h->sb_tcn ? Rnn4{} : expand("sb_model.sequence_model.", H, h->NIN);
+    const bool tuned = !h->sb_tcn && !h->generic_sb;            // MFMA kernels exist for this cell / hidden size / input width
+    size_t o_wgen = 0;
+    if (h->generic_sb) {                                        // runtime-sized kernel: transposed [layer][k][4H]
+        o_wgen = alloc(lstm_generic_pack_floats(H, h->NIN));
+        lstm_generic_pack_weights(H, h->NIN, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wgen);
+    }
     size_t o_wpack = 0, o_wpack12 = 0, o_wpack_bf[2] = {0, 0};
-    if (!h->gru && !h->sb_tcn && (H == 384 || H == 256)) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
+    if (!h->gru && tuned && (H == 384 || H == 256)) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
         o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
         lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
         if (H == 384) {
@@ -1315,33 +1333,37 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm16_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack16);
     }
     size_t o_wpack_bf3 = 0;
-    if (!h->gru && !h->sb_tcn && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
+    if (!h->gru && tuned && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
         o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
         lstm_bf3_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_bf3);
     }
     size_t o_wpack_gru = 0;
-    if (h->gru && !h->sb_tcn && H == 384) {
+    if (h->gru && tuned && H == 384) {
         o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
         gru_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_gru);
     }
     size_t o_wpack_coop[4] = {0, 0, 0, 0};
-    for (int ui = 0; ui < 4 && !h->sb_tcn; ++ui) {
+    for (int ui = 0; ui < 4 && tuned; ++ui) {
         const int units = 8 << ui;
         o_wpack_coop[ui] = alloc(lstm_coop_pack_floats(H, h->KX, units));
         lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                blob.data() + o_wpack_coop[ui]);
     }
-    const size_t o_wpack_coopn = alloc(h->sb_tcn ? 0 : lstm_coopn_pack_floats(H, h->KX));
-    if (!h->sb_tcn)
+    const size_t o_wpack_coopn = alloc(tuned ? lstm_coopn_pack_floats(H, h->KX) : 0);
+    if (tuned)
         lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                 blob.data() + o_wpack_coopn);
     // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
-    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0;
+    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0, o_fbgen = 0;
     const int fsn_kp = (int)align_up(CH, 16), fsn_np = (int)align_up(F, 384);
     if (fsn) {
         const Rnn4 fbw = expand("fb_model.sequence_model.", CH, F);
-        for (int ui = 0; ui < 3; ++ui) {
+        if (h->generic_fb) {
+            o_fbgen = alloc(lstm_generic_pack_floats(CH, F));
+            lstm_generic_pack_weights(CH, F, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(), blob.data() + o_fbgen);
+        }
+        for (int ui = 0; ui < 3 && !h->generic_fb; ++ui) {
             const int units = 8 << ui;
             o_fbpack[ui] = alloc(lstm_coop_pack_floats(CH, KXF, units));
             lstm_coop_pack_weights(CH, F, KXF, units, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(),
@@ -1391,17 +1413,19 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack16 = d + o_wpack16;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
+    h->lw.wgen = d + o_wgen;
     if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
     if (fsn) {
         h->fbw = LstmWeights{};
         for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
         h->fbw.bias = d + o_fbbias;
         h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0; h->fbw.gru = h->gru;
+        h->fbw.wgen = d + o_fbgen;
         h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
     }
     h->d_refl_w = d + o_refl;
     h->d_refl_wfb = d + o_reflfb;
-    if (!h->sb_tcn) {                           // which column-split instantiations fit twice on a CU (registers, LDS)
+    if (tuned) {                                // which column-split instantiations fit twice on a CU (registers, LDS)
         for (int ui = 0; ui < 4; ++ui) h->occ_ksplit[ui] = std::max(1, lstm_coop_occupancy(h->lw, 8 << ui));
         for (int rpg = 1; rpg <= 2; ++rpg) h->occ_coopn[rpg - 1] = std::max(1, lstm_coopn_occupancy(h->lw, rpg));
     }
@@ -1443,8 +1467,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     for (int c = 0; c < 3; ++c) kmax = kmax > h->cfg.kersize[c] ? kmax : h->cfg.kersize[c];
     if (!fsn && h->cfg.attention == FSNP_ATT_TSSE && d.Tp < kmax) { set_error("too few frames: T + look_ahead = %d < largest TSSE kernel %d", d.Tp, kmax); return 2; }
     if ((double)3 * d.B * d.Tp * d.FP * 2 > 2.0e9) { set_error("batch too large for 32-bit gather offsets; split the batch"); return 2; }
-    const int fb_units = fsn ? fb_coop_units(h, batch) : 0;
-    if (fsn && fb_units == 0) { set_error("FullSubNet: at most %d utterances per call (full-band LSTM residency); split the batch", 32 * (h->num_cus_real / 16)); return 2; }
+    const int fb_units = (fsn && !h->generic_fb) ? fb_coop_units(h, batch) : 0;
+    if (fsn && !h->generic_fb && fb_units == 0) { set_error("FullSubNet: at most %d utterances per call (full-band LSTM residency); split the batch", 32 * (h->num_cus_real / 16)); return 2; }
 
     FSNP_ON_DEVICE(h);
     if (calibrate_costs(h)) return 4;            // first planning call of the process for this kind of handle only (~0.1 s)
@@ -1521,9 +1545,11 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fbuf.raw = fptr(w.att); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
         fbuf.md = reinterpret_cast<NormMD*>(base + w.md);
         launch_frontend_mag(d, h->cfg.norm_type, mag, strides[0], is_complex, fbuf, s);
-        const int fb_tiles = fb_row_tiles(batch);
+        // (runtime-sized kernel for a full-band model no K-split instantiation exists for: workgroups of fb_rg sequences)
+        const int fb_rg = h->generic_fb ? lstm_generic_rows_per_group(h->CH, h->F, batch, h->num_cus_real) : 32;
+        const int fb_tiles = h->generic_fb ? cdiv(batch, fb_rg) : fb_row_tiles(batch);
         RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
-        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * 32, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, 32,
+        hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * fb_rg, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, fb_rg,
                            1, frames, 0, 0, 1, 1, 0, 2);
         LstmArgs fa{};
         fa.rows = fb_rows; fa.dense = fptr(w.att); fa.dense_stride = d.FP; fa.md_seq = fbuf.md;
@@ -1532,8 +1558,11 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fa.coop_hx = fptr(w.fb_hx); fa.coop_bar = reinterpret_cast<unsigned*>(base + w.fb_bar); fa.coop_err = h->d_err;
         fa.coop_abort = reinterpret_cast<unsigned*>(base + w.coop_abort) + 16;
         fa.coop_units = fb_units;
-        launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
-        launch_linear_act(fptr(w.y1), d.CH, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
+        const int chp = (int)align_up(d.CH, 4);           // row stride of the h1 sequence (a float4 multiple; pad columns written as zeros)
+        fa.seq_stride = chp;
+        if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
+        else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
+        launch_linear_act(fptr(w.y1), chp, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     }
@@ -1956,8 +1985,8 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind);
+        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind == 7 ? 11 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }

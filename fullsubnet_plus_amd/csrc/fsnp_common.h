@@ -156,6 +156,7 @@ struct LstmWeights {
     const float* wpack16;       // half-tile kernel (lstm16.hip): [wave][k-group of 16][24 tiles of 16 columns][lane][4]
     const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
+    const float* wgen;          // runtime-sized kernel (lstm_generic.hip): transposed [layer][k][4H], layer 0 k = [x | h0], layer 1 = [h0 | h1]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
     const float* bias;   // [2][4H]  b_ih + b_hh, reference gate order i,f,g,o
@@ -177,6 +178,7 @@ struct LstmArgs {
     int dense_stride;          // cooperative kernel only (the row-tile kernel assumes NIN)
     const NormMD* md_seq;      // cooperative kernel only: optional [sequence = row.b][Tp] table, overrides md_utt / md_row
     float* seq_out;            // cooperative SEQ kernel: h1 of the second layer, [row.b][t][H]
+    int seq_stride;            // floats between its rows (0 = H); >= H
     float* out;            // out[row.out_off + o*out_stride_o + (t-LA)]
     long out_stride_o;
     int num_rows;          // valid rows
@@ -230,6 +232,12 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles);
 // group of H / 8 workgroups worked on in turn (hand-off latency of one tile hidden behind the others); weights = wpack_coop[0]
 void launch_lstm_pp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 bool lstm_pp_available(const LstmWeights& w);
+// lstm_generic.hip: runtime-sized fp32-FMA kernel for the sizes no tuned kernel is instantiated for (any hidden size / input width);
+// a.num_tiles workgroups of a.coop_rows_per_group (1, 2, 4, 8) sequences; seq = the full-band model of the original FullSubNet
+void launch_lstm_generic(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s);
+size_t lstm_generic_pack_floats(int H, int NIN);
+void lstm_generic_pack_weights(int H, int NIN, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
+int lstm_generic_rows_per_group(int H, int NIN, int num_seq, int num_cus);   // 0 = the sizes do not fit a CU's LDS
 // lstm_coopn.hip: 3 workgroups x 128 hidden units share 1-2 row tiles (43..170 row tiles)
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_coopn_pack_floats(int H, int KX);

@@ -494,6 +494,7 @@ class _HipModel(nn.Module):
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
                  5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
+                 11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
                  **{6 + r: f"lstm2_coop_pp_kernel (K split, fused phase, {r} row tile{'s' if r > 1 else ''} per group in turn)" for r in (1, 2, 3, 4)}}
         return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
                 for i in range(n)]
@@ -578,8 +579,6 @@ class FullSubNet_Plus(_HipModel):
             raise NotImplementedError("subband_num != 1 only works with channel_attention_model='ECA' (as in the reference)")
         if subband_num < 1:
             raise NotImplementedError("subband_num must be >= 1")
-        if (sb_num_neighbors * 2 + 1) + 3 * (fb_num_neighbors * 2 + 1) > 64:
-            raise NotImplementedError("HIP path: more than 64 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
@@ -693,8 +692,6 @@ class FullSubNet(_HipModel):
                  ):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if (sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1) > 64:
-            raise NotImplementedError("HIP path: more than 64 sub-band input features (sb / fb_num_neighbors too large)")
         if norm_type not in _lib.NORM_TYPES:
             raise NotImplementedError("You must set up a type of Norm. "
                                       "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")

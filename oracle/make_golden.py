@@ -106,6 +106,11 @@ CASES = [
     dict(name="b1_t20_h512", wseed=34, profile="default", args={"sb_model_hidden_size": 512}, inp=("spec", 1, 20, 35), stages=False),
     dict(name="gru_b3_t16_h256", wseed=35, profile="default", args={"sb_model_hidden_size": 256, "sequence_model": "GRU"},
          inp=("spec", 3, 16, 36), stages=False),
+    # sizes WITHOUT a tuned (MFMA) kernel instantiation: they run on the runtime-sized kernel (csrc/lstm_generic.hip)
+    dict(name="b3_t16_h320", wseed=36, profile="harsh", args={"sb_model_hidden_size": 320}, inp=("spec", 3, 16, 37), stages=False),
+    dict(name="b1_t20_fbn6", wseed=37, profile="default", args={"fb_num_neighbors": 6}, inp=("spec", 1, 20, 38), stages=False),
+    dict(name="gru_b3_t16_h190", wseed=38, profile="default", args={"sb_model_hidden_size": 190, "sequence_model": "GRU"},
+         inp=("spec", 3, 16, 39), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -133,6 +138,10 @@ FSN_CASES = [
     dict(name="fsn_b3_t16_fbn8", wseed=13, profile="harsh", args={"fb_num_neighbors": 8}, inp=("spec", 3, 16, 33), stages=False),
     dict(name="fsn_gru_b3_t20_default", wseed=10, profile="default", args={"sequence_model": "GRU"},
          inp=("spec", 3, 20, 30), stages=False),
+    # full-band / sub-band hidden sizes without a tuned kernel instantiation (csrc/lstm_generic.hip)
+    dict(name="fsn_b3_t16_fbh256", wseed=14, profile="harsh", args={"fb_model_hidden_size": 256}, inp=("spec", 3, 16, 34), stages=False),
+    dict(name="fsn_b1_t20_fbh300_h320", wseed=15, profile="default", args={"fb_model_hidden_size": 300, "sb_model_hidden_size": 320},
+         inp=("spec", 1, 20, 35), stages=True),
 ]
 
 SB_ROWS = [0, 1, 14, 15, 16, 128, 240, 241, 242, 255, 256]   # sub-bands kept from stage sb_input (B=1)
@@ -217,7 +226,8 @@ def run_case_fsn(case, Model):
     model = Model(**args).eval()
     sd = make_state_dict_fullsubnet(case["wseed"], case["profile"], sequence_model=args["sequence_model"],
                                     fb_num_neighbors=args["fb_num_neighbors"], num_freqs=args["num_freqs"],
-                                    sb_num_neighbors=args["sb_num_neighbors"])
+                                    sb_num_neighbors=args["sb_num_neighbors"], fb_hidden=args["fb_model_hidden_size"],
+                                    sb_hidden=args["sb_model_hidden_size"])
     res = model.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     kind, B, t, iseed = case["inp"]

@@ -36,7 +36,9 @@ class Golden:
                                               sequence_model=self.args.get("sequence_model", "LSTM"),
                                               fb_num_neighbors=self.args.get("fb_num_neighbors", 0),
                                               num_freqs=self.args.get("num_freqs", 257),
-                                              sb_num_neighbors=self.args.get("sb_num_neighbors", 15))
+                                              sb_num_neighbors=self.args.get("sb_num_neighbors", 15),
+                                              fb_hidden=self.args.get("fb_model_hidden_size", 512),
+                                              sb_hidden=self.args.get("sb_model_hidden_size", 384))
         return make_state_dict(self.meta["wseed"], self.meta["profile"],
                                attention=self.args.get("channel_attention_model", "TSSE"),
                                sequence_model=self.args.get("sequence_model", "LSTM"),

@@ -22,7 +22,7 @@ int main(void) {
     rc = fsnp_create(&cfg, &h);
     printf("create rc=%d handle=%s msg=%s\n", rc, h ? "set" : "null", rc ? fsnp_last_error() : "");
     if (rc == 0) fsnp_destroy(h);                         /* a GPU box: fine too */
-    cfg.sb_hidden = 100;                                  /* invalid configuration: must be rejected before any device call */
+    cfg.sb_hidden = 0;                                    /* invalid configuration: must be rejected before any device call */
     rc = fsnp_create(&cfg, &h);
     if (rc == 0) { printf("FAIL: bad sb_hidden accepted\n"); return 1; }
     printf("bad config rc=%d msg=%s\n", rc, fsnp_last_error());

@@ -217,6 +217,31 @@ def test_ping_pong_k_split_equals_serial_schedule(n, steps, r):
         assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), pp)
 
 
+@pytest.mark.parametrize("seq,hidden,fbn", [("LSTM", 320, 0), ("GRU", 190, 0), ("LSTM", 384, 6), ("LSTM", 1030, 0)])
+def test_generic_recurrent_kernel_dense_vs_oracle(seq, hidden, fbn):
+    """csrc/lstm_generic.hip: sizes without a tuned (MFMA) instantiation - any sb_model_hidden_size, more than 64 sub-band
+    features - run on the runtime-sized fp32-FMA kernel instead of being rejected (the reference builds nn.LSTM / nn.GRU for
+    any sizes, sequence_model.py:31-46).  Fused recurrent model + Linear alone on dense inputs, 1 / 2 / 4 / 8 sequences per
+    workgroup (by sequence count), against torch.lstm / torch.gru + linear."""
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": seq, "sb_model_hidden_size": hidden, "fb_num_neighbors": fbn}
+    sd = make_state_dict(77, "harsh", sequence_model=seq, sb_hidden=hidden, fb_num_neighbors=fbn)
+    m = _model(args, sd)
+    nin = 31 + 3 * (2 * fbn + 1)
+    for n, steps in ((3, 7), (300, 9), (700, 6), (1500, 5), (2500, 4)):
+        if hidden > 1000 and n > 300:
+            continue
+        rng = np.random.Generator(np.random.PCG64(5 * n + hidden))
+        x = torch.from_numpy(rng.standard_normal((n, nin, steps)).astype(np.float32))
+        want = fsnp_torch.lstm2_fc(x, sd).numpy()
+        got = m.lstm2_fc(x.cuda()).cpu().numpy()
+        m.check_errors()
+        assert all(c["kernel"].startswith("lstm2_generic_kernel") for c in m.describe_plan(1))
+        err = rel_err(got, want)
+        _record(f"generic_{seq}_h{hidden}_fbn{fbn}_{n}x{steps}", rel=err)
+        assert err < 2e-5, (n, steps, err)
+        assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+
+
 def test_b32_remainder_runs_role_split_outside_the_pipelined_loop(b32):
     sd, (mag, real, imag), m, full = b32
     plan = m.describe_plan(32)
