@@ -269,8 +269,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "alt_ms_per_step": None if alt_elapsed is None else alt_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16_ih": "f32 + bf16 ih-GEMM (configs[4])",
-                                  "bf16x3": "f32 emulated by split bf16 (3 MFMAs per product, fp32 accumulate) - optional mode"}[args.precision],
+        # the arithmetic type per launch of the sub-band plan (the bf16 variants exist for the one-tile-per-CU LSTM kernel only)
+        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else
+                       "; ".join(f"{c['precision']} on {c['sequences']} sequences" for c in plan) +
+                       (" (BASELINE configs[4])" if args.precision == "bf16_ih" else " - optional mode"),
         "data": "synthetic",
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
                                f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)" +

@@ -48,6 +48,7 @@ SYMBOLS = {
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),
     "fsnp_get_timing": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 4), ctypes.POINTER(c_i64 * 4), c_i32]),
     "fsnp_describe_plan": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
+    "fsnp_describe_plan_ex": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fsnp_reserve": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_dump_config": (ctypes.c_int64, [c_vp, ctypes.c_char_p, ctypes.c_int64]),
     "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 24), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),

@@ -14,6 +14,7 @@
 
 #include "fsnp_common.h"
 #include "lstm_common.h"
+#include "planner.h"
 
 namespace fsnp {
 
@@ -52,17 +53,6 @@ struct GraphKey {
     }
 };
 struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
-
-// per-step cost table of the sub-band planner (see default_costs / calibrate_costs)
-struct CostTable {
-    double ksplit[4][2];       // K-split kernel at 8 / 16 / 32 / 64 units per workgroup x {<= 1, 2} workgroups per CU, launch FULL
-    double ksplit1[4];         // the same with ONE row tile (the exchange traffic, hence a step, grows with the tiles in flight)
-    double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
-    double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
-    double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
-    double pp[4];                 // ping-pong K split at 8 units (lstm_pp.hip) with 1 / 2 / 3 / 4 row tiles per group
-    int calibrated;
-};
 
 struct TimingRec {
     hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
@@ -176,6 +166,19 @@ struct fsnp_handle {
 };
 
 namespace fsnp {
+
+// what the planner needs to know of a handle
+static PlannerCtx pctx(const fsnp_handle* h) {
+    PlannerCtx c;
+    c.H = h->H; c.NIN = h->NIN; c.num_cus = h->num_cus; c.num_cus_real = h->num_cus_real;
+    c.gru = h->gru != 0; c.sb_tcn = h->sb_tcn != 0; c.generic_sb = h->generic_sb; c.rowtile_ok = h->rowtile_ok; c.lstm16_ok = h->lstm16_ok;
+    c.pp_ok = h->pp_ok; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
+    for (int i = 0; i < 4; ++i) c.occ_ksplit[i] = h->occ_ksplit[i];
+    for (int i = 0; i < 2; ++i) c.occ_coopn[i] = h->occ_coopn[i];
+    c.coop_split = h->coop_split; c.coop_pp = h->coop_pp; c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
+    c.cost = h->cost;
+    return c;
+}
 
 static const int kDilations[8] = {1, 2, 5, 9, 1, 2, 5, 9};  // sequence_model.py:48-57
 static const char* kAtt[3] = {"channel_attention", "channel_attention_real", "channel_attention_imag"};
@@ -391,224 +394,10 @@ static void launch_coop_chained(int dev, hipStream_t s, F launch) {
     g_coop_used[dev] = hipEventRecord(g_coop_ev[dev], s) == hipSuccess;
 }
 
-// ---- plan of the sub-band recurrent model: which kernel runs which sequences.
-// The row-tile kernel (lstm.hip) needs >= 256 tiles to fill the chip and costs ~208 us per step however few tiles it
-// gets; the column-split kernels pay one inter-workgroup barrier per step instead:
-//   <= 42 row tiles  : lstm_coop.hip  (K split, 8..64 hidden units per workgroup, row_tiles * H/units <= CUs)
-//   43..170 row tiles: lstm_coopn.hip (3 workgroups x 128 units share 1-2 row tiles)
-// A problem is cut into CHUNKS of consecutive sequences that run back to back: e.g. B = 40 (10280 sequences) = one full
-// round of the row-tile kernel (8192) + 66 tiles on lstm_coopn.hip instead of two rounds; GRU (column-split only) =
-// chunks of <= 170 tiles.  Every chunk owns a slice of the row descriptors / per-row norm tables (slot0) and, if it is
-// column-split, of the exchange images and barrier counters (coop_tile0).
-struct SbChunk {
-    int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn, 4 = half tile (lstm16.hip: 16-row tiles, rps = 16)
-    int row0, nrows;           // sequences [row0, row0 + nrows)
-    int num_tiles, ex, rps;    // tiles, VALU rows per tile, slots per tile (32 + ex)
-    int units, groups, rpg;    // column-split parameters
-    int slot0, coop_tile0;
-};
-struct SbPlan {
-    std::vector<SbChunk> chunks;
-    int total_slots = 0, coop_tiles = 0;
-};
-// Per-step cost (microseconds) of every kernel shape the planner can choose.  The defaults are the round-1 measurements
-// (profiles/r01_column_split.md); fsnp_forward replaces them once per process and device with values MEASURED on the
-// device (calibrate_costs below: each shape timed at two step counts, cost = slope), so a kernel change can no longer
-// silently mis-plan.  [.][1] = the launch has more workgroups than CUs, i.e. two are co-resident per CU and share its
-// matrix pipes (their hand-off stalls then overlap: two independent row tiles per CU) - only planned when the kernels'
-// occupancy allows it (coop_occ >= 2) and, without a calibration, priced so that it is never chosen.
-static CostTable default_costs() {
-    CostTable t{};
-    // round-2 measurements (profiles/r02_planner_costs.json): a full launch, one row tile, three-way split, one-tile-per-CU
-    // K split (serial schedule at 8 units, layer-skewed from 16 up): a full launch / one row tile; three-way split at 85 / 170 row
-    // tiles; one round of the one-tile-per-CU kernel - from 128-step runs (profiles/r02_column_split.md)
-    const double ks[4] = {14.4, 16.5, 26.0, 48.5}, k1[4] = {8.7, 14.0, 22.5, 42.0}, cn[2] = {78.0, 157.0};
-    for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
-    for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 108.0;
-    // round 3 (profiles/r03_column_split.md): ping-pong K split, a full launch of 5 groups with 1 / 2 / 3 / 4 row tiles each (measured)
-    const double pp[4] = {9.1, 15.5, 22.9, 30.4};
-    for (int i = 0; i < 4; ++i) t.pp[i] = pp[i];
-    return t;
-}
-// the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
-static CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
-    CostTable t = default_costs();
-    if (gru) t.rowtile *= 0.75;   // three of the four gate tiles per k-group
-    if (sb_hidden != 384 && !sb_tcn) {     // scale by the work per step
-        const double f = sb_hidden / 384.0;
-        for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; t.pp[i] *= f; }
-        for (int i = 0; i < 2; ++i) { t.coopn[i][0] *= f; t.coopn[i][1] *= f; }
-        t.rowtile *= f * f;
-    }
-    return t;
-}
-static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
-// per-step cost of the role-split K-split schedule relative to the one-set kernel of the same units and tile count
-// (lstm_coop.hip: lstm2_coop_split_kernel; measured, profiles/r02_column_split.md section 8: 1 tile at 8 units 11.06 -> 9.47 us,
-// 2 tiles 14.40 -> 11.32; from 16 units up it does not pay - a step is ONE hand-off on either schedule, the split only takes
-// the other layer's MFMA + cell time out of the chain)
-static const double kSplitRatio[4] = {0.85, 1.0, 1.1, 1.25};
-static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) {
-    if (c.kind == 1) return c.num_tiles * (h->H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
-    if (c.kind == 2) return c.groups * (h->H / 128);
-    if (c.kind == 6) return cdiv(c.num_tiles, c.rpg) * (h->H / 8);
-    return c.num_tiles;
-}
-static double est_step_us(const fsnp_handle* h, const SbChunk& c) {
-    const int dbl = chunk_workgroups(h, c) > h->num_cus_real ? 1 : 0;
-    if (c.kind == 1) {
-        const int ui = units_index(c.units);
-        if (c.rpg) {             // role-split schedule: priced relative to the same shape on the one-set kernels (kSplitRatio)
-            const int cap = h->num_cus_real / (2 * (h->H / c.units));
-            const double r = h->coop_split == 2 ? 0.01 : kSplitRatio[ui];
-            // 8 units: measured directly (1 tile 8.2 us, 2 tiles 10.0 - the one-set kernel: 8.7 / 13.2), scaled with the table
-            if (ui == 0 && c.num_tiles <= 2 && h->coop_split != 2) return (c.num_tiles == 1 ? 8.2 : 10.0) * h->cost.ksplit1[0] / 8.7;
-            if (cap <= 1) return r * h->cost.ksplit1[ui];
-            const double f = (double)(c.num_tiles - 1) / (cap - 1);
-            return r * (h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0));
-        }
-        const int cap = h->num_cus_real / (h->H / c.units);
-        if (dbl || cap <= 1) return h->cost.ksplit[ui][dbl];
-        const double f = (double)(c.num_tiles - 1) / (cap - 1);              // 1 tile .. a full launch
-        return h->cost.ksplit1[ui] + (h->cost.ksplit[ui][0] - h->cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
-    }
-    if (c.kind == 2) return h->cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
-    if (c.kind == 6) return h->cost.pp[(c.num_tiles < c.rpg ? c.num_tiles : c.rpg) - 1];      // a step lasts as long as the fullest group's turn
-    if (c.kind == 4) return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile16;
-    return cdiv(c.num_tiles, h->num_cus) * h->cost.rowtile * (1.0 + h->cost.rowtile_ex * c.ex);
-}
-static SbChunk rowtile_chunk(const fsnp_handle* h, int row0, int nrows) {
-    if (h->gru || h->H != 384) return SbChunk{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};   // VALU rows: LSTM at H = 384 only
-    const LstmPlan lp = plan_lstm_tiles(nrows, h->num_cus);
-    return SbChunk{0, row0, nrows, lp.num_tiles, lp.ex, lp.rows_per_slot_tile, 0, 0, 0, 0, 0};
-}
-// Column-split launches for `nrows` sequences (any count): the cheapest sequence of launches by the cost table.  A launch
-// costs the same per step whether its kernel is full or not, so this is a shortest path over tile counts: best[t] = min over
-// launch shapes c (K split at 8..64 units, one or two row tiles per three-workgroup group; one or - if the kernels fit -
-// two workgroups per CU) of cost(c) + best[t - min(t, capacity(c))].  E.g. with the round-1 table: 128 tiles = 85 one per
-// group (76 us) + 42 K-split (55) + 1 (9) instead of two per group (151); 97 = 85 + 12 (76 + 29).
-static std::vector<SbChunk> plan_columns(const fsnp_handle* h, int row0, int nrows) {
-    std::vector<SbChunk> out;
-    const int S3 = h->H / 128;
-    if (h->H < 128 || h->num_cus_real / S3 <= 0) return out;   // fewer CUs than one group needs: no column-split plan
-    const int T = cdiv(nrows, 32);
-    struct Shape { int kind, units, rpg, cap, dbl; };
-    std::vector<Shape> shapes;
-    for (int occ = 1; occ <= (h->coop_occ >= 2 ? 2 : 1); ++occ) {          // two per CU: only shapes whose kernel fits twice
-        const int slots = h->num_cus_real * occ;
-        for (int u = 8; u <= 64; u *= 2)
-            if (h->H % u == 0 && slots / (h->H / u) > 0 && h->occ_ksplit[units_index(u)] >= occ)
-                shapes.push_back({1, u, 0, slots / (h->H / u), occ - 1});
-        for (int rpg = 1; rpg <= 2; ++rpg)
-            if (h->occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
-        // role-split K split: 2 S workgroups per row tile, LSTM only; not in the pipelined loop, where the chunk runs beside the
-        // next forward's full-band stages and twice the CUs for 15 % less time is a bad trade (auto mode)
-        if (occ == 1 && !h->gru && (h->coop_split >= 2 || (h->coop_split == 1 && !h->pipeline)))      // (3 = auto, also when pipelined: tuning)
-            for (int u = 8; u <= 64; u *= 2)
-                if (h->H % u == 0 && slots / (2 * (h->H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h->H / u)), 0});
-        // ping-pong K split (lstm_pp.hip): groups of H / 8 workgroups, 1..4 row tiles per group
-        if (occ == 1 && h->pp_ok && h->coop_pp && slots / (h->H / 8) > 0)
-            for (int rpg = 1; rpg <= 4; ++rpg) shapes.push_back({6, 8, rpg, (slots / (h->H / 8)) * rpg, 0});
-    }
-    auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
-        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
-        return est_step_us(h, c) + 1.2;                         // + a launch (prologue / drain, amortised over ~100 steps): fewer chunks win near-ties
-    };
-    std::vector<double> best(T + 1, 0.0);
-    std::vector<int> pick(T + 1, -1);
-    for (int t = 1; t <= T; ++t) {
-        best[t] = 1e30;
-        for (int i = 0; i < (int)shapes.size(); ++i) {
-            const int n = t < shapes[i].cap ? t : shapes[i].cap;
-            if (shapes[i].kind == 2 && shapes[i].rpg == 2 && n < 2) continue;
-            const double c = shape_cost(shapes[i], n) + best[t - n];
-            if (c < best[t] - 1e-9) { best[t] = c; pick[t] = i; }
-        }
-        if (pick[t] < 0) return out;
-    }
-    std::vector<std::pair<int, int>> taken;                     // (tiles, shape), largest first
-    for (int t = T; t > 0;) {
-        const Shape& sh = shapes[pick[t]];
-        const int n = t < sh.cap ? t : sh.cap;
-        taken.push_back({n, pick[t]});
-        t -= n;
-    }
-    std::stable_sort(taken.begin(), taken.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-    int r0 = row0, left = nrows;
-    for (const auto& tk : taken) {
-        const Shape& sh = shapes[tk.second];
-        const int rows = tk.first * 32 < left ? tk.first * 32 : left;
-        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
-        out.push_back(c);
-        r0 += rows; left -= rows;
-    }
-    return out;
-}
-
-static SbPlan plan_sb(const fsnp_handle* h, int num_rows) {
-    SbPlan p;
-    auto push = [&](SbChunk c) {
-        c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 6) p.coop_tiles += c.num_tiles;
-        p.chunks.push_back(c);
-    };
-    if (h->sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel
-    if (h->generic_sb) {                                        // the runtime-sized kernel: workgroups of rg sequences, one launch
-        const int rg = lstm_generic_rows_per_group(h->H, h->NIN, num_rows, h->num_cus_real);
-        if (rg > 0) push(SbChunk{7, 0, num_rows, cdiv(num_rows, rg), 0, rg, 0, 0, rg, 0, 0});
-        return p;
-    }
-    auto cost_of = [&](const std::vector<SbChunk>& v) { double c = 0; for (const SbChunk& k : v) c += est_step_us(h, k); return c; };
-    const bool rowtile_ok = h->rowtile_ok;                     // a one-tile-per-CU kernel exists for this cell / size
-    const bool coop_on = h->lstm_coop != 0 || !rowtile_ok;     // (without one the column-split kernels are the only path)
-    const SbChunk whole = rowtile_chunk(h, 0, num_rows);
-    // bf16-ih mode (configs[4]) only changes the row-tile kernel: sequences that run on a column-split kernel (small
-    // batches, remainder tiles) stay fp32 - more accurate and, there, faster
-    if (!coop_on) { push(whole); return p; }
-    // candidates: everything column-split; one launch of the row-tile kernel (VALU rows / extra rounds as needed); full
-    // rounds of the row-tile kernel + the remainder column-split (must be `composite_gain` cheaper than the single launch)
-    const int full = h->num_cus * 32, q = num_rows / full, rem = num_rows - q * full;
-    std::vector<SbChunk> best;
-    double best_cost = 1e30;
-    if (cdiv(num_rows, 32) <= 4 * h->num_cus_real || !rowtile_ok) {        // (bounded: the shortest path is O(tiles x shapes))
-        const std::vector<SbChunk> cols = plan_columns(h, 0, num_rows);
-        if (!cols.empty()) { best = cols; best_cost = cost_of(cols); }
-    }
-    if (rowtile_ok) {
-        const double cw = est_step_us(h, whole);
-        if (cw < best_cost) { best = {whole}; best_cost = cw; }
-        if (q >= 1 && rem > 0) {
-            std::vector<SbChunk> comp{SbChunk{0, 0, q * full, q * h->num_cus, 0, 32, 0, 0, 0, 0, 0}};
-            const std::vector<SbChunk> rc = plan_columns(h, q * full, rem);
-            if (!rc.empty()) {
-                comp.insert(comp.end(), rc.begin(), rc.end());
-                const double cc = cost_of(comp);
-                if (cc < h->composite_gain * cw && cc < best_cost) { best = comp; best_cost = cc; }
-            }
-        }
-    }
-    // half tiles (lstm16.hip, LSTM at the default sizes, fp32): 16 CUs-worth of sequences per round in about half the time of a
-    // 32-row round - the cheapest shape between the column-split kernels' range and a chip-filling round (parity-mode B = 32:
-    // 4096 sequences = 256 half tiles, one launch), alone or as one full round + a column-split remainder
-    if (h->lstm16_ok && h->ih_bf16 == 0) {
-        const int per_round = h->num_cus * 16;
-        const SbChunk all16{4, 0, num_rows, cdiv(num_rows, 16), 0, 16, 0, 0, 0, 0, 0};
-        const double c_all = est_step_us(h, all16);
-        if (c_all < best_cost) { best = {all16}; best_cost = c_all; }
-        if (num_rows > per_round) {
-            std::vector<SbChunk> comp{SbChunk{4, 0, per_round, h->num_cus, 0, 16, 0, 0, 0, 0, 0}};
-            const std::vector<SbChunk> rc = plan_columns(h, per_round, num_rows - per_round);
-            if (!rc.empty()) {
-                comp.insert(comp.end(), rc.begin(), rc.end());
-                const double cc = cost_of(comp);
-                if (cc < best_cost) { best = comp; best_cost = cc; }
-            }
-        }
-    }
-    for (const SbChunk& c : best) push(c);                     // empty = "this device cannot run the model"
-    return p;
-}
+// The planner itself (cost table, launch shapes, shortest path over tile counts) is host-only code: planner.h / planner.cpp.
+static PlannerCtx pctx(const fsnp_handle* h);
+static SbPlan plan_sb(const fsnp_handle* h, int num_rows) { return plan_sb(pctx(h), num_rows); }
+static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) { return chunk_workgroups(pctx(h), c); }
 // Launches chunks [first, last) of the plan on stream s.  `bar` = per-tile arrival counters followed (at bar +
 // plan.coop_tiles, 64-byte aligned by the caller) by the launch-abort word.
 static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmArgs& a, float* hx, unsigned* bar, unsigned* abort_word,
@@ -986,7 +775,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
     if (cfg->sb_hidden < 1 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be >= 1"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
-    if (cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }
+    if (cfg->model != FSNP_MODEL_FULLSUBNET && cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }      // (TCN GEMM tiles; the reference hard-codes 512)
     if (cfg->norm_type < 0 || cfg->norm_type > 3) { set_error("unknown norm_type %d", cfg->norm_type); return 2; }
     if (cfg->attention < 0 || cfg->attention > 3) { set_error("unknown attention model %d", cfg->attention); return 2; }
     if (cfg->model != FSNP_MODEL_FULLSUBNET_PLUS && cfg->model != FSNP_MODEL_FULLSUBNET) { set_error("unknown model %d", cfg->model); return 2; }
@@ -1903,7 +1692,7 @@ int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int3
 int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                           int32_t workgroups_per_cu, const double* costs, int32_t* out, int32_t max_chunks) {
     if (!out || num_rows <= 0 || num_cus <= 0 || hidden < 128 || hidden % 128 != 0 || max_chunks <= 0) { set_error("fsnp_debug_plan_rows: bad argument"); return -1; }
-    fsnp_handle h;                      // host-only: the planner never touches the device
+    PlannerCtx h;                       // host-only: the planner never touches the device
     h.H = hidden; h.num_cus = num_cus; h.num_cus_real = num_cus; h.gru = gru; h.lstm_coop = coop; h.composite_gain = composite_gain;
     h.cost = default_costs(); h.coop_occ = workgroups_per_cu >= 2 ? 2 : 1;
     for (int i = 0; i < 4; ++i) h.occ_ksplit[i] = h.coop_occ;
@@ -1922,7 +1711,7 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
     if (gru == 2) h.cost.rowtile *= 0.75;
-    const SbPlan plan = plan_sb(&h, num_rows);
+    const SbPlan plan = plan_sb(h, num_rows);
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
@@ -1989,6 +1778,25 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
         out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind == 7 ? 11 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
+    }
+    return n;
+}
+
+int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks) {
+    if (!h || !out || batch <= 0 || max_chunks <= 0) { set_error("fsnp_describe_plan_ex: bad argument"); return -1; }
+    int32_t base[4 * 64];
+    const int n = fsnp_describe_plan(h, batch, mode, base, max_chunks < 64 ? max_chunks : 64);
+    if (n < 0) return n;
+    const SbPlan plan = plan_sb(h, batch * rows_per_utt(h, mode));
+    for (int i = 0; i < n; ++i) {
+        const SbChunk& c = plan.chunks[i];
+        for (int k = 0; k < 4; ++k) out[6 * i + k] = base[4 * i + k];
+        // arithmetic of THIS chunk: the bf16 variants exist for the one-tile-per-CU LSTM kernel only (lstm.hip / lstm_bf3.hip);
+        // sequences that the plan hands to any other kernel run in fp32 whatever fsnp_set_precision says
+        int prec = 0;
+        if (!h->sb_tcn && !h->gru && c.kind == 0) prec = h->ih_bf16 == 1 ? 1 : (h->ih_bf16 == 2 && c.ex == 0) ? 2 : 0;
+        out[6 * i + 4] = prec;
+        out[6 * i + 5] = h->sb_tcn ? 0 : chunk_workgroups(h, c);
     }
     return n;
 }

@@ -483,10 +483,11 @@ class _HipModel(nn.Module):
         return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "lstm_first_chunk_ms": ms[3], "count": int(cnt[0])}
 
     def describe_plan(self, batch, parity=False):
-        """-> [{"kernel", "sequences", "tiles", "valu_rows"}, ...]: how the sub-band sequences of a `batch`-utterance
-        forward are cut into kernel launches (fsnp_describe_plan)."""
-        buf = (ctypes.c_int32 * 64)()
-        n = _lib.load().fsnp_describe_plan(self._handle, int(batch), int(parity), buf, 16)
+        """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups"}, ...]: how the sub-band sequences of a
+        `batch`-utterance forward are cut into kernel launches, and the arithmetic each launch runs in under the current
+        set_precision mode (fsnp_describe_plan_ex)."""
+        buf = (ctypes.c_int32 * 96)()
+        n = _lib.load().fsnp_describe_plan_ex(self._handle, int(batch), int(parity), buf, 16)
         if n < 0:
             raise RuntimeError(_lib.last_error())
         names = {0: ("gru2_fc_kernel" if self.sequence_model == "GRU" else "lstm2_fc_kernel") + " (one 32-row tile per CU)",
@@ -496,8 +497,9 @@ class _HipModel(nn.Module):
                  5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
                  **{6 + r: f"lstm2_coop_pp_kernel (K split, fused phase, {r} row tile{'s' if r > 1 else ''} per group in turn)" for r in (1, 2, 3, 4)}}
-        return [{"kernel": names[buf[4 * i]], "sequences": buf[4 * i + 1], "tiles": buf[4 * i + 2], "valu_rows": buf[4 * i + 3]}
-                for i in range(n)]
+        prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}
+        return [{"kernel": names[buf[6 * i]], "sequences": buf[6 * i + 1], "tiles": buf[6 * i + 2], "valu_rows": buf[6 * i + 3],
+                 "precision": prec[buf[6 * i + 4]], "workgroups": buf[6 * i + 5]} for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
         """Test hook: pin the planner's cost table (24 values, fsnp_get_costs order; None = built-in) and whether it may put

@@ -212,6 +212,11 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
  *  FSNP_COOP_PP=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
+/* The same with 6 ints per record: {kernel, sequences, tiles, VALU rows, precision, workgroups}; precision = the arithmetic of
+ * THAT launch under the handle's fsnp_set_precision mode: 0 = fp32, 1 = fp32 with the layer-1 ih-GEMM in bf16 (BASELINE
+ * configs[4]), 2 = fp32 emulated by split bf16.  The bf16 variants exist for the one-tile-per-CU LSTM kernel only: the
+ * sequences a plan hands to any other kernel (small batches, the remainder of a chip-filling batch) run in fp32. */
+int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
  * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU} when the
  * launch is full, out[14..17] = the same four with ONE row tile (costs in between are interpolated in the tile count),
