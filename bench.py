@@ -285,8 +285,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, committed; NOT "
-                                       "re-measured by this run)" if traffic is not None else None,
+                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of round 3 by "
+                                       "tools/gpu_r03_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
