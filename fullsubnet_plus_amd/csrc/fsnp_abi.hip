@@ -425,8 +425,6 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
         ca.coop_skew = h->coop_skew;
         ca.coop_split = c.kind == 1 && c.rpg ? 1 : 0;
-        static const int fc_split = [] { const char* e = getenv("FSNP_FC_SPLIT"); return e && e[0] == '0' ? 0 : 1; }();
-        ca.coop_fc_split = fc_split;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
         // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)

@@ -194,8 +194,6 @@ struct LstmArgs {
     unsigned* coop_bar2;       // second counter per row tile (layer-skewed K-split kernel: finished layer-1 phases)
     int coop_skew;             // lstm_coop.hip: 1 = layer-skewed schedule (lstm2_coop_skew_kernel)
     int coop_split;            // lstm_coop.hip: 1 = role-split schedule (lstm2_coop_split_kernel: 2 S workgroups per row tile)
-    int coop_fc_split;         // lstm_coop.hip (8 / 16 units): 1 = the Linear's partial-sum loads are issued behind the barrier and consumed after the
-                               // layer-1 MFMA pass instead of a load-and-sum chain on the critical path of slice 0 (FSNP_FC_SPLIT=0: off)
     unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64

@@ -308,34 +308,17 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         __syncthreads();
         return abort_s == 0;
     };
-    // Workgroup cs == 0 sums the S partials of step t_done in a fixed order.  Round 3: in two halves - the S loads are ISSUED right
-    // behind the barrier and CONSUMED after the layer-1 MFMA pass, so their round trip (they were a serial ~1.5 us on the critical
-    // path of slice 0, which every other slice then waited for at the next barrier) hides behind the pass.
-    constexpr bool FC_SPLIT = !SEQ && UNITS <= 16;       // (32 / 64 units: the register file is full, S <= 12 partials are a short chain)
-    float fcv[SEQ ? 1 : S];
-    auto fc_issue = [&](int t_done) {
-        if constexpr (!SEQ) {
-            if (cs == 0 && tid < 64) {
-                const float* part = fcp + (size_t)(t_done & 1) * S * 64 + (tid >> 5) * 32 + (tid & 31);
-#pragma unroll
-                for (int p = 0; p < S; ++p) fcv[p] = xchg_load(part + p * 64);
-            }
+    auto fc_epilogue = [&](int t_done) {     // workgroup cs == 0 sums the S partials of step t_done in a fixed order
+        if (cs == 0 && tid < 64) {
+            const int row = tid & 31, o = tid >> 5;
+            const RowDesc rd = rows_s[row];
+            const float* part = fcp + (size_t)(t_done & 1) * S * 64;
+            float sum = w.bfc[o];
+            for (int p = 0; p < S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
+            if (rd.valid && t_done >= a.LA)
+                a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
         }
     };
-    auto fc_finish = [&](int t_done) {
-        if constexpr (!SEQ) {
-            if (cs == 0 && tid < 64) {
-                const int row = tid & 31, o = tid >> 5;
-                const RowDesc rd = rows_s[row];
-                float sum = w.bfc[o];
-#pragma unroll
-                for (int p = 0; p < S; ++p) sum += fcv[p];
-                if (rd.valid && t_done >= a.LA)
-                    a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
-            }
-        }
-    };
-    auto fc_epilogue = [&](int t_done) { fc_issue(t_done); fc_finish(t_done); };
 
     __syncthreads();
 
@@ -396,7 +379,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         }
         if (!inter_wg_barrier((unsigned)S * (unsigned)(t + 1))) return;   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
 
-        if constexpr (!SEQ) { if (t > 0) { if (FC_SPLIT && a.coop_fc_split) fc_issue(t - 1); else fc_epilogue(t - 1); } }
+        if constexpr (!SEQ) { if (t > 0) fc_epilogue(t - 1); }
 
         // ---------------- layer 1: [h1_{t-1} | h0_t] ----------------
 #pragma unroll
@@ -409,7 +392,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
         else
             coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(2 + prv, i); },
                                               [&](int i) -> float4 { return hload(cur, i); });
-        if constexpr (FC_SPLIT) { if (t > 0 && a.coop_fc_split) fc_finish(t - 1); }
         publish_tiles(acc);
         {
             float* img = reinterpret_cast<float*>(h1img[cur]);
@@ -654,30 +636,17 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         __syncthreads();
         return abort_s == 0;
     };
-    // slice 0 sums the S partials of step t_done in a fixed order; the loads are issued behind the wait that makes them visible and
-    // consumed after the layer-1 MFMA pass that follows (see lstm2_coop_kernel)
-    // (only where registers are to spare: at 32 / 64 units the kernel uses the whole file, and S <= 12 partials are a short chain)
-    constexpr bool FC_SPLIT = UNITS <= 16;
-    float fcv[S];
-    auto fc_issue = [&](int t_done) {
-        if (cs == 0 && tid < 64) {
-            const float* part = fcp + (size_t)(t_done & 1) * S * 64 + (tid >> 5) * 32 + (tid & 31);
-#pragma unroll
-            for (int p = 0; p < S; ++p) fcv[p] = xchg_load(part + p * 64);
-        }
-    };
-    auto fc_finish = [&](int t_done) {
+    auto fc_epilogue = [&](int t_done) {     // slice 0 sums the S partials of step t_done in a fixed order
         if (cs == 0 && tid < 64) {
             const int row = tid & 31, o = tid >> 5;
             const RowDesc rd = rows_s[row];
+            const float* part = fcp + (size_t)(t_done & 1) * S * 64;
             float sum = w.bfc[o];
-#pragma unroll
-            for (int p = 0; p < S; ++p) sum += fcv[p];
+            for (int p = 0; p < S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
             if (rd.valid && t_done >= a.LA)
                 a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
         }
     };
-    auto fc_epilogue = [&](int t_done) { fc_issue(t_done); fc_finish(t_done); };
 
     // A_t: layer 0 of step t.  m3 = t % 3, pm3 = (t - 1) % 3
     unsigned early0 = 0, early1 = 0;                    // counters as read ahead of the next waits
@@ -717,7 +686,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         }
         if (with_c) {
             if (!wait_for(bar1, (unsigned)S * (unsigned)(t - 1), early1)) return false;   // h1_{t-2}, Linear partials of step t-2
-            if (FC_SPLIT && a.coop_fc_split && t >= 2) fc_issue(t - 2);
             if constexpr (!WREG) {
                 const int h1p = h1off(t & 1), h0c = h0off(pm3);      // C_{t-1} reads h1_{t-2} (parity t & 1) and h0_{t-1}
                 coop_layer_prefill<NT, G1W, KGH / 4, G0W>(ca, cb, ws, [&](int i) -> float4 { return hload(h1p, i); },
@@ -728,7 +696,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         return true;
     };
     // C_t: layer 1 of step t over [h1_{t-1} | h0_t]
-    auto phase_c = [&](int t, int m3, bool prefilled, int fc_done) {      // fc_done >= 0: the step whose Linear loads are in flight
+    auto phase_c = [&](int t, int m3, bool prefilled) {
         const int cur = t & 1, prv = cur ^ 1;
         f32x16 acc[NT];
 #pragma unroll
@@ -746,7 +714,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
             coop_layer_run<NT, G1W, KGH / 4, G0W>(acc, ca, cb, ws, [&](int i) -> float4 { return hload(h1p, i); },
                                                   [&](int i) -> float4 { return hload(h0c, i); });
         }
-        if (FC_SPLIT && a.coop_fc_split && fc_done >= 0) fc_finish(fc_done);
         early0 = poll_early(bar0);                       // for the wait in front of the next A phase
         publish_tiles(acc);
         float* img = reinterpret_cast<float*>(hx + h1off(cur));
@@ -770,15 +737,15 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
     for (int t = 1; t < Tp; ++t) {
         if (!wait_for(bar0, (unsigned)S * (unsigned)t, early0)) return;            // h0_{t-1} published by every slice
         if (!phase_a(t, m3, pm3, true)) return;                                    // (waits for b1 >= S (t-1) inside)
-        if (!(FC_SPLIT && a.coop_fc_split) && t >= 2) fc_epilogue(t - 2);
-        phase_c(t - 1, pm3, !WREG, t >= 2 ? t - 2 : -1);
+        if (t >= 2) fc_epilogue(t - 2);
+        phase_c(t - 1, pm3, !WREG);
         pm3 = m3;
         m3 = m3 == 2 ? 0 : m3 + 1;
     }
     if (!wait_for(bar0, (unsigned)S * (unsigned)Tp, early0)) return;
     if (!wait_for(bar1, (unsigned)S * (unsigned)(Tp - 1), Tp >= 2 ? poll_early(bar1) : 0u)) return;
     if (Tp >= 2) fc_epilogue(Tp - 2);
-    phase_c(Tp - 1, pm3, false, -1);
+    phase_c(Tp - 1, pm3, false);
     if (!wait_for(bar1, (unsigned)S * (unsigned)Tp, 0u)) return;
     fc_epilogue(Tp - 1);
 }
