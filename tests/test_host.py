@@ -433,6 +433,28 @@ def test_column_split_kernels_keep_their_asm_invariants():
         assert r["sc1_loads"] > 0 and r["sc1_stores"] > 0, (name, r)
 
 
+def test_round3_kernels_keep_their_asm_invariants():
+    """Static checks of the round-3 kernels (tools/check_lstm_asm.py).  lstm2_coop_pp_kernel: no scratch, no cache maintenance, the
+    exchange images are written with 16-byte sc1 stores and read with 16-byte sc1 loads, and every
+    MFMA of the time loop takes its weights from an AGPR (the pinning survived the compiler).  lstm2_generic_kernel: plain FMAs, no
+    MFMA, no scratch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pp = mod.analyse_ping_pong()
+    assert len(pp) == 16, sorted(pp)                          # H 256 / 384 x K 40 / 64 x 1..4 tiles per group
+    for name, r in pp.items():
+        assert r["scratch"] == 0 and r["cache_maint"] == 0, (name, r)
+        # (the only dword sc1 stores left are the abort / error words of the bounded waits: two per wait site, 3 + 2 R sites)
+        assert r["sc1_stores16"] >= 3 and r["sc1_loads16"] >= 16 and r["sc1_stores4"] <= 2 * (3 + 2 * int(re.search(r"ELi(\d)EEEv", name).group(1))), (name, r)
+        assert r["mfma"] >= 100 and r["mfma_b_in_agpr"] >= 0.9 * r["mfma"], (name, r)
+    gen = mod.analyse_generic()
+    assert len(gen) == 8, sorted(gen)                         # 1 / 2 / 4 / 8 sequences per workgroup x {sub-band, full-band}
+    for name, r in gen.items():
+        assert r["mfma"] == 0 and r["scratch"] == 0 and r["fma"] > 0 and r["ds_read128"] > 0, (name, r)
+
+
 # ---------------------------------------------------------------- sub-band planner (fsnp_abi.hip plan_sb), host only
 def _plan(rows, cus=256, gru=0, coop=1, gain=0.97):
     import ctypes as ct

@@ -14,8 +14,9 @@ from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_state_dict  #
 n, steps = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 seq = os.environ.get("SEQ", "LSTM")
-m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": seq})
-m.load_state_dict(make_state_dict(0, "default", sequence_model=seq), strict=True)
+hidden = int(os.environ.get("HIDDEN", "384"))          # e.g. 320: no tuned instantiation -> the runtime-sized kernel
+m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "sequence_model": seq, "sb_model_hidden_size": hidden})
+m.load_state_dict(make_state_dict(0, "default", sequence_model=seq, sb_hidden=hidden), strict=True)
 m = m.to("cuda").eval()
 torch.manual_seed(1234 + n)
 x = torch.randn(n, 34, steps, device="cuda")
@@ -40,4 +41,4 @@ for _ in range(reps):
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
 m.check_errors()
-print(f"PP_R={os.environ.get('PP_R')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
+print(f"H={hidden} PP_R={os.environ.get('PP_R')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
