@@ -8,12 +8,12 @@
 // now it runs here: plain fp32 FMAs (v_fma_f32), every size a run-time argument.
 //   * a workgroup owns RG sequences (1, 2, 4 or 8: fewer when there are few sequences, so that more CUs work) and keeps their
 //     x_t, h0, h1, c0, c1 and the pre-activations of one layer in LDS;
-//   * thread c of a 256-column chunk owns gate column c of all RG rows: per 4 k it issues 4 coalesced weight loads
+//   * thread c of a 1024-column chunk owns gate column c of all RG rows: per 4 k it issues 4 coalesced weight loads
 //     (wT[k][column], a transposed copy packed at fsnp_commit_weights) and RG broadcast ds_read_b128 of the operands;
 //   * cell update, Linear(H, OUT) epilogue / h1 sequence output, input gather and normalisation as in the tuned kernels
 //     (same LstmArgs, same four-slot gate layout: LSTM i, f, g, o; GRU r, z, n_x, n_h).
-// Speed is not the point (B = 1 at hidden 320: ~6 ms per forward against 2.2 ms on the tuned kernels at 384); results meet the
-// same oracle tolerance (tests/test_gpu_parity.py::test_generic_recurrent_kernel_*).
+// Speed is not the point (hidden 320, 128 steps: 9.8 ms at B = 1, 76 ms at B = 32 against 2.2 / 27.3 ms on the tuned kernels at 384);
+// results meet the same oracle tolerance (tests/test_gpu_parity.py::test_generic_recurrent_kernel_*).
 #include "fsnp_common.h"
 #include "lstm_common.h"
 
@@ -32,8 +32,12 @@ inline size_t gen_smem_floats(int RG, int H, int NIN) { return (size_t)RG * (gen
 
 // SEQ = true: the full-band model of the original FullSubNet (dense rows of NIN features, per-frame (m, d) table, h1 sequence
 // out, no Linear); SEQ = false: the sub-band model (gathered or dense input, fused Linear + activation + look-ahead slice).
+// 1024 threads: the kernel is bound by the latency of its weight stream (every column reads K weights from L2 per step) and LDS
+// allows one workgroup per CU, so the workgroup itself brings the 16 waves that hide it.
+constexpr int kGenThreads = 1024;
 template <int RG, bool SEQ>
-__global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmArgs a) {
+__global__ __launch_bounds__(kGenThreads) void lstm2_generic_kernel(LstmWeights w, LstmArgs a) {
+    constexpr int NTHR = kGenThreads;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int H = w.H, NIN = w.NIN, OUT = w.OUT, G4 = 4 * H;
     const int HP = gen_pad4(H), NINP = gen_pad4(NIN);
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
     const int Tp = a.Tp;
     const bool gru = w.gru != 0;
     if (tid < RG) rows_s[tid] = a.rows[slot0 + tid];
-    for (int i = tid; i < RG * (NINP + 8 * HP); i += 256) gsm[i] = 0.0f;
+    for (int i = tid; i < RG * (NINP + 8 * HP); i += NTHR) gsm[i] = 0.0f;
     __syncthreads();
 
     const bool dense = a.dense != nullptr;
@@ -59,16 +63,34 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
     const float* wT0 = w.wgen;                                   // [NIN + H][4H]
     const float* wT1 = w.wgen + (size_t)(NIN + H) * G4;          // [2H][4H]
 
-    // acc[r] += sum_k wT[k][col] * op[r][k]   (op rows of stride `ld` floats in LDS, 16-byte aligned, zero padded to 4)
+    // acc[r] += sum_k wT[k][col] * op[r][k]   (op rows of stride `ld` floats in LDS, 16-byte aligned, zero padded to 4).
+    // Blocks of 16 k, software-pipelined: the 16 coalesced weight loads of block b + 1 are in flight while block b is multiplied
+    // (without the pipeline every block waited out an L2 round trip: 400 us per step at B = 1 instead of ~45).
     auto accumulate = [&](float (&acc)[RG], const float* wT, int col, const float* op, int ld, int K) {
+        constexpr int KB = 16;                   // k per block: 16 weight loads in flight per thread
         int k = 0;
-        for (; k + 4 <= K; k += 4) {
-            const float w0 = wT[(size_t)k * G4 + col], w1 = wT[(size_t)(k + 1) * G4 + col];
-            const float w2 = wT[(size_t)(k + 2) * G4 + col], w3 = wT[(size_t)(k + 3) * G4 + col];
+        if (K >= KB) {
+            float wn[KB];
 #pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const float4 v = *reinterpret_cast<const float4*>(op + r * ld + k);
-                acc[r] = fmaf(w0, v.x, acc[r]); acc[r] = fmaf(w1, v.y, acc[r]); acc[r] = fmaf(w2, v.z, acc[r]); acc[r] = fmaf(w3, v.w, acc[r]);
+            for (int j = 0; j < KB; ++j) wn[j] = wT[(size_t)j * G4 + col];
+            for (; k + KB <= K; k += KB) {
+                float wc[KB];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) wc[j] = wn[j];
+                if (k + 2 * KB <= K) {
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) wn[j] = wT[(size_t)(k + KB + j) * G4 + col];
+                }
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    float t = acc[r];
+#pragma unroll
+                    for (int q = 0; q < KB / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(op + r * ld + k + 4 * q);
+                        t = fmaf(wc[4 * q], v.x, t); t = fmaf(wc[4 * q + 1], v.y, t); t = fmaf(wc[4 * q + 2], v.z, t); t = fmaf(wc[4 * q + 3], v.w, t);
+                    }
+                    acc[r] = t;
+                }
             }
         }
         for (; k < K; ++k) {
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
     };
     // one layer: pre = bias + W [opA | opB], then the cell update of every (row, unit) into (c, h)
     auto layer = [&](const float* wT, const float* bias, const float* opA, int ldA, int KA, const float* opB, int KB, float* c, float* h) {
-        for (int col = tid; col < G4; col += 256) {
+        for (int col = tid; col < G4; col += NTHR) {
             float acc[RG];
             const float b = bias[col];
 #pragma unroll
@@ -90,7 +112,7 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
             for (int r = 0; r < RG; ++r) pre[r * 4 * HP + col] = acc[r];
         }
         __syncthreads();
-        for (int i = tid; i < RG * H; i += 256) {
+        for (int i = tid; i < RG * H; i += NTHR) {
             const int r = i / H, u = i % H;
             const float* p = pre + r * 4 * HP;
             float hv;
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
 
     for (int t = 0; t < Tp; ++t) {
         // ---- x_t of the RG rows, normalised
-        for (int i = tid; i < RG * NIN; i += 256) {
+        for (int i = tid; i < RG * NIN; i += NTHR) {
             const int r = i / NIN, j = i % NIN;
             const RowDesc rd = rows_s[r];
             float v = 0.0f;
@@ -131,13 +153,13 @@ __global__ __launch_bounds__(256) void lstm2_generic_kernel(LstmWeights w, LstmA
         layer(wT1, w.bias + G4, h0, HP, H, h1, H, c1, h1);             // layer 1 over [h0_t | h1_{t-1}]
         if constexpr (SEQ) {
             const int ss = a.seq_stride > 0 ? a.seq_stride : H;        // (pad columns [H, ss) are written as zeros: a GEMM operand)
-            for (int i = tid; i < RG * ss; i += 256) {
+            for (int i = tid; i < RG * ss; i += NTHR) {
                 const int r = i / ss, u = i % ss;
                 const RowDesc rd = rows_s[r];
                 if (rd.valid) a.seq_out[((size_t)rd.b * Tp + t) * ss + u] = u < H ? h1[r * HP + u] : 0.0f;
             }
         } else {
-            for (int item = wave; item < RG * OUT; item += 4) {        // Linear(H, OUT): a wave per (row, output), K across the lanes
+            for (int item = wave; item < RG * OUT; item += NTHR / 64) {        // Linear(H, OUT): a wave per (row, output), K across the lanes
                 const int r = item / OUT, o = item % OUT;
                 float s = 0.0f;
                 for (int u = lane; u < H; u += 64) s = fmaf(w.wfc[(size_t)o * H + u], h1[r * HP + u], s);
@@ -173,7 +195,10 @@ void lstm_generic_pack_weights(int H, int NIN, const float* wih0, const float* w
 
 // sequences per workgroup: as many as LDS allows, fewer when there are few sequences (more CUs take part); 0 = does not fit at all
 int lstm_generic_rows_per_group(int H, int NIN, int num_seq, int num_cus) {
-    int rg = num_seq >= 8 * num_cus ? 8 : num_seq >= 4 * num_cus ? 4 : num_seq >= 2 * num_cus ? 2 : 1;
+    // every workgroup streams ALL the weights from L2 once per step (5 MB at hidden 320), so few sequences per workgroup means
+    // weight traffic, many means idle CUs: 4 from 128 sequences up (B = 1: 65 workgroups), 8 once 8 x the CUs are filled
+    (void)num_cus;
+    int rg = num_seq >= 2048 ? 8 : num_seq >= 128 ? 4 : num_seq >= 32 ? 2 : 1;
     while (rg > 1 && gen_smem_floats(rg, H, NIN) * 4 > (size_t)150 * 1024) rg /= 2;
     return gen_smem_floats(rg, H, NIN) * 4 <= (size_t)150 * 1024 ? rg : 0;
 }
@@ -185,12 +210,12 @@ static void launch_generic_rg(const LstmWeights& w, const LstmArgs& a, bool seq,
         auto k = lstm2_generic_kernel<RG, true>;
         static PerDeviceOnce once;
         once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
-        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     } else {
         auto k = lstm2_generic_kernel<RG, false>;
         static PerDeviceOnce once;
         once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
-        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(256), smem, s, w, a);
+        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     }
 }
 
