@@ -1,6 +1,6 @@
-// fsnp_abi.hip - C ABI of libfsnp_hip.so (include/fsnp.h): handle, strict weight loading + packing,
-// workspace management and the forward orchestration.  Host code only; kernels live in
-// frontend.hip / tcn.hip / subband.hip / lstm.hip.
+// fsnp_abi.hip - C ABI of libfsnp_hip.so (include/fsnp.h): handle life cycle, workspace management, the forward orchestration and
+// the tuning / test hooks.  Host code only; kernels live in frontend.hip / tcn.hip / subband.hip / lstm*.hip; the planner in
+// planner.cpp, weight packing in fsnp_weights.hip, the STFT entry points in fsnp_stft_abi.hip (shared declarations: fsnp_handle.h).
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +15,7 @@
 #include "fsnp_common.h"
 #include "lstm_common.h"
 #include "planner.h"
+#include "fsnp_handle.h"
 
 namespace fsnp {
 
@@ -29,141 +30,9 @@ void set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 
-struct WeightSpec {
-    std::string name;
-    int64_t numel;
-};
-
-struct Workspace {
-    // offsets in bytes from the workspace base
-    size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, sbt_x0, sbt_x, sbt_fb, sbt_y1, sbt_y2, zero_begin,
-        fsum, gn, sb_acc, coop_hx, coop_bar, coop_abort, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
-};
-
-// The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1); it
-// can be captured once per (shape, mode, plan) into a hipGraph and replayed (opt-in: FSNP_GRAPH=1).  Measured: no gain -
-// the launches are asynchronous and the host runs ahead of the GPU, so the chain is bound by the kernels' own latency.
-struct GraphKey {
-    int B, T, mode, boff, gb, num_cus, coop, bf16, debug;
-    const void* ws;
-    const void* weights;
-    bool operator==(const GraphKey& o) const {
-        return B == o.B && T == o.T && mode == o.mode && boff == o.boff && gb == o.gb && num_cus == o.num_cus &&
-               coop == o.coop && bf16 == o.bf16 && debug == o.debug && ws == o.ws && weights == o.weights;
-    }
-};
-struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
-
-struct TimingRec {
-    hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
-};
-
-// Every entry point that touches the device runs on the handle's device and puts the caller's current device back.
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-#define FSNP_ON_DEVICE(h)                                                              \
-    fsnp::DeviceGuard _dev_guard((h)->device);                                         \
-    if (!_dev_guard.ok) { fsnp::set_error("hipSetDevice(%d) failed", (h)->device); return 1; }
-
 }  // namespace fsnp
 
 using namespace fsnp;
-
-struct fsnp_handle {
-    fsnp_config cfg{};
-    int device = 0;
-    int F = 0, FP = 0, CH = 0, H = 0, NSB = 0, NIN = 0, KX = 0, NB = 0, Fr = 0;
-    std::vector<WeightSpec> specs;
-    std::map<std::string, std::vector<float>> host_w;
-    bool committed = false;
-
-    float* d_weights = nullptr;
-    FrontendWeights fw{};
-    TcnWeights tw{};
-    LstmWeights lw{};
-    // original FullSubNet only: full-band 2-layer LSTM(F -> CH) (cooperative kernel) + Linear(CH, F) (GEMM)
-    int model = FSNP_MODEL_FULLSUBNET_PLUS;
-    int NFB = 3;                 // full-band features per sub-band frame: 3 (FullSubNet+) or 1 (FullSubNet)
-    int gru = 0;                 // 1 = nn.GRU cells (sub-band model; FullSubNet: also the full-band model)
-    bool lstm16_ok = false;      // the half-tile kernel (lstm16.hip) exists for this handle (LSTM, H = 384, K = 40) and is enabled
-    bool rowtile_ok = true;      // a one-tile-per-CU kernel (lstm.hip / lstm_gru.hip) exists for this handle's sub-band model
-    CostTable cost{};            // per-step costs the planner minimises (defaults, then measured on the device)
-    int coop_occ = 1;            // workgroups per CU the column-split kernels may be planned with (FSNP_COOP_OCC; 1 or 2) ...
-    int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};   // ... and what each instantiation really fits (measured at commit)
-    int calibrate = 0;           // FSNP_CALIBRATE=1: replace the built-in table by one measured on this device at the first planning call
-    int sb_tcn = 0;              // 1 = the sub-band model is a TCN stack (FullSubNet+ with sequence_model="TCN")
-    TcnWeights sbt{};            //     its weights (one branch, NIN input channels)
-    int XS = 0;                  //     row stride of its [slot][t][NIN] activations
-    int NG = 4;                  // gate blocks per weight matrix: 4 (LSTM) or 3 (GRU)
-    LstmWeights fbw{};
-    const float* fsn_wf = nullptr;   // [F pad 384][CH pad 16]
-    const float* fsn_bf = nullptr;   // [F pad 384]
-    int fsn_kp = 0;
-    const float* d_refl_w = nullptr;
-    const float* d_refl_wfb = nullptr;
-
-    unsigned char* ws = nullptr;
-    size_t ws_bytes = 0;
-    Workspace last_ws{};
-    Dims last_dims{};
-    bool have_last = false;
-    bool debug = false;
-    int num_cus = 256;
-    int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
-    int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
-    int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
-    int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
-    int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
-    bool generic_sb = false;     // the sub-band recurrent model runs on the runtime-sized kernel (lstm_generic.hip): a hidden size or an
-                                 // input width no tuned kernel is instantiated for
-    bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
-    bool pp_ok = false;          // the ping-pong K-split kernel (lstm_pp.hip) exists for this handle's sub-band model
-    int coop_pp = 0, coop_pp_cfg = 0;   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
-    int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups
-                                 // per row tile), 0 = never, 2 = wherever it fits (FSNP_COOP_SPLIT, tuning)
-    unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
-                                 // so the NEXT call on the handle can fail loudly without a device synchronisation
-    int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
-
-    // STFT / iSTFT around the model (stft.hip): DFT GEMM operands, built on first use, and an I/O workspace
-    float* d_stft = nullptr;     // [fwd (2F pad 384) x n_fft][inv (n_fft pad 384) x (2F pad 16)][window n_fft][zero bias 768]
-    unsigned char* io = nullptr;
-    size_t io_bytes = 0;
-
-    double composite_gain = 0.97;   // a row-tile + remainder plan must be estimated this much cheaper to be chosen
-    int use_graph = 0;           // 0 = plain launches (default: measured no gain), 1 = replay on the
-                                 // private stream, 2 = replay straight into the caller's stream (FSNP_GRAPH=1|2)
-    hipStream_t cap_stream = nullptr;   // private stream: graph capture and replay
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    std::vector<GraphEntry> graphs;
-
-    bool timing = false;
-    std::vector<TimingRec> timing_recs;   // recorded, not yet read back (drained by fsnp_get_timing, or when 256 pile up)
-    std::vector<hipEvent_t> event_pool;   // events are re-used: a forward with timing on allocates nothing in steady state
-    double acc_ms[4] = {0, 0, 0, 0};
-    int64_t acc_cnt[4] = {0, 0, 0, 0};
-
-    // pipelined serving mode (fsnp_set_pipeline): the column-split remainder chunks that follow a row-tile chunk run on
-    // `side_stream`, so that they overlap the full-band stages of the NEXT forward (which leave most CUs idle); the
-    // workspace is double buffered because forward i+1 rebuilds att / fb while the remainder of forward i still reads them
-    int pipeline = 0;
-    int defer_small = 1;         // pipelined mode: plans that start with a column-split launch run on the side stream whole (FSNP_DEFER_SMALL=0: off)
-    int ws_slots = 1, ws_slot = 0;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
-    bool side_used[2] = {false, false};
-    unsigned char* last_base = nullptr;   // workspace half of the last forward (fsnp_read_stage)
-    hipEvent_t ev_done = nullptr;         // end of the last forward on its stream: a forward on another stream waits for it
-    hipStream_t done_stream = nullptr;
-    bool done_valid = false;
-};
 
 namespace fsnp {
 
@@ -180,14 +49,8 @@ static PlannerCtx pctx(const fsnp_handle* h) {
     return c;
 }
 
-static const int kDilations[8] = {1, 2, 5, 9, 1, 2, 5, 9};  // sequence_model.py:48-57
-static const char* kAtt[3] = {"channel_attention", "channel_attention_real", "channel_attention_imag"};
-static const char* kFb[3] = {"fb_model", "fb_model_real", "fb_model_imag"};
-static const char* kConvNames[3] = {"smallConv1d", "middleConv1d", "largeConv1d"};
 
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-static void drop_graphs(fsnp_handle* h) {
+void drop_graphs(fsnp_handle* h) {
     for (auto& e : h->graphs) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
     h->graphs.clear();
 }
@@ -237,97 +100,6 @@ static int run_graphed(fsnp_handle* h, const GraphKey& key, hipStream_t s, F mid
     }
     h->graphs.push_back({key, g, ex});
     return launch_graph_between(h, ex, s);
-}
-
-static void build_specs(fsnp_handle* h) {
-    auto add = [&](const std::string& n, int64_t numel) { h->specs.push_back({n, numel}); };
-    const int F = h->F, CH = h->CH, H = h->H, Fr = h->Fr;
-    const int att = h->cfg.attention;
-    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
-    if (fsn) {   // fullsubnet.py:39-47: SequenceModel(257 -> 512 x 2 -> 257), same key layout as nn.LSTM
-        const std::string f = "fb_model.sequence_model.";
-        const int64_t G = h->NG;
-        add(f + "weight_ih_l0", G * CH * F);
-        add(f + "weight_hh_l0", G * CH * CH);
-        add(f + "bias_ih_l0", G * CH);
-        add(f + "bias_hh_l0", G * CH);
-        add(f + "weight_ih_l1", G * CH * CH);
-        add(f + "weight_hh_l1", G * CH * CH);
-        add(f + "bias_ih_l1", G * CH);
-        add(f + "bias_hh_l1", G * CH);
-        add("fb_model.fc_output_layer.weight", (int64_t)F * CH);
-        add("fb_model.fc_output_layer.bias", F);
-    }
-    for (int a = 0; a < 3 && !fsn; ++a) {
-        const std::string p = kAtt[a];
-        if (att == FSNP_ATT_TSSE) {
-            for (int c = 0; c < 3; ++c) {
-                add(p + "." + kConvNames[c] + ".0.weight", (int64_t)F * h->cfg.kersize[c]);
-                add(p + "." + kConvNames[c] + ".0.bias", F);
-            }
-            add(p + ".feature_concate_fc.weight", 3);
-            add(p + ".feature_concate_fc.bias", 1);
-        }
-        if (att == FSNP_ATT_ECA) {
-            add(p + ".conv.weight", 3);
-        } else {
-            add(p + ".fc1.weight", (int64_t)Fr * F);
-            add(p + ".fc1.bias", Fr);
-            add(p + ".fc2.weight", (int64_t)F * Fr);
-            add(p + ".fc2.bias", F);
-        }
-    }
-    for (int b = 0; b < 3 && !fsn; ++b) {
-        for (int i = 0; i < h->NB; ++i) {
-            const std::string p = std::string(kFb[b]) + ".sequence_model." + std::to_string(i);
-            add(p + ".conv1x1.weight", (int64_t)CH * F);
-            add(p + ".conv1x1.bias", CH);
-            add(p + ".prelu1.weight", 1);
-            add(p + ".norm1.weight", CH);
-            add(p + ".norm1.bias", CH);
-            add(p + ".depthwise_conv.weight", (int64_t)CH * 3);
-            add(p + ".depthwise_conv.bias", CH);
-            add(p + ".prelu2.weight", 1);
-            add(p + ".norm2.weight", CH);
-            add(p + ".norm2.bias", CH);
-            add(p + ".sconv.weight", (int64_t)F * CH);
-            add(p + ".sconv.bias", F);
-        }
-        add(std::string(kFb[b]) + ".fc_output_layer.weight", (int64_t)F * F);
-        add(std::string(kFb[b]) + ".fc_output_layer.bias", F);
-    }
-    if (h->sb_tcn) {
-        for (int i = 0; i < 8; ++i) {
-            const std::string p = "sb_model.sequence_model." + std::to_string(i);
-            add(p + ".conv1x1.weight", (int64_t)CH * h->NIN);
-            add(p + ".conv1x1.bias", CH);
-            add(p + ".prelu1.weight", 1);
-            add(p + ".norm1.weight", CH);
-            add(p + ".norm1.bias", CH);
-            add(p + ".depthwise_conv.weight", (int64_t)CH * 3);
-            add(p + ".depthwise_conv.bias", CH);
-            add(p + ".prelu2.weight", 1);
-            add(p + ".norm2.weight", CH);
-            add(p + ".norm2.bias", CH);
-            add(p + ".sconv.weight", (int64_t)h->NIN * CH);
-            add(p + ".sconv.bias", h->NIN);
-        }
-        add("sb_model.fc_output_layer.weight", (int64_t)h->cfg.output_size * h->NIN);
-        add("sb_model.fc_output_layer.bias", h->cfg.output_size);
-        return;
-    }
-    const std::string s = "sb_model.sequence_model.";
-    const int64_t G = h->NG;
-    add(s + "weight_ih_l0", G * H * h->NIN);
-    add(s + "weight_hh_l0", G * H * H);
-    add(s + "bias_ih_l0", G * H);
-    add(s + "bias_hh_l0", G * H);
-    add(s + "weight_ih_l1", G * H * H);
-    add(s + "weight_hh_l1", G * H * H);
-    add(s + "bias_ih_l1", G * H);
-    add(s + "bias_hh_l1", G * H);
-    add("sb_model.fc_output_layer.weight", (int64_t)h->cfg.output_size * H);
-    add("sb_model.fc_output_layer.bias", h->cfg.output_size);
 }
 
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
@@ -537,11 +309,11 @@ static int ensure_workspace(fsnp_handle* h, size_t bytes, hipStream_t s) {
     return 0;
 }
 // Orders `s` behind the last forward of this handle if that ran on ANOTHER stream (the workspace is shared by all of them)
-static int order_after_last_forward(fsnp_handle* h, hipStream_t s) {
+int order_after_last_forward(fsnp_handle* h, hipStream_t s) {
     if (h->done_valid && h->done_stream != s) FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_done, 0));
     return 0;
 }
-static int mark_forward_done(fsnp_handle* h, hipStream_t s) {
+int mark_forward_done(fsnp_handle* h, hipStream_t s) {
     if (!h->ev_done) FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     FSNP_HIP_CHECK(hipEventRecord(h->ev_done, s));
     h->done_stream = s; h->done_valid = true;
@@ -915,314 +687,6 @@ void fsnp_destroy(fsnp_handle* h) {
     delete h;
 }
 
-int fsnp_num_weights(const fsnp_handle* h) { return h ? (int)h->specs.size() : 0; }
-
-int fsnp_weight_info(const fsnp_handle* h, int index, const char** name, int64_t* numel) {
-    if (!h || index < 0 || index >= (int)h->specs.size()) { set_error("fsnp_weight_info: bad index"); return 1; }
-    if (name) *name = h->specs[index].name.c_str();
-    if (numel) *numel = h->specs[index].numel;
-    return 0;
-}
-
-int fsnp_set_weight(fsnp_handle* h, const char* name, const float* host_data, int64_t numel) {
-    if (!h || !name || !host_data) { set_error("fsnp_set_weight: null argument"); return 1; }
-    for (const auto& s : h->specs) {
-        if (s.name == name) {
-            if (s.numel != numel) {
-                set_error("size mismatch for %s: expected %lld elements, got %lld", name, (long long)s.numel, (long long)numel);
-                return 2;
-            }
-            h->host_w[s.name].assign(host_data, host_data + numel);
-            h->committed = false;
-            return 0;
-        }
-    }
-    set_error("unexpected key in state_dict: %s", name);
-    return 2;
-}
-
-int fsnp_commit_weights(fsnp_handle* h) {
-    if (!h) { set_error("null handle"); return 1; }
-    for (const auto& s : h->specs)
-        if (!h->host_w.count(s.name)) { set_error("missing key in state_dict: %s", s.name.c_str()); return 2; }
-    const int F = h->F, CH = h->CH, H = h->H, NB = h->NB, Fr = h->Fr;
-    std::vector<float> blob;
-    auto alloc = [&](size_t n) { size_t o = blob.size(); blob.resize(align_up(o + n, 64), 0.0f); return o; };
-    auto W = [&](const std::string& n) -> const std::vector<float>& { return h->host_w.at(n); };
-    auto put = [&](const std::string& n) { const auto& v = W(n); size_t o = alloc(v.size()); std::copy(v.begin(), v.end(), blob.begin() + o); return o; };
-
-    // ---- frontend (TSSE) : reference layouts are already what the kernels want
-    size_t o_conv_w[3][3] = {}, o_conv_b[3][3] = {}, o_cat_w[3] = {}, o_cat_b[3] = {}, o_fc1w[3] = {}, o_fc1b[3] = {},
-           o_fc2w[3] = {}, o_fc2b[3] = {};
-    const int att = h->cfg.attention;
-    const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
-    const int nbr_w = fsn ? 0 : 3;          // the original FullSubNet has neither attention nor TCN branches
-    for (int a = 0; a < nbr_w; ++a) {
-        const std::string p = kAtt[a];
-        if (att == FSNP_ATT_TSSE) {
-            for (int c = 0; c < 3; ++c) {
-                o_conv_w[a][c] = put(p + "." + kConvNames[c] + ".0.weight");
-                o_conv_b[a][c] = put(p + "." + kConvNames[c] + ".0.bias");
-            }
-            o_cat_w[a] = put(p + ".feature_concate_fc.weight");
-            o_cat_b[a] = put(p + ".feature_concate_fc.bias");
-        }
-        if (att == FSNP_ATT_ECA) {
-            o_cat_w[a] = put(p + ".conv.weight");            // the 3 taps of Conv1d(1,1,3) over the channel axis
-            continue;
-        }
-        {   // transposed copies: fc1 [Fr][F] -> [F][Fr], fc2 [F][Fr] -> [Fr][F]
-            const auto& w1 = W(p + ".fc1.weight");
-            o_fc1w[a] = alloc((size_t)F * Fr);
-            for (int o = 0; o < Fr; ++o)
-                for (int f = 0; f < F; ++f) blob[o_fc1w[a] + (size_t)f * Fr + o] = w1[(size_t)o * F + f];
-            const auto& w2 = W(p + ".fc2.weight");
-            o_fc2w[a] = alloc((size_t)Fr * F);
-            for (int o = 0; o < F; ++o)
-                for (int f = 0; f < Fr; ++f) blob[o_fc2w[a] + (size_t)f * F + o] = w2[(size_t)o * Fr + f];
-        }
-        o_fc1b[a] = put(p + ".fc1.bias");
-        o_fc2b[a] = put(p + ".fc2.bias");
-    }
-    // ---- TCN stacks (SequenceModel(sequence_model="TCN"), sequence_model.py:47-58,80-81): zero-padded row-major
-    // [N pad 384][K pad 16] GEMM operands, [model][block] major.  `cin` channels in / out of every TCNBlock, `fc_out` rows of
-    // the final Linear(cin, fc_out).  Used for the three full-band models and for a sub-band TCN.
-    struct TcnOff { size_t w1, b1, a1, g1w, g1b, dw, db, a2, g2w, g2b, w2, b2, w2g, c1, c2, wf, bf; int NB, N1P, K1P, N2P, K2P; };
-    auto pack_tcn = [&](const std::vector<std::string>& models, int nb, int cin, int fc_out) {
-        TcnOff t{};
-        const size_t nm = models.size() ? models.size() : 1;
-        t.NB = nb; t.N1P = (int)align_up(CH, 384); t.K1P = (int)align_up(cin, 16); t.N2P = (int)align_up(cin, 384); t.K2P = (int)align_up(CH, 16);
-        t.w1 = alloc(nm * nb * t.N1P * t.K1P); t.b1 = alloc(nm * nb * t.N1P); t.a1 = alloc(nm * nb + 1);
-        t.g1w = alloc(nm * nb * CH); t.g1b = alloc(nm * nb * CH);
-        t.dw = alloc(nm * nb * 3 * CH); t.db = alloc(nm * nb * CH); t.a2 = alloc(nm * nb + 1);
-        t.g2w = alloc(nm * nb * CH); t.g2b = alloc(nm * nb * CH);
-        t.w2 = alloc(nm * nb * t.N2P * t.K2P); t.b2 = alloc(nm * nb * t.N2P);
-        t.w2g = alloc(nm * nb * t.N2P * t.K2P); t.c1 = alloc(nm * nb * t.N2P); t.c2 = alloc(nm * nb * t.N2P);
-        t.wf = alloc(nm * t.N2P * t.K1P); t.bf = alloc(nm * t.N2P);
-        for (size_t b = 0; b < models.size(); ++b) {
-            for (int i = 0; i < nb; ++i) {
-                const std::string p = models[b] + ".sequence_model." + std::to_string(i);
-                const size_t bi = b * nb + i;
-                const auto& w1 = W(p + ".conv1x1.weight");           // [CH][cin][1]
-                for (int n = 0; n < CH; ++n)
-                    for (int k = 0; k < cin; ++k) blob[t.w1 + (bi * t.N1P + n) * t.K1P + k] = w1[(size_t)n * cin + k];
-                std::copy(W(p + ".conv1x1.bias").begin(), W(p + ".conv1x1.bias").end(), blob.begin() + t.b1 + bi * t.N1P);
-                blob[t.a1 + bi] = W(p + ".prelu1.weight")[0];
-                std::copy(W(p + ".norm1.weight").begin(), W(p + ".norm1.weight").end(), blob.begin() + t.g1w + bi * CH);
-                std::copy(W(p + ".norm1.bias").begin(), W(p + ".norm1.bias").end(), blob.begin() + t.g1b + bi * CH);
-                const auto& dw = W(p + ".depthwise_conv.weight");     // [CH][1][3] -> tap major
-                for (int c = 0; c < CH; ++c)
-                    for (int jj = 0; jj < 3; ++jj) blob[t.dw + (bi * 3 + jj) * CH + c] = dw[(size_t)c * 3 + jj];
-                std::copy(W(p + ".depthwise_conv.bias").begin(), W(p + ".depthwise_conv.bias").end(), blob.begin() + t.db + bi * CH);
-                blob[t.a2 + bi] = W(p + ".prelu2.weight")[0];
-                std::copy(W(p + ".norm2.weight").begin(), W(p + ".norm2.weight").end(), blob.begin() + t.g2w + bi * CH);
-                std::copy(W(p + ".norm2.bias").begin(), W(p + ".norm2.bias").end(), blob.begin() + t.g2b + bi * CH);
-                const auto& w2 = W(p + ".sconv.weight");              // [cin][CH][1]
-                for (int n = 0; n < cin; ++n)
-                    for (int k = 0; k < CH; ++k) blob[t.w2 + (bi * t.N2P + n) * t.K2P + k] = w2[(size_t)n * CH + k];
-                std::copy(W(p + ".sconv.bias").begin(), W(p + ".sconv.bias").end(), blob.begin() + t.b2 + bi * t.N2P);
-                // GroupNorm 2 folded into the sconv GEMM (tcn.hip tcn_gemm_dma_kernel): weights times gamma, and the two
-                // per-output constants of  sum_k ((a - m) r g_k + b_k) W[n][k] = r sum_k a g_k W[n][k] + c1[n] - r m c2[n]
-                const auto& g2 = W(p + ".norm2.weight");
-                const auto& be2 = W(p + ".norm2.bias");
-                const auto& sb2 = W(p + ".sconv.bias");
-                for (int n = 0; n < cin; ++n) {
-                    double s1 = sb2[n], s2 = 0.0;
-                    for (int k = 0; k < CH; ++k) {
-                        const double wv = w2[(size_t)n * CH + k];
-                        blob[t.w2g + (bi * t.N2P + n) * t.K2P + k] = (float)(wv * (double)g2[k]);
-                        s1 += (double)be2[k] * wv;
-                        s2 += (double)g2[k] * wv;
-                    }
-                    blob[t.c1 + bi * t.N2P + n] = (float)s1;
-                    blob[t.c2 + bi * t.N2P + n] = (float)s2;
-                }
-            }
-            const auto& wf = W(models[b] + ".fc_output_layer.weight");   // [fc_out][cin]: top rows of a zero-padded [N2P][K1P]
-            for (int n = 0; n < fc_out; ++n)
-                for (int k = 0; k < cin; ++k) blob[t.wf + (b * t.N2P + n) * t.K1P + k] = wf[(size_t)n * cin + k];
-            const auto& bf = W(models[b] + ".fc_output_layer.bias");
-            std::copy(bf.begin(), bf.end(), blob.begin() + t.bf + b * t.N2P);
-        }
-        return t;
-    };
-    auto bind_tcn = [&](TcnWeights& t, const TcnOff& o, const float* d) {
-        t.w1 = d + o.w1; t.b1 = d + o.b1; t.a1 = d + o.a1; t.g1w = d + o.g1w; t.g1b = d + o.g1b;
-        t.dw = d + o.dw; t.db = d + o.db; t.a2 = d + o.a2; t.g2w = d + o.g2w; t.g2b = d + o.g2b;
-        t.w2 = d + o.w2; t.b2 = d + o.b2; t.wf = d + o.wf; t.bf = d + o.bf;
-        t.w2g = d + o.w2g; t.c1 = d + o.c1; t.c2 = d + o.c2;
-        t.num_cus = h->num_cus; t.NB = o.NB; t.N1P = o.N1P; t.K1P = o.K1P; t.N2P = o.N2P; t.K2P = o.K2P;
-        for (int i = 0; i < o.NB; ++i) t.dilation[i] = kDilations[i];
-        const char* de = getenv("FSNP_GEMM_DMA");          // 0 = the general GEMM kernel everywhere (tuning / A-B)
-        t.gemm_dma = de && de[0] == '0' ? 0 : 1;
-    };
-    std::vector<std::string> fb_models;
-    for (int b = 0; b < nbr_w; ++b) fb_models.push_back(kFb[b]);
-    const TcnOff fb_off = pack_tcn(fb_models, NB, F, F);
-    const TcnOff sb_off = h->sb_tcn ? pack_tcn({"sb_model"}, 8, h->NIN, h->cfg.output_size) : TcnOff{};
-    // ---- recurrent models: MFMA B-fragment order + summed biases.  Every kernel sees FOUR column slots per hidden unit:
-    // LSTM i, f, g, o (the reference's gate order); GRU r, z, n_x, n_h with W_in only in the input rows of K and W_hn only
-    // in the hidden rows (zero blocks elsewhere), biases b_ir + b_hr, b_iz + b_hz, b_in, b_hn.
-    struct Rnn4 { std::vector<float> wih0, whh0, wih1, whh1, bias; };
-    auto expand = [&](const std::string& pre, int Hh, int nin) {
-        Rnn4 r;
-        const auto &a0 = W(pre + "weight_ih_l0"), &a1 = W(pre + "weight_hh_l0"), &a2 = W(pre + "weight_ih_l1"), &a3 = W(pre + "weight_hh_l1");
-        r.bias.assign((size_t)2 * 4 * Hh, 0.0f);
-        if (!h->gru) {
-            r.wih0 = a0; r.whh0 = a1; r.wih1 = a2; r.whh1 = a3;
-            for (int l = 0; l < 2; ++l) {
-                const auto& bi = W(pre + "bias_ih_l" + std::to_string(l));
-                const auto& bh = W(pre + "bias_hh_l" + std::to_string(l));
-                for (int i = 0; i < 4 * Hh; ++i) r.bias[(size_t)l * 4 * Hh + i] = bi[i] + bh[i];
-            }
-            return r;
-        }
-        auto spread = [&](const std::vector<float>& src, int cols, bool hidden) {   // [3H][cols] -> [4H][cols]
-            std::vector<float> dst((size_t)4 * Hh * cols, 0.0f);
-            std::copy(src.begin(), src.begin() + (size_t)2 * Hh * cols, dst.begin());                        // r, z
-            std::copy(src.begin() + (size_t)2 * Hh * cols, src.end(), dst.begin() + (size_t)(hidden ? 3 : 2) * Hh * cols);   // n
-            return dst;
-        };
-        r.wih0 = spread(a0, nin, false); r.whh0 = spread(a1, Hh, true);
-        r.wih1 = spread(a2, Hh, false); r.whh1 = spread(a3, Hh, true);
-        for (int l = 0; l < 2; ++l) {
-            const auto& bi = W(pre + "bias_ih_l" + std::to_string(l));
-            const auto& bh = W(pre + "bias_hh_l" + std::to_string(l));
-            float* b = r.bias.data() + (size_t)l * 4 * Hh;
-            for (int i = 0; i < 2 * Hh; ++i) b[i] = bi[i] + bh[i];
-            for (int i = 0; i < Hh; ++i) { b[2 * Hh + i] = bi[2 * Hh + i]; b[3 * Hh + i] = bh[2 * Hh + i]; }
-        }
-        return r;
-    };
-    const Rnn4 sbw = h->sb_tcn ? Rnn4{} : expand("sb_model.sequence_model.", H, h->NIN);
-    const bool tuned = !h->sb_tcn && !h->generic_sb;            // MFMA kernels exist for this cell / hidden size / input width
-    size_t o_wgen = 0;
-    if (h->generic_sb) {                                        // runtime-sized kernel: transposed [layer][k][4H]
-        o_wgen = alloc(lstm_generic_pack_floats(H, h->NIN));
-        lstm_generic_pack_weights(H, h->NIN, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wgen);
-    }
-    size_t o_wpack = 0, o_wpack12 = 0, o_wpack_bf[2] = {0, 0};
-    if (!h->gru && tuned && (H == 384 || H == 256)) {      // the row-tile kernel (and its bf16 variant) exists for LSTM only
-        o_wpack = alloc(lstm_pack_floats(H, h->KX, 4));
-        lstm_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack);
-        if (H == 384) {
-            o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
-            lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
-        }
-        for (int i = 0; i < 2 && h->KX == 40 && H == 384; ++i) {      // the bf16-ih variant is built for the default input width only
-            const int nw = i == 0 ? 4 : 12;
-            o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
-            lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
-                                     blob.data() + o_wpack_bf[i]);
-        }
-    }
-    size_t o_wpack16 = 0;
-    if (h->lstm16_ok) {
-        o_wpack16 = alloc(lstm16_pack_floats(H, h->KX));
-        lstm16_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack16);
-    }
-    size_t o_wpack_bf3 = 0;
-    if (!h->gru && tuned && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
-        o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
-        lstm_bf3_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_bf3);
-    }
-    size_t o_wpack_gru = 0;
-    if (h->gru && tuned && H == 384) {
-        o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
-        gru_pack_weights(H, h->NIN, h->KX, 4, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_gru);
-    }
-    size_t o_wpack_coop[4] = {0, 0, 0, 0};
-    for (int ui = 0; ui < 4 && tuned; ++ui) {
-        const int units = 8 << ui;
-        o_wpack_coop[ui] = alloc(lstm_coop_pack_floats(H, h->KX, units));
-        lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
-                               blob.data() + o_wpack_coop[ui]);
-    }
-    const size_t o_wpack_coopn = alloc(tuned ? lstm_coopn_pack_floats(H, h->KX) : 0);
-    if (tuned)
-        lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
-                                blob.data() + o_wpack_coopn);
-    // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
-    constexpr int KXF = 264;
-    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0, o_fbgen = 0;
-    const int fsn_kp = (int)align_up(CH, 16), fsn_np = (int)align_up(F, 384);
-    if (fsn) {
-        const Rnn4 fbw = expand("fb_model.sequence_model.", CH, F);
-        if (h->generic_fb) {
-            o_fbgen = alloc(lstm_generic_pack_floats(CH, F));
-            lstm_generic_pack_weights(CH, F, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(), blob.data() + o_fbgen);
-        }
-        for (int ui = 0; ui < 3 && !h->generic_fb; ++ui) {
-            const int units = 8 << ui;
-            o_fbpack[ui] = alloc(lstm_coop_pack_floats(CH, KXF, units));
-            lstm_coop_pack_weights(CH, F, KXF, units, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(),
-                                   blob.data() + o_fbpack[ui]);
-        }
-        o_fbbias = alloc(fbw.bias.size());
-        std::copy(fbw.bias.begin(), fbw.bias.end(), blob.begin() + o_fbbias);
-        o_fsn_wf = alloc((size_t)fsn_np * fsn_kp);
-        const auto& wf = W("fb_model.fc_output_layer.weight");          // [F][CH]
-        for (int n = 0; n < F; ++n)
-            for (int k = 0; k < CH; ++k) blob[o_fsn_wf + (size_t)n * fsn_kp + k] = wf[(size_t)n * CH + k];
-        o_fsn_bf = alloc(fsn_np);
-        const auto& bf = W("fb_model.fc_output_layer.bias");
-        std::copy(bf.begin(), bf.end(), blob.begin() + o_fsn_bf);
-    }
-    const size_t o_lbias = alloc(sbw.bias.size());
-    std::copy(sbw.bias.begin(), sbw.bias.end(), blob.begin() + o_lbias);
-    const size_t o_wfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.weight");
-    const size_t o_bfc = h->sb_tcn ? 0 : put("sb_model.fc_output_layer.bias");
-    // ---- unfold multiplicities w_r, by brute force over (f, j)
-    const size_t o_refl = alloc(F), o_reflfb = alloc(F);
-    for (int f = 0; f < F; ++f) {
-        for (int j = 0; j < h->NSB; ++j) blob[o_refl + reflect_index(f - h->cfg.sb_num_neighbors + j, F)] += 1.0f;
-        for (int j = 0; j < 2 * h->cfg.fb_num_neighbors + 1; ++j) blob[o_reflfb + reflect_index(f - h->cfg.fb_num_neighbors + j, F)] += 1.0f;
-    }
-
-    FSNP_ON_DEVICE(h);
-    drop_graphs(h);
-    if (h->d_weights) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->d_weights)); h->d_weights = nullptr; }
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_weights), blob.size() * sizeof(float)));
-    FSNP_HIP_CHECK(hipMemcpy(h->d_weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
-    const float* d = h->d_weights;
-    for (int a = 0; a < 3; ++a) {
-        for (int c = 0; c < 3; ++c) { h->fw.conv_w[a][c] = d + o_conv_w[a][c]; h->fw.conv_b[a][c] = d + o_conv_b[a][c]; }
-        h->fw.cat_w[a] = d + o_cat_w[a]; h->fw.cat_b[a] = d + o_cat_b[a];
-        h->fw.fc1_wT[a] = d + o_fc1w[a]; h->fw.fc1_b[a] = d + o_fc1b[a];
-        h->fw.fc2_wT[a] = d + o_fc2w[a]; h->fw.fc2_b[a] = d + o_fc2b[a];
-    }
-    for (int c = 0; c < 3; ++c) h->fw.ksize[c] = h->cfg.kersize[c];
-    h->fw.attention = h->cfg.attention;
-    h->fw.subband_num = h->cfg.subband_num > 0 ? h->cfg.subband_num : 1;
-    bind_tcn(h->tw, fb_off, d);
-    h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
-    h->lw.wpack_coopn = d + o_wpack_coopn;
-    h->lw.wpack_gru = d + o_wpack_gru;
-    h->lw.wpack_bf3 = d + o_wpack_bf3;
-    h->lw.wpack16 = d + o_wpack16;
-    h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
-    h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
-    h->lw.wgen = d + o_wgen;
-    if (h->sb_tcn) bind_tcn(h->sbt, sb_off, d);
-    if (fsn) {
-        h->fbw = LstmWeights{};
-        for (int ui = 0; ui < 3; ++ui) h->fbw.wpack_coop[ui] = d + o_fbpack[ui];
-        h->fbw.bias = d + o_fbbias;
-        h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0; h->fbw.gru = h->gru;
-        h->fbw.wgen = d + o_fbgen;
-        h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
-    }
-    h->d_refl_w = d + o_refl;
-    h->d_refl_wfb = d + o_reflfb;
-    if (tuned) {                                // which column-split instantiations fit twice on a CU (registers, LDS)
-        for (int ui = 0; ui < 4; ++ui) h->occ_ksplit[ui] = std::max(1, lstm_coop_occupancy(h->lw, 8 << ui));
-        for (int rpg = 1; rpg <= 2; ++rpg) h->occ_coopn[rpg - 1] = std::max(1, lstm_coopn_occupancy(h->lw, rpg));
-    }
-    h->committed = true;
-    (void)Fr;
-    return 0;
-}
-
 size_t fsnp_workspace_bytes(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode) {
     if (!h || batch <= 0 || frames <= 0) return 0;
     return plan_workspace(h, batch, frames, mode).total;
@@ -1453,69 +917,6 @@ int fsnp_forward_complex(fsnp_handle* h, const float* noisy, const int64_t strid
     return forward_impl(h, noisy, nullptr, nullptr, true, st, out, batch, frames, mode, batch_offset, global_batch, hip_stream);
 }
 
-// ---------------------------------------------------------------------------------------------- STFT / iSTFT (f-3)
-namespace fsnp {
-struct StftPlan {
-    int n_fft, hop, F, N2, sp;          // sp = padded float stride of one internal spectrum row (multiple of 4)
-    size_t o_fwd, o_inv, o_win, o_zero, total;   // float offsets inside d_stft
-    int inv_ld;
-};
-static StftPlan stft_plan(const fsnp_handle* h) {
-    StftPlan p{};
-    p.F = h->F; p.n_fft = 2 * (h->F - 1); p.hop = p.n_fft / 2; p.N2 = 2 * p.F; p.sp = (int)align_up(p.N2, 4);
-    p.inv_ld = (int)align_up(p.N2, 16);
-    p.o_fwd = 0;
-    p.o_inv = p.o_fwd + align_up(p.N2, 384) * (size_t)p.n_fft;
-    p.o_win = p.o_inv + align_up(p.n_fft, 384) * (size_t)p.inv_ld;
-    p.o_zero = p.o_win + align_up(p.n_fft, 64);
-    p.total = p.o_zero + align_up(p.N2 > p.n_fft ? p.N2 : p.n_fft, 384);
-    return p;
-}
-static int ensure_stft(fsnp_handle* h) {
-    if (h->d_stft) return 0;
-    if (h->F < 3 || ((h->F - 1) & (h->F - 2)) != 0) { set_error("STFT: num_freqs - 1 must be a power of two (n_fft = 2 (num_freqs - 1))"); return 2; }
-    const StftPlan p = stft_plan(h);
-    std::vector<float> host(p.total, 0.0f);
-    stft_build_matrices(p.n_fft, host.data() + p.o_fwd, host.data() + p.o_inv, host.data() + p.o_win);
-    FSNP_ON_DEVICE(h);
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_stft), p.total * sizeof(float)));
-    FSNP_HIP_CHECK(hipMemcpy(h->d_stft, host.data(), p.total * sizeof(float), hipMemcpyHostToDevice));
-    return 0;
-}
-static int ensure_io(fsnp_handle* h, size_t bytes, hipStream_t s) {      // stream-ordered, like ensure_workspace
-    if (bytes <= h->io_bytes) return 0;
-    if (order_after_last_forward(h, s)) return 4;
-    unsigned char* nio = nullptr;
-    FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&nio), bytes, s));
-    if (h->io) FSNP_HIP_CHECK(hipFreeAsync(h->io, s));
-    h->io = nio;
-    h->io_bytes = bytes;
-    return 0;
-}
-__global__ void spec_repack_kernel(const float2* __restrict__ in, long sb, long sf, long st, float2* __restrict__ out, int B,
-                                   int F, int T, int spc) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (b, t, f) over the padded row of spc complex elements
-    if (i >= (long)B * T * spc) return;
-    const int f = (int)(i % spc), t = (int)((i / spc) % T), b = (int)(i / ((long)spc * T));
-    out[i] = f < F ? in[b * sb + f * sf + t * st] : make_float2(0.f, 0.f);
-}
-// wav [B][L] -> spectrum rows [B][T][ldc] (interleaved complex), T = 1 + L / hop
-static void stft_into(fsnp_handle* h, const StftPlan& p, const float* wav, long wav_stride, float* xp, long xs, float* spec,
-                      int ldc, int B, int L, hipStream_t s) {
-    const int T = 1 + L / p.hop;
-    launch_stft_pad(wav, wav_stride, xp, xs, B, L, p.n_fft, s);
-    launch_linear_act(xp, p.hop, h->d_stft + p.o_fwd, p.n_fft, h->d_stft + p.o_zero, spec, ldc, p.n_fft, p.N2, B, T,
-                      FSNP_ACT_NONE, h->num_cus, s, xs, p.n_fft);
-}
-// spectrum rows [B][T][sp] -> wav [B][L]
-static void istft_from(fsnp_handle* h, const StftPlan& p, const float* spec, float* frames, float* wav, long wav_stride, int B,
-                       int T, int L, hipStream_t s) {
-    launch_linear_act(spec, p.sp, h->d_stft + p.o_inv, p.inv_ld, h->d_stft + p.o_zero, frames, p.n_fft, p.N2, p.n_fft, B, T,
-                      FSNP_ACT_NONE, h->num_cus, s, (long)T * p.sp, p.N2);
-    launch_istft_ola(frames, h->d_stft + p.o_win, wav, wav_stride, B, T, L, p.n_fft, s);
-}
-}  // namespace fsnp
-
 int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t mode, int32_t max_samples, void* hip_stream) {
     if (!h || max_batch <= 0 || max_frames <= 0 || max_samples < 0) { set_error("fsnp_reserve: bad argument"); return 1; }
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
@@ -1540,81 +941,6 @@ int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t 
         const size_t mask_b = align_up((size_t)max_batch * 2 * p.F * T * 4, 256), fr_b = (size_t)max_batch * T * p.n_fft * 4;
         if (ensure_io(h, xp_b + 2 * spec_b + mask_b + fr_b, s)) return 4;
     }
-    return mark_forward_done(h, s);
-}
-
-int fsnp_stft(fsnp_handle* h, const float* wav, int64_t wav_stride, float* spec, int32_t batch, int32_t samples, void* hip_stream) {
-    if (!h || !wav || !spec) { set_error("fsnp_stft: null argument"); return 1; }
-    if (batch <= 0) { set_error("fsnp_stft: empty input"); return 2; }
-    if (ensure_stft(h)) return 2;
-    const StftPlan p = stft_plan(h);
-    if (samples <= p.hop) { set_error("fsnp_stft: need more than n_fft/2 = %d samples (reflect padding)", p.hop); return 2; }
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_ON_DEVICE(h);
-    const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
-    if (order_after_last_forward(h, s)) return 4;
-    if (ensure_io(h, (size_t)batch * xs * 4, s)) return 4;
-    stft_into(h, p, wav, wav_stride, reinterpret_cast<float*>(h->io), xs, spec, p.N2, batch, samples, s);
-    FSNP_HIP_CHECK(hipGetLastError());
-    return mark_forward_done(h, s);
-}
-
-int fsnp_istft(fsnp_handle* h, const float* spec, const int64_t strides[3], float* wav, int64_t wav_stride, int32_t batch,
-               int32_t frames, int32_t samples, void* hip_stream) {
-    if (!h || !spec || !strides || !wav) { set_error("fsnp_istft: null argument"); return 1; }
-    if (batch <= 0 || frames <= 0 || samples <= 0) { set_error("fsnp_istft: empty input"); return 2; }
-    if (ensure_stft(h)) return 2;
-    const StftPlan p = stft_plan(h);
-    if ((long)(frames - 1) * p.hop + p.n_fft < (long)samples + p.hop) { set_error("fsnp_istft: %d frames do not cover %d samples", frames, samples); return 2; }
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_ON_DEVICE(h);
-    const size_t spec_b = align_up((size_t)batch * frames * p.sp * 4 + 256, 256), fr_b = (size_t)batch * frames * p.n_fft * 4;
-    if (order_after_last_forward(h, s)) return 4;
-    if (ensure_io(h, spec_b + fr_b, s)) return 4;
-    float* sp = reinterpret_cast<float*>(h->io);
-    float* fr = reinterpret_cast<float*>(h->io + spec_b);
-    const long n = (long)batch * frames * (p.sp / 2);
-    hipLaunchKernelGGL(spec_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2*>(spec),
-                       (long)strides[0], (long)strides[1], (long)strides[2], reinterpret_cast<float2*>(sp), batch, p.F, frames, p.sp / 2);
-    istft_from(h, p, sp, fr, wav, wav_stride, batch, frames, samples, s);
-    FSNP_HIP_CHECK(hipGetLastError());
-    return mark_forward_done(h, s);
-}
-
-int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, float* out, int64_t out_stride, int32_t batch,
-                      int32_t samples, void* hip_stream) {
-    if (!h || !wav || !out) { set_error("fsnp_enhance_wave: null argument"); return 1; }
-    if (batch <= 0) { set_error("fsnp_enhance_wave: empty input"); return 2; }
-    if (!h->committed) { set_error("fsnp_enhance_wave: weights not committed (call fsnp_commit_weights)"); return 2; }
-    if (ensure_stft(h)) return 2;
-    const StftPlan p = stft_plan(h);
-    if (samples <= p.hop) { set_error("fsnp_enhance_wave: need more than n_fft/2 = %d samples (reflect padding)", p.hop); return 2; }
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    FSNP_ON_DEVICE(h);
-    const int T = 1 + samples / p.hop;
-    const long xs = (long)align_up((size_t)samples + p.n_fft, 4);
-    const size_t xp_b = align_up((size_t)batch * xs * 4, 256), spec_b = align_up((size_t)batch * T * p.sp * 4 + 256, 256);
-    const size_t mask_b = align_up((size_t)batch * 2 * p.F * T * 4, 256), fr_b = (size_t)batch * T * p.n_fft * 4;
-    if (order_after_last_forward(h, s)) return 4;
-    if (ensure_io(h, xp_b + 2 * spec_b + mask_b + fr_b, s)) return 4;
-    float* xp = reinterpret_cast<float*>(h->io);
-    float* noisy = reinterpret_cast<float*>(h->io + xp_b);
-    float* enh = reinterpret_cast<float*>(h->io + xp_b + spec_b);
-    float* mask = reinterpret_cast<float*>(h->io + xp_b + 2 * spec_b);
-    float* fr = reinterpret_cast<float*>(h->io + xp_b + 2 * spec_b + mask_b);
-    // inferencer.py:142-158: stft -> (mag, real, imag) -> model -> decompress_cIRM, complex multiply -> istft(length)
-    stft_into(h, p, wav, wav_stride, xp, xs, noisy, p.sp, batch, samples, s);
-    const int64_t cst[3] = {(int64_t)T * (p.sp / 2), 1, p.sp / 2};       // complex-element strides of [B][T][sp/2] as (b, f, t)
-    const int rc = fsnp_forward_complex(h, noisy, cst, mask, batch, T, FSNP_MODE_FULL, 0, batch, hip_stream);
-    if (rc) return rc;
-    // pipelined mode: the forward left chunks of the sub-band plan on the side stream (at B = 1 the whole plan); `mask` is read
-    // right here and lives in the single-buffered io area, so `s` waits for them now (fsnp_flush) - nothing of this call is deferred
-    if (h->pipeline && fsnp_flush(h, hip_stream)) return 4;
-    // the pad column of every row of `enh` is never written by apply_cirm and multiplies zero weights: clear it once
-    FSNP_HIP_CHECK(hipMemsetAsync(enh, 0, spec_b, s));
-    launch_apply_cirm(mask, noisy, cst, enh, cst, batch, p.F, T, s);
-    istft_from(h, p, enh, fr, out, out_stride, batch, T, samples, s);
-    FSNP_HIP_CHECK(hipGetLastError());
     return mark_forward_done(h, s);
 }
 
