@@ -51,9 +51,9 @@ SYMBOLS = {
     "fsnp_describe_plan_ex": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fsnp_reserve": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_dump_config": (ctypes.c_int64, [c_vp, ctypes.c_char_p, ctypes.c_int64]),
-    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 24), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 26), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fsnp_debug_plan_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 24)]),
+    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 26)]),
     "fsnp_debug_set_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), c_i32]),
     "fsnp_debug_plan_rows2": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(c_i32), c_i32]),
@@ -80,7 +80,7 @@ SYMBOLS = {
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 7          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 8          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

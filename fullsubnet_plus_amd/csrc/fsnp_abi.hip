@@ -41,7 +41,7 @@ static PlannerCtx pctx(const fsnp_handle* h) {
     PlannerCtx c;
     c.H = h->H; c.NIN = h->NIN; c.num_cus = h->num_cus; c.num_cus_real = h->num_cus_real;
     c.gru = h->gru != 0; c.sb_tcn = h->sb_tcn != 0; c.generic_sb = h->generic_sb; c.rowtile_ok = h->rowtile_ok; c.lstm16_ok = h->lstm16_ok;
-    c.pp_ok = h->pp_ok; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
+    c.pp_ok = h->pp_ok; c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
     for (int i = 0; i < 4; ++i) c.occ_ksplit[i] = h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) c.occ_coopn[i] = h->occ_coopn[i];
     c.coop_split = h->coop_split; c.coop_pp = h->coop_pp; c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
@@ -193,8 +193,9 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         if (c.kind == 4) { launch_lstm16(h->lw, ca, s); continue; }
         if (c.kind == 7) { ca.coop_rows_per_group = c.rpg; launch_lstm_generic(h->lw, ca, false, s); continue; }
         ca.coop_hx = hx + (size_t)c.coop_tile0 * hx_floats_per_tile;
-        ca.coop_bar = bar + c.coop_tile0;
-        ca.coop_bar2 = bar + plan.coop_tiles + c.coop_tile0;      // second half of the counter array
+        ca.coop_bar = bar + (size_t)c.coop_tile0 * kCoopCounterStride;
+        ca.coop_bar_stride = kCoopCounterStride;
+        ca.coop_bar2 = nullptr;
         ca.coop_skew = h->coop_skew;
         ca.coop_split = c.kind == 1 && c.rpg ? 1 : 0;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
@@ -209,11 +210,13 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
         static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
         {
-            const int S = c.kind == 1 ? (h->H / c.units) * (c.rpg ? 2 : 1) : h->H / 128, T = c.kind == 1 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
+            const int S = c.kind == 8 ? h->H / 16 : c.kind == 1 ? (h->H / c.units) * (c.rpg ? 2 : 1) : h->H / 128;
+            const int T = c.kind == 1 || c.kind == 8 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
             ca.coop_xcd = c.kind != 6 && xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
             if (c.kind == 6) launch_lstm_pp(h->lw, ca, s);
+            else if (c.kind == 8) launch_lstm_hp(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
         });
@@ -271,7 +274,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
-    w.coop_bar = take((size_t)plan.coop_tiles * 2 * 4);      // two arrival counters per row tile
+    w.coop_bar = take(coop_counter_bytes(plan.coop_tiles));      // two arrival counters per row tile (+ the padded copies: lstm_common.h)
     w.coop_abort = take(256);             // [0] sub-band launches, [16] full-band LSTM (FullSubNet)
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
@@ -370,7 +373,7 @@ static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, fl
     const bool coop = plan.coop_tiles != 0;
     const size_t coop_off = align_up((size_t)num_slots * sizeof(RowDesc), 256);
     const size_t coop_hx_bytes = coop ? align_up(lstm_coop_exchange_bytes(h->H, plan.coop_tiles), 256) : 0;
-    const size_t coop_bar_bytes = align_up((size_t)plan.coop_tiles * 2 * 4, 256);
+    const size_t coop_bar_bytes = align_up(coop_counter_bytes(plan.coop_tiles), 256);
     const size_t coop_bytes = coop ? coop_hx_bytes + coop_bar_bytes + 256 : 0;       // images, counters, abort word
     if (order_after_last_forward(h, s)) return 4;
     if (ensure_workspace(h, coop_off + coop_bytes, s)) return 4;
@@ -457,7 +460,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     auto time_shape = [&](SbChunk c) -> double {
         c.row0 = 0; c.nrows = c.num_tiles * c.rps; c.slot0 = 0; c.coop_tile0 = 0;
         SbPlan plan;
-        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 6) ? c.num_tiles : 0;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 6 || c.kind == 8) ? c.num_tiles : 0;
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
@@ -506,6 +509,11 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         if (groups <= 0) break;
         const double us = time_shape(SbChunk{6, 0, 0, groups * rpg, 0, 32, 8, groups, rpg, 0, 0});
         if (us < 0) rc = 4; else t.pp[rpg - 1] = us;
+    }
+    if (rc == 0 && h->hp_ok && h->num_cus_real / (h->H / 16) > 0) {
+        const int cap = h->num_cus_real / (h->H / 16);
+        const double u1 = time_shape(SbChunk{8, 0, 0, 1, 0, 32, 16, 0, 0, 0, 0}), uf = time_shape(SbChunk{8, 0, 0, cap, 0, 32, 16, 0, 0, 0, 0});
+        if (u1 < 0 || uf < 0) rc = 4; else { t.hp[0] = u1; t.hp[1] = uf; }
     }
     if (rc == 0 && h->lstm16_ok) {
         const double us16 = time_shape(SbChunk{4, 0, 0, h->num_cus_real, 0, 16, 0, 0, 0, 0, 0});
@@ -640,6 +648,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         h->coop_pp = pe && pe[0] == '1' ? 1 : 0;
         h->coop_pp_cfg = h->coop_pp;
         h->pp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
+        // The half-tile ping-pong kernel (lstm_hp.hip): FSNP_COOP_HP=1 lets the planner use it, 0 never
+        const char* he = getenv("FSNP_COOP_HP");
+        h->coop_hp = he ? (he[0] == '1' ? 1 : 0) : 0;
+        h->coop_hp_cfg = h->coop_hp;
+        h->hp_ok = h->pp_ok;
     }
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
@@ -1030,8 +1043,11 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
         for (int i = 0; i < 4; ++i) h.cost.ksplit1[i] = costs[14 + i];
         h.cost.rowtile16 = costs[18];
         for (int i = 0; i < 4; ++i) h.cost.pp[i] = costs[20 + i];
+        h.cost.hp[0] = costs[24]; h.cost.hp[1] = costs[25];
     }
     h.pp_ok = gru == 0 && (hidden == 384 || hidden == 256);
+    h.hp_ok = h.pp_ok;
+    h.coop_hp = costs != nullptr;
     h.coop_pp = costs != nullptr;          // (a caller's table prices the ping-pong launches in or out; the built-in plans do not use them)
     h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
@@ -1049,7 +1065,7 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     return n;
 }
 
-int fsnp_get_costs(const fsnp_handle* h, double out[24], int32_t* calibrated, int32_t* occ) {
+int fsnp_get_costs(const fsnp_handle* h, double out[26], int32_t* calibrated, int32_t* occ) {
     if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
     for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
@@ -1057,12 +1073,13 @@ int fsnp_get_costs(const fsnp_handle* h, double out[24], int32_t* calibrated, in
     for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
     out[18] = h->cost.rowtile16; out[19] = 0.0;
     for (int i = 0; i < 4; ++i) out[20 + i] = h->cost.pp[i];
+    out[24] = h->cost.hp[0]; out[25] = h->cost.hp[1];
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
     return 0;
 }
 
-int fsnp_measure_costs(fsnp_handle* h, double out[24]) {
+int fsnp_measure_costs(fsnp_handle* h, double out[26]) {
     if (!h || !out) { set_error("fsnp_measure_costs: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_measure_costs: weights not committed"); return 2; }
     if (h->sb_tcn) { set_error("fsnp_measure_costs: the sub-band model of this handle is a TCN (no recurrent kernels)"); return 2; }
@@ -1073,6 +1090,7 @@ int fsnp_measure_costs(fsnp_handle* h, double out[24]) {
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
     out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16; out[19] = 0.0;
     for (int i = 0; i < 4; ++i) out[20 + i] = t.pp[i];
+    out[24] = t.hp[0]; out[25] = t.hp[1];
     return 0;
 }
 
@@ -1087,6 +1105,7 @@ int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups
         for (int i = 0; i < 4; ++i) h->cost.ksplit1[i] = costs[14 + i];
         h->cost.rowtile16 = costs[18];
         for (int i = 0; i < 4; ++i) h->cost.pp[i] = costs[20 + i];
+        h->cost.hp[0] = costs[24]; h->cost.hp[1] = costs[25];
     }
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
@@ -1100,8 +1119,9 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind == 7 ? 11 : c.kind);
+        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel,
+        // 12 = half-tile ping-pong (lstm_hp.hip)
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
@@ -1158,15 +1178,16 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
                           uint64_t* host_stamps, int64_t num_stamps) {
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_pp_profile: null argument"); return 1; }
     if (!h->committed || !h->pp_ok) { set_error("fsnp_debug_pp_profile: no ping-pong K-split kernel for this handle"); return 2; }
-    if (tiles_per_group < 1 || tiles_per_group > 4 || num_stamps != (int64_t)steps * tiles_per_group * 8) { set_error("fsnp_debug_pp_profile: need steps * tiles_per_group * 8 stamps"); return 2; }
-    const int tiles = cdiv(num_seq, 32), groups = cdiv(tiles, tiles_per_group);
-    if (num_seq <= 0 || groups * (h->H / 8) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
+    const bool hp = tiles_per_group == 0;           // 0 = the half-tile ping-pong kernel (lstm_hp.hip): 2 halves x 16 stamps per step
+    if (tiles_per_group < 0 || tiles_per_group > 4 || num_stamps != (int64_t)steps * (hp ? 4 : tiles_per_group) * 8) { set_error("fsnp_debug_pp_profile: need steps * tiles_per_group * 8 stamps (tiles_per_group 0: steps * 32)"); return 2; }
+    const int tiles = cdiv(num_seq, 32), groups = hp ? tiles : cdiv(tiles, tiles_per_group);
+    if (num_seq <= 0 || groups * (h->H / (hp ? 16 : 8)) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
     FSNP_ON_DEVICE(h);
     SbPlan plan;
-    plan.chunks = {SbChunk{6, 0, num_seq, tiles, 0, 32, 8, groups, tiles_per_group, 0, 0}};
+    plan.chunks = {hp ? SbChunk{8, 0, num_seq, tiles, 0, 32, 16, 0, 0, 0, 0} : SbChunk{6, 0, num_seq, tiles, 0, 32, 8, groups, tiles_per_group, 0, 0}};
     plan.total_slots = tiles * 32; plan.coop_tiles = tiles;
     const size_t rows_b = align_up((size_t)plan.total_slots * sizeof(RowDesc), 256), hx_b = align_up(lstm_coop_exchange_bytes(h->H, tiles), 256);
-    const size_t bar_b = align_up((size_t)tiles * 2 * 4, 256), st_b = (size_t)num_stamps * 8;
+    const size_t bar_b = align_up(coop_counter_bytes(tiles), 256), st_b = (size_t)num_stamps * 8;
     if (order_after_last_forward(h, nullptr)) return 4;
     if (ensure_workspace(h, rows_b + hx_b + bar_b + 256 + st_b, nullptr)) return 4;
     FSNP_HIP_CHECK(hipDeviceSynchronize());
@@ -1279,6 +1300,7 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("effective settings (environment variable as read at fsnp_create = value in force):\n");
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
     add("  FSNP_COOP_PP=%s -> ping-pong K split (lstm_pp.hip) %s\n", env("FSNP_COOP_PP"), !h->pp_ok ? "not built for this model" : h->coop_pp ? "planned" : "never");
+    add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
     add("  FSNP_COOP_SKEW=%s -> K-split schedule %s\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed from 16 units up" : "serial");
     add("  FSNP_COOP_SPLIT=%s -> role-split K split mode %d (0 never, 1 auto outside the pipelined loop, 2 wherever it fits, 3 auto also pipelined)\n", env("FSNP_COOP_SPLIT"), h->coop_split);
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
@@ -1323,11 +1345,12 @@ int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 3) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule) or 3 (auto + the ping-pong K split)"); return 1; }
+    if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule, no opt-in kernels), 3 (auto + the ping-pong K split) or 4 (auto + the half-tile ping-pong kernel)"); return 1; }
     h->lstm_coop = mode != 0;
-    h->coop_skew = mode == 1 || mode == 3;
-    h->coop_split = mode == 1 || mode == 3 ? h->coop_split_cfg : 0;
+    h->coop_skew = mode == 1 || mode >= 3;
+    h->coop_split = mode == 1 || mode >= 3 ? h->coop_split_cfg : 0;
     h->coop_pp = mode == 3 ? 1 : mode == 1 ? h->coop_pp_cfg : 0;
+    h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
     drop_graphs(h);            // a captured chain holds row descriptors / a zero region laid out for the old plan

@@ -156,6 +156,7 @@ struct LstmWeights {
     const float* wpack16;       // half-tile kernel (lstm16.hip): [wave][k-group of 16][24 tiles of 16 columns][lane][4]
     const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
+    const float* wpack_hp;      // half-tile ping-pong kernel (lstm_hp.hip): [column slice of 16 units][gate][k-group of 16][lane][4]
     const float* wgen;          // runtime-sized kernel (lstm_generic.hip): transposed [layer][k][4H], layer 0 k = [x | h0], layer 1 = [h0 | h1]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
@@ -197,6 +198,7 @@ struct LstmArgs {
     unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64
+    int coop_bar_stride;       // words between the counters of consecutive row tiles (lstm_common.h: 64, second counter at + 32); 0 = packed: coop_bar[tile], coop_bar2[tile]
     int coop_xcd;              // > 0 = CUs per XCD: place the workgroups that share a row tile on one XCD (lstm_common.h)
     int coop_own_cu;           // lstm_coop.hip: > 0 = claim this many bytes of dynamic LDS (the whole CU's) so that no workgroup of a
                                // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
@@ -232,6 +234,12 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles);
 // group of H / 8 workgroups worked on in turn (hand-off latency of one tile hidden behind the others); weights = wpack_coop[0]
 void launch_lstm_pp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 bool lstm_pp_available(const LstmWeights& w);
+// lstm_hp.hip: 16 units per workgroup (S = H / 16 workgroups per row tile, one XCD), waves split the gates, weights resident,
+// every row tile worked on as two half tiles of 16 sequences in turn (the hand-off of one half hidden behind the other)
+void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+bool lstm_hp_available(const LstmWeights& w);
+size_t lstm_hp_pack_floats(int H, int KX);
+void lstm_hp_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 // lstm_generic.hip: runtime-sized fp32-FMA kernel for the sizes no tuned kernel is instantiated for (any hidden size / input width);
 // a.num_tiles workgroups of a.coop_rows_per_group (1, 2, 4, 8) sequences; seq = the full-band model of the original FullSubNet
 void launch_lstm_generic(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s);

@@ -334,6 +334,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                blob.data() + o_wpack_coop[ui]);
     }
+    size_t o_wpack_hp = 0;
+    if (h->hp_ok) {
+        o_wpack_hp = alloc(lstm_hp_pack_floats(H, h->KX));
+        lstm_hp_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_hp);
+    }
     const size_t o_wpack_coopn = alloc(tuned ? lstm_coopn_pack_floats(H, h->KX) : 0);
     if (tuned)
         lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
@@ -393,6 +398,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     bind_tcn(h->tw, fb_off, d);
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
+    h->lw.wpack_hp = d + o_wpack_hp;
     h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack_bf3 = d + o_wpack_bf3;
     h->lw.wpack16 = d + o_wpack16;

@@ -62,6 +62,15 @@ __host__ __device__ __forceinline__ int a_frag_index(int row, int k) {
 // ---- per-row-tile exchange region of the column-split kernels, in float4 units (HIMG = (HID / 8) * 64 = one 32 x HID image
 // in A-fragment order):  [h0 parity 0][h0 parity 1][h1 parity 0][h1 parity 1][Linear partials 2 x (HID / 8) x 16][h0 third]
 // The third h0 image is used by the layer-skewed K-split kernel only (lstm_coop.hip: lstm2_coop_skew_kernel).
+// ---- arrival counters of a column-split plan: one 256-byte slot per row tile (word 0 = first counter, word 32 = second), so
+// that no two counters share a 128-byte line.  Every workgroup of a tile adds to its counters and polls them every step; packed
+// ([T] + [T] words, rounds 1-2) the counters of ALL tiles of a launch sat in one line and the launch's 200+ workgroups
+// serialised on it: the half-tile ping-pong kernel's pass went 4.7 -> 6.1 (9 tiles) -> 8.4 us (10 tiles) until they were padded
+// (profiles/r03_column_split.md section 6).  LstmArgs::coop_bar_stride = 0: the packed layout (full-band LSTM of FullSubNet).
+constexpr int kCoopCounterStride = 64;      // words per row tile
+#define FSNP_COOP_BAR(a, tile, which) ((a).coop_bar_stride ? (a).coop_bar + (size_t)(tile) * (a).coop_bar_stride + (which) * ((a).coop_bar_stride / 2) \
+                                                           : ((which) ? (a).coop_bar2 : (a).coop_bar) + (tile))
+__host__ __device__ constexpr size_t coop_counter_bytes(int tiles) { return (size_t)tiles * kCoopCounterStride * 4; }
 __host__ __device__ constexpr int coop_tile_f4(int HID) { return 5 * (HID / 8) * 64 + 2 * (HID / 8) * 16; }
 
 // ---- XCD-local placement of the column-split kernels' workgroups.  The S workgroups that share a row tile (a group)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
     float4* h0img[2] = {hx, hx + HIMG};
     float4* h1img[2] = {hx + 2 * HIMG, hx + 3 * HIMG};
     float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
-    unsigned* bar = a.coop_bar + rt;
+    unsigned* bar = FSNP_COOP_BAR(a, rt, 0);
 
     __shared__ int abort_s;                        // set by thread 0 when an inter-workgroup wait gives up
     if (tid == 0) abort_s = 0;
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
     auto h0off = [](int m3) -> int { return m3 < 2 ? m3 * HIMG : 4 * HIMG + FCP4; };
     auto h1off = [](int par) -> int { return (2 + par) * HIMG; };
     float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
-    unsigned* bar0 = a.coop_bar + rt;
-    unsigned* bar1 = a.coop_bar2 + rt;
+    unsigned* bar0 = FSNP_COOP_BAR(a, rt, 0);
+    unsigned* bar1 = FSNP_COOP_BAR(a, rt, 1);
 
     if (tid == 0) abort_s = 0;
     for (int i = tid; i < KGXP * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -793,8 +793,8 @@ __global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, Ls
     auto h0off = [](int m3) -> int { return m3 < 2 ? m3 * HIMG : 4 * HIMG + FCP4; };
     auto h1off = [](int par) -> int { return (2 + par) * HIMG; };
     float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
-    unsigned* bar0 = a.coop_bar + rt;
-    unsigned* bar1 = a.coop_bar2 + rt;
+    unsigned* bar0 = FSNP_COOP_BAR(a, rt, 0);
+    unsigned* bar1 = FSNP_COOP_BAR(a, rt, 1);
 
     if (tid == 0) abort_s = 0;
     for (int i = tid; i < KGXP * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
         live[r] = rt[r] < a.num_tiles;
         if (!live[r]) rt[r] = g;                   // harmless duplicate addresses; nothing is computed for it
     }
-    unsigned* bar = a.coop_bar + g;
+    unsigned* bar = FSNP_COOP_BAR(a, g, 0);
     if (tid == 0) abort_s = 0;
 
 #pragma unroll

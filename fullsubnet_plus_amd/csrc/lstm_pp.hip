@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_pp_kernel(LstmWeights w, LstmA
         if (wave == 0) {
             store16(stage[lane], (cs * 64 + lane) * 16, r * TILE_BYTES + H0OFF);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(a.coop_bar + tile0 + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(FSNP_COOP_BAR(a, tile0 + r, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_pp_kernel(LstmWeights w, LstmA
     bool pending = false, pending_fast = false;       // wave 0: the arrival of the previous tile-phase has not been issued yet
     unsigned* pending_bar = nullptr;
     bool dead = false;                                // the launch was aborted (a peer never arrived)
-    if (tid == 0 && !xchg_wait(a.coop_bar + tile0, (unsigned)S, a.coop_abort, a.coop_err)) flags[0] = 1;
+    if (tid == 0 && !xchg_wait(FSNP_COOP_BAR(a, tile0, 0), (unsigned)S, a.coop_abort, a.coop_err)) flags[0] = 1;
     __syncthreads();
     if (flags[0]) return;
     issue(std::integral_constant<int, 0>{}, 0);
@@ -308,11 +308,11 @@ __global__ __launch_bounds__(256) void lstm2_coop_pp_kernel(LstmWeights w, LstmA
             constexpr int r = decltype(RC)::value;
             constexpr int rn = r + 1 < R ? r + 1 : 0;
             if (r >= nt || dead) return;
-            unsigned* bar = a.coop_bar + tile0 + r;
+            unsigned* bar = FSNP_COOP_BAR(a, tile0 + r, 0);
             const bool last_tile = r + 1 >= nt;
             const bool has_next = !(last_tile && t + 1 >= Tp);
             const unsigned next_target = (unsigned)S * (unsigned)((last_tile ? t + 1 : t) + 1);
-            unsigned* next_bar = a.coop_bar + tile0 + (last_tile ? 0 : r + 1);
+            unsigned* next_bar = FSNP_COOP_BAR(a, tile0 + (last_tile ? 0 : r + 1), 0);
             const bool fc_now = fc_wg && t >= 1;
             // ---- one pass: acc0 = W_ih0 x_{t+1} + W_hh0 h0_t, acc1 = W_hh1 h1_{t-1} + W_ih1 h0_t
             FSNP_PP_STAMP(0);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_pp_kernel(LstmWeights w, LstmA
     for (int r = 0; r < R; ++r) {
         if (r >= nt) break;
         __syncthreads();                             // fc_red of the previous tile has been read
-        if (tid == 0 && !xchg_wait(a.coop_bar + tile0 + r, (unsigned)S * (unsigned)(Tp + 1), a.coop_abort, a.coop_err)) flags[0] = 1;
+        if (tid == 0 && !xchg_wait(FSNP_COOP_BAR(a, tile0 + r, 0), (unsigned)S * (unsigned)(Tp + 1), a.coop_abort, a.coop_err)) flags[0] = 1;
         __syncthreads();
         if (flags[0]) return;
         if (tid < 2 * S)

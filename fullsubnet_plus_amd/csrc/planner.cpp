@@ -26,6 +26,7 @@ CostTable default_costs() {
     // round 3 (profiles/r03_column_split.md): ping-pong K split, a full launch of 5 groups with 1 / 2 / 3 / 4 row tiles each (measured)
     const double pp[4] = {9.1, 15.5, 22.9, 30.4};
     for (int i = 0; i < 4; ++i) t.pp[i] = pp[i];
+    t.hp[0] = 12.0; t.hp[1] = 13.0;      // half-tile ping-pong: one row tile / a full launch (placeholders until measured)
     return t;
 }
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
@@ -35,6 +36,7 @@ CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
     if (sb_hidden != 384 && !sb_tcn) {     // scale by the work per step
         const double f = sb_hidden / 384.0;
         for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; t.pp[i] *= f; }
+        t.hp[0] *= f; t.hp[1] *= f;
         for (int i = 0; i < 2; ++i) { t.coopn[i][0] *= f; t.coopn[i][1] *= f; }
         t.rowtile *= f * f;
     }
@@ -50,6 +52,7 @@ int chunk_workgroups(const PlannerCtx& h, const SbChunk& c) {
     if (c.kind == 1) return c.num_tiles * (h.H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
     if (c.kind == 2) return c.groups * (h.H / 128);
     if (c.kind == 6) return cdiv(c.num_tiles, c.rpg) * (h.H / 8);
+    if (c.kind == 8) return c.num_tiles * (h.H / 16);
     return c.num_tiles;
 }
 double est_step_us(const PlannerCtx& h, const SbChunk& c) {
@@ -72,6 +75,12 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
     }
     if (c.kind == 2) return h.cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
     if (c.kind == 6) return h.cost.pp[(c.num_tiles < c.rpg ? c.num_tiles : c.rpg) - 1];      // a step lasts as long as the fullest group's turn
+    if (c.kind == 8) {
+        const int cap = h.num_cus_real / (h.H / 16);
+        if (cap <= 1) return h.cost.hp[0];
+        const double f = (double)(c.num_tiles - 1) / (cap - 1);
+        return h.cost.hp[0] + (h.cost.hp[1] - h.cost.hp[0]) * (f < 1.0 ? f : 1.0);
+    }
     if (c.kind == 4) return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile16;
     return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile * (1.0 + h.cost.rowtile_ex * c.ex);
 }
@@ -107,6 +116,8 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
         // ping-pong K split (lstm_pp.hip): groups of H / 8 workgroups, 1..4 row tiles per group
         if (occ == 1 && h.pp_ok && h.coop_pp && slots / (h.H / 8) > 0)
             for (int rpg = 1; rpg <= 4; ++rpg) shapes.push_back({6, 8, rpg, (slots / (h.H / 8)) * rpg, 0});
+        // half-tile ping-pong (lstm_hp.hip): H / 16 workgroups per row tile
+        if (occ == 1 && h.hp_ok && h.coop_hp && slots / (h.H / 16) > 0) shapes.push_back({8, 16, 0, slots / (h.H / 16), 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
         SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
@@ -147,7 +158,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
         c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 6) p.coop_tiles += c.num_tiles;
+        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 6 || c.kind == 8) p.coop_tiles += c.num_tiles;
         p.chunks.push_back(c);
     };
     if (h.sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel

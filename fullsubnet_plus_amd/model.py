@@ -496,19 +496,21 @@ class _HipModel(nn.Module):
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
                  5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
+                 12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)",
                  **{6 + r: f"lstm2_coop_pp_kernel (K split, fused phase, {r} row tile{'s' if r > 1 else ''} per group in turn)" for r in (1, 2, 3, 4)}}
         prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}
         return [{"kernel": names[buf[6 * i]], "sequences": buf[6 * i + 1], "tiles": buf[6 * i + 2], "valu_rows": buf[6 * i + 3],
                  "precision": prec[buf[6 * i + 4]], "workgroups": buf[6 * i + 5]} for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
-        """Test hook: pin the planner's cost table (24 values, fsnp_get_costs order; None = built-in) and whether it may put
-        two column-split workgroups on a CU (fsnp_debug_set_costs).  A 20-value table (the round-2 layout) prices the
-        ping-pong K-split launches (values 20..23) out of every plan."""
+        """Test hook: pin the planner's cost table (26 values, fsnp_get_costs order; None = built-in) and whether it may put
+        two column-split workgroups on a CU (fsnp_debug_set_costs).  A shorter table (20 values = the round-2 layout, 24 = before
+        the half-tile ping-pong kernel) prices the launch shapes it does not name (values 20..23: ping-pong K split, 24..25:
+        half-tile ping-pong) out of every plan."""
         lib = self._ensure_handle(_resolve_device(device))
-        if costs is not None and len(costs) == 20:
-            costs = list(costs) + [1e9] * 4
-        arr = (ctypes.c_double * 24)(*costs) if costs is not None else None
+        if costs is not None and len(costs) < 26:
+            costs = list(costs) + [1e9] * (26 - len(costs))
+        arr = (ctypes.c_double * 26)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
     @staticmethod
@@ -516,11 +518,11 @@ class _HipModel(nn.Module):
         return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
                 "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18],
-                "pingpong_us": {r: v[19 + r] for r in (1, 2, 3, 4)}}
+                "pingpong_us": {r: v[19 + r] for r in (1, 2, 3, 4)}, "halftile_pingpong_us": {"one_tile": v[24], "full_launch": v[25]}}
 
     def measure_costs(self):
         """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""
-        buf = (ctypes.c_double * 24)()
+        buf = (ctypes.c_double * 26)()
         with torch.cuda.device(self._hip.device):
             _lib.check(_lib.load().fsnp_measure_costs(self._handle, ctypes.byref(buf)), "fsnp_measure_costs")
         return self._cost_dict(list(buf))
@@ -534,14 +536,14 @@ class _HipModel(nn.Module):
         return buf.value.decode()
 
     def planner_costs_raw(self):
-        """-> the 24 values of fsnp_get_costs (the layout debug_set_costs takes)."""
-        buf = (ctypes.c_double * 24)()
+        """-> the 26 values of fsnp_get_costs (the layout debug_set_costs takes)."""
+        buf = (ctypes.c_double * 26)()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), None, None), "fsnp_get_costs")
         return list(buf)
 
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
-        buf, cal, occ = (ctypes.c_double * 24)(), ctypes.c_int32(), ctypes.c_int32()
+        buf, cal, occ = (ctypes.c_double * 26)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
         return {**self._cost_dict(list(buf)), "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 

@@ -230,12 +230,15 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
  * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
  * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
  * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
-int fsnp_get_costs(const fsnp_handle* h, double out[24], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel,
-                                                                                                out[20..23] = ping-pong K split, 1..4 row tiles per group */
-int fsnp_measure_costs(fsnp_handle* h, double out[24]);
+int fsnp_get_costs(const fsnp_handle* h, double out[26], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel,
+                                                                                                out[20..23] = ping-pong K split, 1..4 row tiles per group,
+                                                                                                out[24..25] = half-tile ping-pong kernel (csrc/lstm_hp.hip):
+                                                                                                one row tile, a full launch */
+int fsnp_measure_costs(fsnp_handle* h, double out[26]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
- * (kernel 1) or groups (kernel 2, 6), row tiles per group, first slot}; kernel 6 = the ping-pong K split.  Used by the CPU tests. */
+ * (kernel 1) or groups (kernel 2, 6), row tiles per group, first slot}; kernel 6 = the ping-pong K split, 8 = the half-tile
+ * ping-pong kernel.  Used by the CPU tests. */
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks);
 
@@ -256,7 +259,10 @@ double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 /* Profiling hook of the ping-pong K-split kernel (csrc/lstm_pp.hip): num_seq sequences as ONE launch with tiles_per_group row
  * tiles per group; workgroup 0 stamps the 100 MHz wall clock at 7 points of every tile-phase (0 pass start, 1 MFMA pass done,
  * 2 past the barrier, 3 partial tiles in LDS, 4 cell phase done, 5 past the barrier, 6 published / next operands issued) and
- * [7] = 1 if the next tile-phase's operands were fetched early.  host_stamps: steps * tiles_per_group * 8 values.  Synchronises. */
+ * [7] = 1 if the next tile-phase's operands were fetched early.  host_stamps: steps * tiles_per_group * 8 values.  Synchronises.
+ * tiles_per_group = 0: the half-tile ping-pong kernel (csrc/lstm_hp.hip) instead - steps * 2 * 16 stamps per (step, half): 0 phase start,
+ * 1 operands in LDS, 2 / 3 before / after the deferred arrival inside the pass, 4 MFMA pass done, 5 pre-activations exchanged,
+ * 6 cells done, 7 past the barrier, 8 published / next operands issued, [15] = 1 if the next half-phase was fetched early. */
 int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
                           uint64_t* host_stamps, int64_t num_stamps);
 /* Profiling hook: fsnp_lstm2_fc on the default stream + s_memtime stamps of workgroup 0 at 8 points of
@@ -311,7 +317,9 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
                                                                   schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0);
                                                                   3 = as 1 + the planner may use the opt-in ping-pong K split (csrc/lstm_pp.hip,
-                                                                  also FSNP_COOP_PP=1 at fsnp_create time) */
+                                                                  also FSNP_COOP_PP=1 at fsnp_create time);
+                                                                  4 = as 1 + the planner may use the half-tile ping-pong kernel
+                                                                  (csrc/lstm_hp.hip, also FSNP_COOP_HP=1 at fsnp_create time) */
 /* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
  * LDS DMA, GroupNorm folded into the sconv weights at fsnp_create; csrc/tcn.hip) where its layout requirements hold;
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
@@ -350,7 +358,7 @@ const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 7
+#define FSNP_ABI_VERSION 8
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

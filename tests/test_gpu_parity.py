@@ -217,6 +217,37 @@ def test_ping_pong_k_split_equals_serial_schedule(n, steps, r):
         assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), pp)
 
 
+def _hp_only_costs():
+    """A cost table (fsnp_get_costs layout, 26 values) under which every column-split launch is the half-tile ping-pong kernel."""
+    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0]
+
+
+@pytest.mark.parametrize("n,steps,hidden", [(1, 1, 384), (16, 2, 384), (17, 3, 384), (32, 40, 384), (33, 5, 384), (257, 41, 384), (300, 7, 384),
+                                            (320, 128, 384), (500, 9, 384), (48, 300, 384), (257, 33, 256), (40, 2, 256)])
+def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden):
+    """csrc/lstm_hp.hip: 16 hidden units per workgroup (24 workgroups per row tile, one XCD), the four waves split the GATES over
+    the whole K (v_mfma_f32_16x16x4_f32, weights resident, no partial tiles to reduce), every row tile worked on as two half
+    tiles of 16 sequences in turn (the hand-off of one half is in flight while the other computes), operands by LDS DMA, fused
+    two-layer phase.  The 16x16x4 MFMA sums K in another order than the 32x32x2 kernels: same oracle tolerance as every other
+    recurrent kernel, bitwise repeatable; 1 ... 300 steps, ragged tiles (second half empty / one row), two launches (500)."""
+    args = {**DEFAULT_MODEL_ARGS, "sb_model_hidden_size": hidden}
+    sd = make_state_dict(3, "harsh", sb_hidden=hidden)
+    m = _model(args, sd)
+    rng = np.random.Generator(np.random.PCG64(977 + n + steps))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
+    m.lstm2_fc(x[:1])
+    m.debug_set_lstm_coop(4)
+    m.debug_set_costs(_hp_only_costs(), 1)
+    assert all(c["kernel"].startswith("lstm2_coop_hp_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
+    got = m.lstm2_fc(x).cpu().numpy()
+    m.check_errors()
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
+    assert rel_err(got, want) < 2e-5, rel_err(got, want)
+    for _ in range(3):
+        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), got)
+    m.check_errors()
+
+
 @pytest.mark.parametrize("seq,hidden,fbn", [("LSTM", 320, 0), ("GRU", 190, 0), ("LSTM", 384, 6), ("LSTM", 1030, 0)])
 def test_generic_recurrent_kernel_dense_vs_oracle(seq, hidden, fbn):
     """csrc/lstm_generic.hip: sizes without a tuned (MFMA) instantiation - any sb_model_hidden_size, more than 64 sub-band

@@ -540,7 +540,7 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
 
     def plan(rows, occ, costs=None, gru=0):
         buf = (ct.c_int32 * (8 * 64))()
-        arr = (ct.c_double * 24)(*(list(costs) + [1e9] * (24 - len(costs)))) if costs else None      # (ping-pong launches priced out unless given)
+        arr = (ct.c_double * 26)(*(list(costs) + [1e9] * (26 - len(costs)))) if costs else None      # (opt-in launch shapes priced out unless given)
         n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
         assert n > 0, lib.fsnp_last_error()
         keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
@@ -573,6 +573,17 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     for c in plan(1285, 1, cheap_pp):            # 41 tiles: several launches, each within its capacity
         assert c["kind"] != 6 or (c["par"] <= 5 and c["par"] * c["rpg"] >= c["tiles"])
     assert all(c["kind"] != 6 for rows in (32, 257, 640, 8224) for c in plan(rows, 1))      # built-in plans: never
+    # the half-tile ping-pong kernel (kernel 8: 24 workgroups per row tile, at most 10 row tiles per launch)
+    cheap_hp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 1e9, 1e9, 1e9, 1e9, 9, 11]
+    p = plan(257, 1, cheap_hp)
+    assert len(p) == 1 and p[0]["kind"] == 8 and p[0]["tiles"] == 9 and p[0]["rows"] == 257
+    p = plan(32, 1, cheap_hp)
+    assert len(p) == 1 and p[0]["kind"] == 8 and p[0]["tiles"] == 1
+    p = plan(352, 1, cheap_hp)                   # 11 tiles: two launches, each within 10 tiles
+    assert [c["kind"] for c in p] == [8, 8] and sorted(c["tiles"] for c in p) == [1, 10] and sum(c["rows"] for c in p) == 352
+    p = plan(8224, 1, cheap_hp)                  # B = 32: the leftover tile
+    assert [(c["kind"], c["rows"]) for c in p] == [(0, 8192), (8, 32)]
+    assert all(c["kind"] != 8 for rows in (32, 257, 640, 8224) for c in plan(rows, 1))      # built-in plans: not while it is opt-in
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():

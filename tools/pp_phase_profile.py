@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase breakdown of the ping-pong K-split kernel (csrc/lstm_pp.hip) from wall-clock stamps (fsnp_debug_pp_profile).
-usage: python tools/pp_phase_profile.py <sequences> <steps> <tiles per group>"""
+usage: python tools/pp_phase_profile.py <sequences> <steps> <tiles per group>     (tiles per group 0 = the half-tile ping-pong kernel, csrc/lstm_hp.hip)"""
 import json
 import os
 import sys
@@ -13,6 +13,18 @@ from fullsubnet_plus_amd import FullSubNet_Plus, _lib  # noqa: E402
 from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_state_dict  # noqa: E402
 
 
+def main_hp(s, n, steps):
+    names = ["drain own DMA + barrier 1 (operands in LDS)", "pass: first quarter", "pass: deferred arrival (store drain + atomic)", "pass: rest (+ fetch of the other half)",
+             "pre-activations -> LDS, barrier 2 (= waiting for the slowest wave)", "cell phase", "barrier 3", "publish (+ wait / late fetch)"]
+    d = np.diff(s[:, :9], axis=1) * 0.01
+    res = {"kernel": "lstm2_coop_hp_kernel", "sequences": n, "steps": steps, "us_per_half_phase": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01),
+           "early_fetch_fraction": float(s[:, 15].mean())}
+    for i, nm in enumerate(names):
+        res[f"{i}: {nm}"] = round(float(d[:, i].mean()), 3)
+    res["gap to the next phase"] = round(float((s[1:, 0] - s[:-1, 8]).mean() * 0.01), 3)
+    print(json.dumps(res, indent=1))
+
+
 def main():
     n, steps, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
@@ -22,13 +34,19 @@ def main():
     out = torch.empty(n, 2, steps, device="cuda")
     m.lstm2_fc(x.permute(0, 2, 1)[:8])          # creates the handle
     lib = _lib.load()
-    stamps = np.zeros(steps * r * 8, dtype=np.uint64)
+    hp = r == 0
+    rr = 2 if hp else r
+    if hp and n <= 16:
+        raise SystemExit("the half-tile profile assumes both halves of row tile 0 hold sequences (n > 16)")
+    stamps = np.zeros(steps * rr * (16 if hp else 8), dtype=np.uint64)
     for _ in range(2):
         _lib.check(lib.fsnp_debug_pp_profile(m._handle, x.data_ptr(), out.data_ptr(), n, steps, r, stamps.ctypes.data, stamps.size), "profile")
-    s = stamps.reshape(steps * r, 8).astype(np.int64)[4 * r:]          # skip warm-up steps; 10 ns ticks
+    if hp:
+        return main_hp(stamps.reshape(steps * 2, 16).astype(np.int64)[8:], n, steps)
+    s = stamps.reshape(steps * rr, 8).astype(np.int64)[4 * rr:]          # skip warm-up steps; 10 ns ticks
     names = ["MFMA pass", "barrier 1 (+flags)", "early fetch + partial tiles -> LDS, barrier 2", "cell phase", "barrier 3", "publish (+ wait / late fetch)"]
     d = np.diff(s[:, :7], axis=1) * 0.01
-    res = {"sequences": n, "steps": steps, "tiles_per_group": r, "us_per_tile_phase": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01),
+    res = {"kernel": "lstm2_coop_hp_kernel" if hp else "lstm2_coop_pp_kernel", "sequences": n, "steps": steps, "tiles_per_group": r, "us_per_tile_phase": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01),
            "early_fetch_fraction": float(s[:, 7].mean())}
     for i, nm in enumerate(names):
         res[f"{i}: {nm}"] = round(float(d[:, i].mean()), 3)

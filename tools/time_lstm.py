@@ -32,6 +32,10 @@ if os.environ.get("PP_R") is not None:          # PP_R=0: never the ping-pong K 
         pp[r - 1] = 5.0
         m.debug_set_lstm_coop(3)
         m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + pp, 1)
+if os.environ.get("HP"):                        # only the half-tile ping-pong kernel (csrc/lstm_hp.hip)
+    m.debug_set_lstm_coop(4)
+    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0], 1)
+    assert all(c["kernel"].startswith("lstm2_coop_hp_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
 torch.cuda.synchronize()
 best = 1e9
 for _ in range(reps):
@@ -41,4 +45,4 @@ for _ in range(reps):
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
 m.check_errors()
-print(f"H={hidden} PP_R={os.environ.get('PP_R')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
+print(f"H={hidden} HP={os.environ.get('HP')} PP_R={os.environ.get('PP_R')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
