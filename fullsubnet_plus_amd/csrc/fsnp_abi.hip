@@ -648,9 +648,10 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         h->coop_pp = pe && pe[0] == '1' ? 1 : 0;
         h->coop_pp_cfg = h->coop_pp;
         h->pp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
-        // The half-tile ping-pong kernel (lstm_hp.hip): FSNP_COOP_HP=1 lets the planner use it, 0 never
+        // The half-tile ping-pong kernel (lstm_hp.hip) is planned wherever the cost table says it pays (6 ... 10 row tiles: B = 1);
+        // FSNP_COOP_HP=0: never
         const char* he = getenv("FSNP_COOP_HP");
-        h->coop_hp = he ? (he[0] == '1' ? 1 : 0) : 0;
+        h->coop_hp = he && he[0] == '0' ? 0 : 1;
         h->coop_hp_cfg = h->coop_hp;
         h->hp_ok = h->pp_ok;
     }
@@ -1047,7 +1048,7 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     }
     h.pp_ok = gru == 0 && (hidden == 384 || hidden == 256);
     h.hp_ok = h.pp_ok;
-    h.coop_hp = costs != nullptr;
+    h.coop_hp = 1;
     h.coop_pp = costs != nullptr;          // (a caller's table prices the ping-pong launches in or out; the built-in plans do not use them)
     h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)

@@ -34,6 +34,7 @@
 //                  cells -> h1_t -> h1img[t & 1], Linear partials -> fcp[t & 1], h0_{t+1} -> h0img[(t+1) & 1]     arrive
 //                  (workgroup q < 16: out[row q][t - 1] = bias + the S partials of step t - 1)
 //   final        : wait counter >= S (Tp + 1); out[.][Tp - 1]
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -61,11 +62,16 @@ constexpr size_t hp_smem_bytes(int HID, int KX) {
     return (size_t)(2 * hp_gx(KX) * 64 + 4 * (HID / 16) * 64 + 8 * 64 + 2 * 64 + 8) * 16 + 2 * (HID / 16) * 4 + 32 * sizeof(RowDesc) + 64;
 }
 
+// sum over the 16 lanes of a DPP row, in every lane (row_ror 8, 4, 2, 1: no LDS round trips)
+template <int N>
+__device__ __forceinline__ float hp_ror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false)); }
+__device__ __forceinline__ float row_sum16(float v) { v += hp_ror<8>(v); v += hp_ror<4>(v); v += hp_ror<2>(v); v += hp_ror<1>(v); return v; }
+
 #define HP_MF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0)
 
 }  // namespace
 
-template <int HID, int KX>
+template <int HID, int KX, int TUNE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     constexpr int S = HID / 16;                      // workgroups per row tile
@@ -76,7 +82,8 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     constexpr int TILE_BYTES = coop_tile_f4(HID) * 16;
     constexpr int H0OFF = 0, H1OFF = 2 * IMG_B, FCOFF = 4 * IMG_B;
     // events inside the MFMA pass, in k-groups of the h part (a group = 12 MFMAs = 384 matrix-pipe cycles)
-    constexpr int ARRIVE_G = GH / 4, POLL1_G = GH / 2, CHECK1_G = (GH * 16) / 24, PEER_G = (GH * 19) / 24, POLL2_G = (GH * 20) / 24;
+    constexpr int ARRIVE_G = (GH * (TUNE == 0 ? 6 : TUNE == 1 ? 4 : 3)) / 24, POLL1_G = (GH * (TUNE == 0 ? 12 : TUNE == 1 ? 10 : 8)) / 24,
+                  CHECK1_G = (GH * (TUNE == 0 ? 16 : TUNE == 1 ? 15 : 14)) / 24, PEER_G = CHECK1_G + (GH * 3) / 24, POLL2_G = PEER_G + 1;
     static_assert(KX <= 64 && GX <= 4, "gathered sub-band input");
     static_assert(S >= 16 && 2 * S <= 64, "one workgroup per output row of a half tile; the Linear partials are fetched by wave 0");
     static_assert((NW0 + NW1) * 4 <= 320 && NW1 * 4 <= 192, "the wave's weights must fit the register file (layer 1: AGPRs)");
@@ -160,10 +167,12 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), hr, voff, soff, kSc1);
     };
 
-    // ---- cell ownership: thread = (unit u = lane >> 2, row 4 wave + (lane & 3)) - its pre-activations are float `tid` of every gate block
-    const int cu = lane >> 2, crow = 4 * wave + (lane & 3);
+    // ---- cell ownership: thread = (unit u = lane & 15, row 4 wave + (lane >> 4)): its pre-activations are float gidx of every gate block
+    // (64 lanes -> 64 distinct banks), and the units of a row are the 16 lanes of a DPP row (the Linear partial sums)
+    const int cu = lane & 15, crow = 4 * wave + (lane >> 4);
     const float wfc0 = w.wfc[cs * 16 + cu], wfc1 = w.wfc[HID + cs * 16 + cu];
     const int sdst = ((cu & 3) * 16 + crow) * 4 + (cu >> 2);             // float index inside a staged k-group (hp_a16)
+    const int gidx = (wave * 16 + cu) * 4 + (lane >> 4);                 // float index inside one gate block [64 lanes][4 rows]
     f32x2 cst[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};                    // {c1, c0} of each half
     const float* gf = reinterpret_cast<const float*>(gat);
     float* sf = reinterpret_cast<float*>(stage);
@@ -172,14 +181,13 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     // Linear(H, 2): workgroup q < 16 owns output row q of both halves; lanes [0, 2 S) of wave 0 fetch the S partials of both outputs
     const bool fc_wg = cs < 16;
     const int fc_voff = (tid % S) * 128 + ((tid / S) * 16 + cs) * 4;
-    auto fc_finish = [&](int hf, int t_done) {         // threads 128, 129: fixed summation order
-        if (fc_wg && (tid == 128 || tid == 129)) {
-            const int o = tid - 128;
+    auto fc_finish = [&](int hf, int t_done) {         // wave 2, lanes 0..31: output o = lane >> 4, a fixed tree over the S partials
+        if (fc_wg && wave == 2 && lane < 32) {
+            const int o = lane >> 4, q = lane & 15;
             const RowDesc rd = rows_s[hf * 16 + cs];
-            float sum = w.bfc[o];
-#pragma unroll
-            for (int p = 0; p < S; ++p) sum += fc_red[o * S + p];
-            if (rd.valid && t_done >= a.LA)
+            float sum = fc_red[o * S + q] + (q + 16 < S ? fc_red[o * S + q + 16] : 0.0f);
+            sum = row_sum16(sum) + w.bfc[o];
+            if (q == 0 && rd.valid && t_done >= a.LA)
                 a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
         }
     };
@@ -217,8 +225,8 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
         __syncthreads();
         {
             f32x2 c = {0.f, cst[hf].y};
-            const f32x2 hh = lstm_cell_pair(f32x2{0.f, gf[0 * 256 + tid]}, f32x2{0.f, gf[1 * 256 + tid]}, f32x2{0.f, gf[2 * 256 + tid]},
-                                            f32x2{0.f, gf[3 * 256 + tid]}, c);
+            const f32x2 hh = lstm_cell_pair(f32x2{0.f, gf[0 * 256 + gidx]}, f32x2{0.f, gf[1 * 256 + gidx]}, f32x2{0.f, gf[2 * 256 + gidx]},
+                                            f32x2{0.f, gf[3 * 256 + gidx]}, c);
             cst[hf].y = c.y;
             sf[sdst] = hh.y;
         }
@@ -239,13 +247,15 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     // fetch(half, t): operands of half-phase (half, t).  Waves 1-3: 2 GH chunks of 1 KB, global -> LDS; wave 0 (workgroups that
     // own an output row): the S Linear partials of step t - 1.  Called once the half's counter shows S (t + 1) arrivals.
     float fcv = 0.0f;
+    // (LDS byte addresses of the two image arrays as integers: a generic -> LDS pointer conversion per chunk carries a null check)
+    const unsigned lds_h1 = (unsigned)(size_t)(lds_ptr)H1s, lds_h0 = (unsigned)(size_t)(lds_ptr)H0s;
     auto fetch = [&](auto HN, int tn) {
         constexpr int hn = decltype(HN)::value;
         if (wave != 0) {
             const int h1src = H1OFF + ((tn & 1) ^ 1) * IMG_B + hn * HALF_B, h0src = H0OFF + (tn & 1) * IMG_B + hn * HALF_B;
             for (int c = wave - 1; c < 2 * GH; c += 3) {
-                if (c < GH) __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(H1s + (hn * GH + c) * 64), 16, lane * 16, h1src + c * 1024, 0, kSc1);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(H0s + (hn * GH + c - GH) * 64), 16, lane * 16, h0src + (c - GH) * 1024, 0, kSc1);
+                if (c < GH) __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(size_t)(lds_h1 + (hn * GH + c) * 1024), 16, lane * 16, h1src + c * 1024, 0, kSc1);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(size_t)(lds_h0 + (hn * GH + c - GH) * 1024), 16, lane * 16, h0src + (c - GH) * 1024, 0, kSc1);
             }
         } else if (fc_wg && tn >= 1 && tid < 2 * S) {
             fcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, fc_voff, FCOFF + ((((tn & 1) ^ 1) * 2 + hn) * S) * 128, kSc1));
@@ -265,6 +275,14 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
 
     bool pending = false;                 // wave 0: the arrival of the previous half-phase has not been issued yet
     unsigned* pending_bar = nullptr;
+    // wave 0 publishes the staged h0 / h1 / Linear partials of half-phase (hp, tp): three 16-byte write-through stores per lane
+    auto publish = [&](int hp, int tp) {
+        store16(stage[lane], (cs * 64 + lane) * 16, H0OFF + ((tp + 1) & 1) * IMG_B + hp * HALF_B);
+        store16(stage[64 + lane], (cs * 64 + lane) * 16, H1OFF + (tp & 1) * IMG_B + hp * HALF_B);
+        if (lane < 8) store16(stage[128 + lane], lane * 16, FCOFF + (((tp & 1) * 2 + hp) * S + cs) * 128);
+    };
+    bool pub_pending = false;             // (two halves) the previous half-phase's cells are staged but not published yet: that happens behind
+    int pub_t = 0;                        // the NEXT half-phase's first barrier, which saves a workgroup barrier per half-phase
     bool dead = false;
     // first half-phase: nothing to overlap with
     if (wave != 0 || fc_wg) { if (wave_wait(bars[0], (unsigned)S)) fetch(std::integral_constant<int, 0>{}, 0); }
@@ -292,6 +310,10 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             __syncthreads();
             if (flags[0]) { dead = true; return; }
             FSNP_HP_STAMP(1);
+            if (wave == 0 && pub_pending) {      // the other half's previous half-phase: staged before this barrier
+                publish(ho, pub_t);
+                pending = true; pending_bar = bars[ho]; pub_pending = false;
+            }
 
             // ---- one pass: acc0 = W_ih0 x_{t+1} + W_hh0 h0_t, acc1 = W_hh1 h1_{t-1} + W_ih1 h0_t  (wave = gate)
             f32x4 a0a = {bias0, bias0, bias0, bias0}, a0b = {0.f, 0.f, 0.f, 0.f};
@@ -360,14 +382,13 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             if (polls && !fetched && __builtin_amdgcn_readfirstlane(flags[1]) == token) { fetch_next(); fetched = true; }
             // ---- cells: {layer 1 (h1_t), layer 0 (h0_{t+1})} of (row crow, unit cu) as ONE packed two-cell update
             {
-                const f32x2 hh = lstm_cell_pair(f32x2{gf[4 * 256 + tid], gf[0 * 256 + tid]}, f32x2{gf[5 * 256 + tid], gf[1 * 256 + tid]},
-                                                f32x2{gf[6 * 256 + tid], gf[2 * 256 + tid]}, f32x2{gf[7 * 256 + tid], gf[3 * 256 + tid]}, cst[hf]);
+                const f32x2 hh = lstm_cell_pair(f32x2{gf[4 * 256 + gidx], gf[0 * 256 + gidx]}, f32x2{gf[5 * 256 + gidx], gf[1 * 256 + gidx]},
+                                                f32x2{gf[6 * 256 + gidx], gf[2 * 256 + gidx]}, f32x2{gf[7 * 256 + gidx], gf[3 * 256 + gidx]}, cst[hf]);
                 sf[sdst] = hh.y;
                 sf[256 + sdst] = hh.x;
                 float p0 = hh.x * wfc0, p1 = hh.x * wfc1;               // partial Linear over this workgroup's 16 units
-#pragma unroll
-                for (int m = 4; m < 64; m <<= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
-                if (lane < 4) { sf[512 + crow] = p0; sf[512 + 16 + crow] = p1; }
+                p0 = row_sum16(p0); p1 = row_sum16(p1);
+                if (cu == 0) { sf[512 + crow] = p0; sf[512 + 16 + crow] = p1; }
             }
             if (have_x) {
 #pragma unroll
@@ -376,21 +397,17 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             }
             if (fc_now) fc_finish(hf, t - 1);
             FSNP_HP_STAMP(6);
-            __syncthreads();
-            FSNP_HP_STAMP(7);
-            // ---- publish: wave 0, 16 bytes per lane, write-through
-            if (wave == 0) {
-                store16(stage[lane], (cs * 64 + lane) * 16, H0OFF + ((t + 1) & 1) * IMG_B + hf * HALF_B);
-                store16(stage[64 + lane], (cs * 64 + lane) * 16, H1OFF + (t & 1) * IMG_B + hf * HALF_B);
-                if (lane < 8) store16(stage[128 + lane], lane * 16, FCOFF + (((t & 1) * 2 + hf) * S + cs) * 128);
-                if (!two) {                       // the next wait is for this very half: arrive now
+            if (!two) {                           // one half only: the next wait is for this very half - publish and arrive now
+                __syncthreads();
+                if (wave == 0) {
+                    publish(hf, t);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(bars[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    pending = true;
-                    pending_bar = bars[hf];
                 }
+            } else {
+                pub_pending = true; pub_t = t;    // (published behind the next half-phase's first barrier)
             }
+            FSNP_HP_STAMP(7);
             if (prof) prof[(t * 2 + hf) * 16 + 15] = fetched ? 1ull : 0ull;        // (wave 0's view: the Linear partials)
             if (has_next && !fetched && (wave != 0 || fc_wg)) {      // not seen complete during the pass: wait for it for real
                 if (wave_wait(nbar, ntarget)) fetch_next();
@@ -398,11 +415,18 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             FSNP_HP_STAMP(8);
         });
     }
-    if (wave == 0 && pending) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(pending_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                      // the last half-phase's cells are staged
+    if (wave == 0 && !dead) {
+        if (pending) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(pending_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pub_pending) {
+            publish(nh - 1, pub_t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(bars[nh - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    __syncthreads();
     if (flags[0] || dead) return;
     // ================= the Linear of the last step =================
     if (!fc_wg) return;
@@ -443,11 +467,11 @@ void lstm_hp_pack_weights(int H, int NIN, int KX, const float* wih0, const float
                     }
 }
 
-template <int HID, int KX>
+template <int HID, int KX, int TUNE>
 static void launch_hp_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     constexpr int S = HID / 16;
     const size_t smem_need = hp_smem_bytes(HID, KX);
-    auto kern = lstm2_coop_hp_kernel<HID, KX>;
+    auto kern = lstm2_coop_hp_kernel<HID, KX, TUNE>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
     if (occ) {
@@ -463,8 +487,12 @@ bool lstm_hp_available(const LstmWeights& w) { return !w.gru && (w.H == 384 || w
 
 // a.num_tiles row tiles x H / 16 workgroups, all co-resident
 void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    if (w.H == 256) { if (w.KX == 64) launch_hp_inst<256, 64>(w, a, s, nullptr); else launch_hp_inst<256, 40>(w, a, s, nullptr); return; }
-    if (w.KX == 64) launch_hp_inst<384, 64>(w, a, s, nullptr); else launch_hp_inst<384, 40>(w, a, s, nullptr);
+    if (w.H == 256) { if (w.KX == 64) launch_hp_inst<256, 64, 0>(w, a, s, nullptr); else launch_hp_inst<256, 40, 0>(w, a, s, nullptr); return; }
+    if (w.KX == 64) { launch_hp_inst<384, 64, 0>(w, a, s, nullptr); return; }
+    static const int tune = [] { const char* e = getenv("FSNP_HP_TUNE"); return e ? atoi(e) : 0; }();      // (exploration: when the in-pass events happen)
+    if (tune == 1) launch_hp_inst<384, 40, 1>(w, a, s, nullptr);
+    else if (tune == 2) launch_hp_inst<384, 40, 2>(w, a, s, nullptr);
+    else launch_hp_inst<384, 40, 0>(w, a, s, nullptr);
 }
 
 }  // namespace fsnp

@@ -16,17 +16,17 @@ namespace fsnp {
 // occupancy allows it (coop_occ >= 2) and, without a calibration, priced so that it is never chosen.
 CostTable default_costs() {
     CostTable t{};
-    // round-2 measurements (profiles/r02_planner_costs.json): a full launch, one row tile, three-way split, one-tile-per-CU
-    // K split (serial schedule at 8 units, layer-skewed from 16 up): a full launch / one row tile; three-way split at 85 / 170 row
-    // tiles; one round of the one-tile-per-CU kernel - from 128-step runs (profiles/r02_column_split.md)
-    const double ks[4] = {14.4, 16.5, 26.0, 48.5}, k1[4] = {8.7, 14.0, 22.5, 42.0}, cn[2] = {78.0, 157.0};
+    // round-3 measurements (fsnp_measure_costs on an MI355X, profiles/r03_planner_costs.json - after the arrival counters got a
+    // 128-byte line each, which took 35 % off a full K-split launch at 8 units and 14 % at 16): K split (serial schedule at 8
+    // units, layer-skewed from 16 up): a full launch / one row tile; three-way split at 85 / 170 row tiles
+    const double ks[4] = {9.4, 14.2, 24.8, 49.2}, k1[4] = {8.9, 13.3, 22.7, 45.6}, cn[2] = {84.0, 154.0};
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
-    t.rowtile = 208.0; t.rowtile_ex = 0.11; t.rowtile16 = 108.0;
+    t.rowtile = 206.0; t.rowtile_ex = 0.11; t.rowtile16 = 103.0;
     // round 3 (profiles/r03_column_split.md): ping-pong K split, a full launch of 5 groups with 1 / 2 / 3 / 4 row tiles each (measured)
-    const double pp[4] = {9.1, 15.5, 22.9, 30.4};
+    const double pp[4] = {9.9, 14.6, 22.3, 29.7};
     for (int i = 0; i < 4; ++i) t.pp[i] = pp[i];
-    t.hp[0] = 12.0; t.hp[1] = 13.0;      // half-tile ping-pong: one row tile / a full launch (placeholders until measured)
+    t.hp[0] = 12.3; t.hp[1] = 12.9;      // half-tile ping-pong (lstm_hp.hip): one row tile / a full launch of 10
     return t;
 }
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)

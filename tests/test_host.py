@@ -497,7 +497,9 @@ def test_subband_plan_choices_match_the_design():
     equal total cost, so multi-chunk cuts are checked by kernel sequence, coverage and capacity)."""
     kinds = lambda rows, **kw: [(c["kind"], c["rows"]) for c in _plan(rows, **kw)]
     seq = lambda rows, **kw: [c["kind"] for c in _plan(rows, **kw)]
-    assert kinds(257) == [(1, 257)] and _plan(257)[0]["par"] == 16                 # B = 1: K split, 16 units
+    assert kinds(257) == [(8, 257)] and _plan(257)[0]["tiles"] == 9                 # B = 1: 9 row tiles on the half-tile ping-pong kernel (lstm_hp.hip)
+    assert kinds(257, gru=1) == [(1, 257)] and _plan(257, gru=1)[0]["par"] == 16    # (GRU: K split, 16 units)
+    assert kinds(160) == [(1, 160)] and _plan(160)[0]["par"] == 8 and kinds(192) == [(8, 192)]   # up to 5 row tiles: K split at 8 units; 6 ... 10: lstm_hp
     assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
     assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
     assert kinds(4096) == [(4, 4096)] and _plan(4096)[0]["tiles"] == 256            # parity-mode B = 32: one round of 256 half tiles
@@ -505,12 +507,13 @@ def test_subband_plan_choices_match_the_design():
     p = _plan(4096, gru=1)                                                          # GRU has no half-tile kernel: 128 tiles = one per
     assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # group + 42 + 1
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert kinds(3200)[0][0] == 2 and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~107 row tiles up
+    assert kinds(3200) == [(4, 3200)] and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~95 row tiles up
+    assert kinds(2800)[0][0] == 2
     assert seq(4256) == [4, 1]                                                      # 133 tiles: half-tile round + 5 tiles K split
     assert kinds(5397) == [(4, 4096), (1, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles K split
     assert kinds(5397, gru=1) == [(2, 5397)] and _plan(5397, gru=1)[0]["rpg"] == 2  # (108 + 48.5 us against 157 for two per group); GRU: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
-    assert _plan(8224)[1]["rpg"] == 1 and _plan(16448)[1]["rpg"] == 1 and _plan(16448)[1]["tiles"] == 2   # 1-2 tiles at 8 units: role-split schedule
+    assert _plan(8224)[1]["rpg"] == 1 and _plan(16448)[1]["rpg"] == 0 and _plan(16448)[1]["tiles"] == 2   # ONE tile at 8 units: role-split schedule
     assert _plan(96)[0]["rpg"] == 0 and _plan(257)[0]["rpg"] == 0                   # (3 tiles and up: it does not pay)
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
@@ -523,7 +526,8 @@ def test_subband_plan_choices_match_the_design():
     assert sum(c["rows"] for c in g) == 65792 and all(c["kind"] == 1 for c in g[12:])   # the short rest K split
     g = _plan(8224, gru=1)                                                          # GRU, B = 32: 257 tiles = 170 + 85 + 2
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
-    p = _plan(3084)                                                                 # B = 12: 97 tiles = one per group + the rest K split
+    assert kinds(3084) == [(4, 3084)]                                               # B = 12: 193 half tiles, one round
+    p = _plan(3084, gru=1)                                                          # (GRU: 97 tiles = one per group + the rest K split)
     assert [c["kind"] for c in p] == [2, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 32 and sum(c["rows"] for c in p) == 3084
     assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2
     p = _plan(1376)                                                                 # 43 tiles: a full K-split launch + a tiny one
@@ -583,7 +587,7 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     assert [c["kind"] for c in p] == [8, 8] and sorted(c["tiles"] for c in p) == [1, 10] and sum(c["rows"] for c in p) == 352
     p = plan(8224, 1, cheap_hp)                  # B = 32: the leftover tile
     assert [(c["kind"], c["rows"]) for c in p] == [(0, 8192), (8, 32)]
-    assert all(c["kind"] != 8 for rows in (32, 257, 640, 8224) for c in plan(rows, 1))      # built-in plans: not while it is opt-in
+    assert [c["kind"] for c in plan(257, 1)] == [8] and all(c["kind"] != 8 for rows in (32, 160, 640, 8224) for c in plan(rows, 1))   # built-in table: B = 1
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():
