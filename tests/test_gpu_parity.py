@@ -421,7 +421,7 @@ def test_measured_cost_table_can_be_adopted(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         res[cal] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert not res["0"]["calibrated"] and res["1"]["calibrated"]
-    assert 120.0 < res["1"]["rowtile"] < 320.0 and res["0"]["rowtile"] == 208.0
+    assert 120.0 < res["1"]["rowtile"] < 320.0 and res["0"]["rowtile"] == 206.0       # (built-in: csrc/planner.cpp default_costs)
     assert res["1"]["plan"][0].startswith("lstm2_fc") and res["0"]["plan"] == res["1"]["plan"]
     assert abs(res["0"]["sum"] - res["1"]["sum"]) <= 1e-4 * abs(res["0"]["sum"])
 
