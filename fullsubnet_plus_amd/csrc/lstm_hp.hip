@@ -34,7 +34,6 @@
 //                  cells -> h1_t -> h1img[t & 1], Linear partials -> fcp[t & 1], h0_{t+1} -> h0img[(t+1) & 1]     arrive
 //                  (workgroup q < 16: out[row q][t - 1] = bias + the S partials of step t - 1)
 //   final        : wait counter >= S (Tp + 1); out[.][Tp - 1]
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -71,7 +70,7 @@ __device__ __forceinline__ float row_sum16(float v) { v += hp_ror<8>(v); v += hp
 
 }  // namespace
 
-template <int HID, int KX, int TUNE>
+template <int HID, int KX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     constexpr int S = HID / 16;                      // workgroups per row tile
@@ -82,8 +81,8 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
     constexpr int TILE_BYTES = coop_tile_f4(HID) * 16;
     constexpr int H0OFF = 0, H1OFF = 2 * IMG_B, FCOFF = 4 * IMG_B;
     // events inside the MFMA pass, in k-groups of the h part (a group = 12 MFMAs = 384 matrix-pipe cycles)
-    constexpr int ARRIVE_G = (GH * (TUNE == 0 ? 6 : TUNE == 1 ? 4 : 3)) / 24, POLL1_G = (GH * (TUNE == 0 ? 12 : TUNE == 1 ? 10 : 8)) / 24,
-                  CHECK1_G = (GH * (TUNE == 0 ? 16 : TUNE == 1 ? 15 : 14)) / 24, PEER_G = CHECK1_G + (GH * 3) / 24, POLL2_G = PEER_G + 1;
+    // (measured: arrival after 3 ... 6 of 24 groups, poll at 8 ... 12, check at 14 ... 16 make no difference - profiles/r03_column_split.md)
+    constexpr int ARRIVE_G = GH / 4, POLL1_G = GH / 2, CHECK1_G = (GH * 2) / 3, PEER_G = CHECK1_G + GH / 8, POLL2_G = PEER_G + 1;
     static_assert(KX <= 64 && GX <= 4, "gathered sub-band input");
     static_assert(S >= 16 && 2 * S <= 64, "one workgroup per output row of a half tile; the Linear partials are fetched by wave 0");
     static_assert((NW0 + NW1) * 4 <= 320 && NW1 * 4 <= 192, "the wave's weights must fit the register file (layer 1: AGPRs)");
@@ -143,7 +142,17 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
         }
     }
     const int xdst0 = hp_a16(xrow, j0);               // (+ 256 floats per further k-group)
-    auto x_load = [&](int hf, int i, int t) -> float { return goff[hf][i] >= 0 ? gbase[goff[hf][i] + t * gstep] : 0.0f; };
+    // (one buffer load per element and step: the per-lane byte offset is loop invariant, the step goes into the scalar offset;
+    //  elements without a source - goff < 0 - load offset 0 and are never written to the x image)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gbase), 0, 0x7FFFFFFC, 0x00020000);
+    int xvo[2][GX];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < GX; ++i) xvo[hf][i] = goff[hf][i] >= 0 ? goff[hf][i] * 4 : 0;
+    auto x_load = [&](int hf, int i, int t) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xvo[hf][i], t * gstep * 4, 0));
+    };
 
     // ---- the wave's weights, resident: [cs][gate = wave][fragment][lane][4]
     float4 w0[NW0], w1[NW1];
@@ -467,11 +476,11 @@ void lstm_hp_pack_weights(int H, int NIN, int KX, const float* wih0, const float
                     }
 }
 
-template <int HID, int KX, int TUNE>
+template <int HID, int KX>
 static void launch_hp_inst(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     constexpr int S = HID / 16;
     const size_t smem_need = hp_smem_bytes(HID, KX);
-    auto kern = lstm2_coop_hp_kernel<HID, KX, TUNE>;
+    auto kern = lstm2_coop_hp_kernel<HID, KX>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
     if (occ) {
@@ -487,12 +496,8 @@ bool lstm_hp_available(const LstmWeights& w) { return !w.gru && (w.H == 384 || w
 
 // a.num_tiles row tiles x H / 16 workgroups, all co-resident
 void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    if (w.H == 256) { if (w.KX == 64) launch_hp_inst<256, 64, 0>(w, a, s, nullptr); else launch_hp_inst<256, 40, 0>(w, a, s, nullptr); return; }
-    if (w.KX == 64) { launch_hp_inst<384, 64, 0>(w, a, s, nullptr); return; }
-    static const int tune = [] { const char* e = getenv("FSNP_HP_TUNE"); return e ? atoi(e) : 0; }();      // (exploration: when the in-pass events happen)
-    if (tune == 1) launch_hp_inst<384, 40, 1>(w, a, s, nullptr);
-    else if (tune == 2) launch_hp_inst<384, 40, 2>(w, a, s, nullptr);
-    else launch_hp_inst<384, 40, 0>(w, a, s, nullptr);
+    if (w.H == 256) { if (w.KX == 64) launch_hp_inst<256, 64>(w, a, s, nullptr); else launch_hp_inst<256, 40>(w, a, s, nullptr); return; }
+    if (w.KX == 64) launch_hp_inst<384, 64>(w, a, s, nullptr); else launch_hp_inst<384, 40>(w, a, s, nullptr);
 }
 
 }  // namespace fsnp

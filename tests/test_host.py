@@ -436,8 +436,9 @@ def test_column_split_kernels_keep_their_asm_invariants():
 def test_round3_kernels_keep_their_asm_invariants():
     """Static checks of the round-3 kernels (tools/check_lstm_asm.py).  lstm2_coop_pp_kernel: no scratch, no cache maintenance, the
     exchange images are written with 16-byte sc1 stores and read with 16-byte sc1 loads, and every
-    MFMA of the time loop takes its weights from an AGPR (the pinning survived the compiler).  lstm2_generic_kernel: plain FMAs, no
-    MFMA, no scratch."""
+    MFMA of the time loop takes its weights from an AGPR (the pinning survived the compiler).  lstm2_coop_hp_kernel: exactly the
+    16x16x4 MFMAs of two unrolled half-phases, layer-1 weights from AGPRs, operands by LDS DMA, 16-byte sc1 stores, DPP row sums, no
+    scratch.  lstm2_generic_kernel: plain FMAs, no MFMA, no scratch."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
     mod = importlib.util.module_from_spec(spec)
@@ -449,6 +450,15 @@ def test_round3_kernels_keep_their_asm_invariants():
         # (the only dword sc1 stores left are the abort / error words of the bounded waits: two per wait site, 3 + 2 R sites)
         assert r["sc1_stores16"] >= 3 and r["sc1_loads16"] >= 16 and r["sc1_stores4"] <= 2 * (3 + 2 * int(re.search(r"ELi(\d)EEEv", name).group(1))), (name, r)
         assert r["mfma"] >= 100 and r["mfma_b_in_agpr"] >= 0.9 * r["mfma"], (name, r)
+    hp = mod.analyse_half_tile_ping_pong()
+    assert len(hp) == 4, sorted(hp)                           # H 256 / 384 x K 40 / 64
+    for name, r in hp.items():
+        h, kx = (int(v) for v in re.search(r"ILi(\d+)ELi(\d+)EEEv", name).groups())
+        per_pass = 4 * ((kx + 15) // 16) + 12 * (h // 16)      # MFMAs of one half-phase; the time loop is unrolled for the two halves
+        assert r["scratch"] == 0 and r["cache_maint"] == 0 and r["mfma_other"] == 0 and r["bpermute"] == 0, (name, r)
+        assert r["mfma"] == 2 * per_pass + 2 * 4 * ((kx + 15) // 16), (name, r)
+        assert r["mfma_b_in_agpr"] >= 0.55 * r["mfma"], (name, r)      # layer 1 = two thirds of the weights, pinned to AGPRs
+        assert r["lds_dma"] >= 2 and r["sc1_stores16"] >= 7 and r["dpp_ror"] >= 8, (name, r)
     gen = mod.analyse_generic()
     assert len(gen) == 8, sorted(gen)                         # 1 / 2 / 4 / 8 sequences per workgroup x {sub-band, full-band}
     for name, r in gen.items():

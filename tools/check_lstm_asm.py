@@ -88,6 +88,27 @@ def analyse_ping_pong(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_half_tile_ping_pong(flags=("-fno-slp-vectorize",)):
+    """Whole-kernel invariants of lstm2_coop_hp_kernel (lstm_hp.hip), per instantiation: 16x16x4 MFMAs (and how many take their B
+    operand - a resident weight - from an AGPR), scratch, cache maintenance, LDS-DMA operand loads (sc1), 16-byte sc1 stores of the
+    exchange images, DPP row rotations (the Linear partial sums), ds_bpermute (must be none)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "lstm_hp.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp20lstm2_coop_hp_kernelI\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        cnt = lambda pat: sum(1 for x in body if re.search(pat, x))
+        res[name] = dict(mfma=cnt(r"v_mfma_f32_16x16x4_f32"), mfma_other=cnt(r"v_mfma") - cnt(r"v_mfma_f32_16x16x4_f32"),
+                         mfma_b_in_agpr=cnt(r"v_mfma_f32_16x16x4_f32 [av]\[\d+:\d+\], v\d+, a\d+, "), scratch=cnt(r"scratch_"),
+                         cache_maint=cnt(r"buffer_wbl2|buffer_inv"), lds_dma=cnt(r"buffer_load_dwordx4.*sc1.*lds|buffer_load_dwordx4.*lds.*sc1"),
+                         sc1_stores16=cnt(r"buffer_store_dwordx4.*sc1"), dpp_ror=cnt(r"row_ror"), bpermute=cnt(r"ds_bpermute"))
+    return res
+
+
 def analyse_generic(flags=("-fno-slp-vectorize",)):
     """lstm2_generic_kernel (lstm_generic.hip): fp32 FMAs only - no MFMA - and no scratch in any instantiation."""
     with tempfile.TemporaryDirectory() as td:

@@ -1,6 +1,7 @@
 #!/bin/bash
-# one-off: full GPU suite + small-batch bench lines after the counter padding / lstm_hp.hip / new cost table
+# one-off: half-tile ping-pong kernel, x gather by buffer loads
 set -u
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -12 | tee gpurun_out/pytest_gpu_hp.log
-for b in 1 2 3 5 8 12 16 32; do timeout 300 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench B=$b: %.3f ms/step (alt %.3f) %.0f frames/s' % (d['ms_per_step'], d.get('alt_ms_per_step') or -1, d['value']), [c['kernel'][:22]+' x%d' % c['sequences'] for c in d['roofline']['subband_plan']])"; done | tee gpurun_out/hp_bench.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py -q --tb=short -p no:cacheprovider -k "half_tile_ping_pong" 2>&1 | tail -3 | tee gpurun_out/hp_tests.txt
+for n in 32 257 320; do HP=1 timeout 120 python tools/time_lstm.py $n 128 5 2>&1 | tail -1; done | tee gpurun_out/hp_times.txt
+timeout 300 python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench B=1: %.3f ms/step (alt %.3f)' % (d['ms_per_step'], d.get('alt_ms_per_step') or -1))" | tee -a gpurun_out/hp_times.txt

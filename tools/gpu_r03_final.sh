@@ -58,8 +58,8 @@ python tools/make_config_table.py r03 > /dev/null
 python tools/dump_costs.py > gpurun_out/dump_costs.log 2>&1
 # RCCL at world size 1: the driver's multi-GPU launch line with N = 1
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_rccl_n1.log
-# the opt-in ping-pong K split at B = 1
-FSNP_COOP_PP=1 timeout 300 python bench.py --batch 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_b1_pp.log
+# B = 1 without the half-tile ping-pong kernel (the round-2 kernels with padded counters)
+FSNP_COOP_HP=0 timeout 300 python bench.py --batch 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_b1_pp.log
 timeout 120 python tools/pp_phase_profile.py 64 64 2 > gpurun_out/pp_profile_64x2.txt 2>&1
 python - <<'PY' | tee gpurun_out/b_final.txt
 import json
@@ -81,5 +81,29 @@ for f in ("bench_rccl_n1.log", "bench_b1_pp.log"):
     except Exception as e:
         print(f, "??", e)
 PY
+# B = 1 (the reference CLI's batch): fabric reads of the sub-band kernel with / without the half-tile ping-pong kernel, its phase
+# profile, isolated timings of the column-split kernels
+cd /tmp
+for hp in 1 0; do
+  rm -rf $R/gpurun_out/pmcb1
+  FSNP_COOP_HP=$hp timeout 300 rocprofv3 --pmc FETCH_SIZE -f csv -d $R/gpurun_out/pmcb1 -o pmc -- python $R/bench.py --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 > $R/gpurun_out/pmcb1_$hp.log 2>&1
+  python - <<PY | tee -a $R/gpurun_out/b1_fetch_size.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$R/gpurun_out/pmcb1/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE" and "lstm2_coop" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0][:60]; agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+for k, (v, n) in agg.items():
+    print("FSNP_COOP_HP=$hp  %-60s FETCH_SIZE per launch = %.4g KB (x2 per MI355X_MICROARCH.md = %.3f GB), %d launches" % (k, v / n, 2 * v / n * 1024 / 1e9, n))
+PY
+done
+rm -rf $R/gpurun_out/pmcb1
+cd $R
+timeout 120 python tools/pp_phase_profile.py 257 64 0 2>&1 | grep -v amdgpu > gpurun_out/hp_phase_profile.txt
+for n in 32 160 257 320; do
+  FSNP_COOP_HP=0 timeout 120 python tools/time_lstm.py $n 128 5 2>&1 | tail -1
+  HP=1 timeout 120 python tools/time_lstm.py $n 128 5 2>&1 | tail -1
+done > gpurun_out/hp_times_final.txt
 head -14 gpurun_out/kernel_stats.csv | cut -c1-170
 echo "== done"
