@@ -371,15 +371,15 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
                 // fabric is slow); the other waves learn the outcome through LDS three groups after that, and again behind barrier 2
                 if ((g == POLL1_G || g == POLL2_G) && wave == 1 && polls && !fetched) seen = __hip_atomic_load(nbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (g == CHECK1_G && wave == 1 && polls && __builtin_amdgcn_readfirstlane(seen) >= ntarget) {
-                    if (lane == 0) flags[1] = token;
+                    if (lane == 0) __hip_atomic_store(&flags[1], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     fetch_next(); fetched = true;
                 }
-                if (g == PEER_G && wave != 1 && polls && __builtin_amdgcn_readfirstlane(flags[1]) == token) { fetch_next(); fetched = true; }
+                if (g == PEER_G && wave != 1 && polls && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == token) { fetch_next(); fetched = true; }
                 __builtin_amdgcn_sched_barrier(0);
                 p = pn; q = qn;
             }
             if (wave == 1 && polls && !fetched && __builtin_amdgcn_readfirstlane(seen) >= ntarget) {
-                if (lane == 0) flags[1] = token;
+                if (lane == 0) __hip_atomic_store(&flags[1], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 fetch_next(); fetched = true;
             }
             FSNP_HP_STAMP(4);
@@ -388,7 +388,7 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             gat[(4 + wave) * 64 + lane] = make_float4(a1a[0], a1a[1], a1a[2], a1a[3]);
             __syncthreads();
             FSNP_HP_STAMP(5);
-            if (polls && !fetched && __builtin_amdgcn_readfirstlane(flags[1]) == token) { fetch_next(); fetched = true; }
+            if (polls && !fetched && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == token) { fetch_next(); fetched = true; }
             // ---- cells: {layer 1 (h1_t), layer 0 (h0_{t+1})} of (row crow, unit cu) as ONE packed two-cell update
             {
                 const f32x2 hh = lstm_cell_pair(f32x2{gf[4 * 256 + gidx], gf[0 * 256 + gidx]}, f32x2{gf[5 * 256 + gidx], gf[1 * 256 + gidx]},
