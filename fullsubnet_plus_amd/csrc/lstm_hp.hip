@@ -20,8 +20,10 @@
 //     ping-pong of lstm_pp.hip without needing a second row tile, i.e. with every CU busy at B = 1 (9 row tiles x 24);
 //   * operands come global -> LDS by DMA (buffer_load_dwordx4 ... lds, waves 1-3: 16 KB each): no VGPRs, no issue slots of
 //     the matrix pipe's wave, and the fetch of the next half-phase is issued from INSIDE the current MFMA pass as soon as a
-//     poll shows the other half's counter complete; wave 0 owns the publishing side (three 16-byte write-through stores
-//     from an LDS staging buffer, the arrival a quarter pass later behind an honest vmcnt(0) - its queue holds nothing else);
+//     poll (ONE wave polls; the others learn the outcome through an LDS token) shows the other half's counter complete;
+//     wave 0 owns the publishing side: three 16-byte write-through stores from an LDS staging buffer, issued behind the NEXT
+//     half-phase's first barrier (which thereby doubles as the "staging complete" barrier), the arrival a quarter pass later
+//     behind an honest vmcnt(0) - wave 0's queue holds nothing else;
 //   * fused phase as in lstm_pp.hip: [layer 1 of step t, layer 0 of step t + 1] is ONE pass over h0_t.
 // Exchange region and abort protocol: those of lstm_coop.hip; arrival counters: one per half tile, each in a 128-byte line of its own.
 // 16x16x4 MFMAs sum K in another order than the 32x32x2 kernels, so results are bit-identical to no sibling kernel; same
