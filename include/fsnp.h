@@ -209,7 +209,9 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
  *  half-tile: 16-row tiles, csrc/lstm16.hip, 5 = lstm2_coop_split K-split with one workgroup set per layer: planned for 1-2 row
  *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never, 7..10 = lstm2_coop_pp K-split at 8 units
  *  with the two layers fused into one phase and 1..4 row tiles per group of H / 8 workgroups worked on in turn, csrc/lstm_pp.hip;
- *  FSNP_COOP_PP=0 = never),
+ *  opt-in: FSNP_COOP_PP=1; 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
+ *  gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row tiles;
+ *  FSNP_COOP_HP=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The same with 6 ints per record: {kernel, sequences, tiles, VALU rows, precision, workgroups}; precision = the arithmetic of
