@@ -23,6 +23,8 @@
 //     published with h1 and summed in a fixed order by workgroup cs == 0 one step later (deterministic, no float
 //     atomics).  SEQ = true (full-band model): h1_t is also written row-major to seq_out[seq][t][H]; the wide
 //     Linear(512, 257) + activation is one GEMM afterwards (tcn.hip).
+#include <cstdlib>
+
 #include "fsnp_common.h"
 #include "lstm_common.h"
 
@@ -1089,10 +1091,13 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     }
     const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(S, a.num_tiles, a.coop_xcd) : a.num_tiles * S;
     if constexpr (!SEQ) {
-        // layer-skewed schedule (lstm2_coop_skew_kernel), same launch shape.  Measured (profiles/r02_column_split.md): it pays from
-        // 16 units per workgroup up (9 tiles 19.8 -> 18.0 us per step, 17 tiles 28.1 -> 25.8, 41 tiles 53.0 -> 48.4); at 8 units
-        // the MFMA phases (2 us) are too short to cover the second drain + arrival per step (1 tile 11.0 -> 10.8, 5 tiles 16 -> 28)
-        if (a.coop_skew && UNITS >= 16) {
+        // layer-skewed schedule (lstm2_coop_skew_kernel), same launch shape.  Measured (profiles/r02_column_split.md): 16 units per
+        // workgroup and up: 9 tiles 19.8 -> 18.0 us per step, 17 tiles 28.1 -> 25.8, 41 tiles 53.0 -> 48.4.  At 8 units it did not
+        // pay in round 2 (1 tile 11.0 -> 10.8, 5 tiles 16 -> 28) - its two arrival counters per tile sat in the one cache line all
+        // counters shared; with a line per counter (round 3, profiles/r03_column_split.md section 8) it does: 1 tile 9.7 -> 8.8,
+        // 5 tiles 10.4 -> 9.1.  FSNP_SKEW_MIN_UNITS=16 restores the round-2 choice.
+        static const int skew_min_units = [] { const char* e = getenv("FSNP_SKEW_MIN_UNITS"); return e ? atoi(e) : 8; }();
+        if (a.coop_skew && UNITS >= skew_min_units) {
             auto skew = lstm2_coop_skew_kernel<HID, KX, UNITS, GRU>;
             static PerDeviceOnce skew_once;
             skew_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds); });

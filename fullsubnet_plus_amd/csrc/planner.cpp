@@ -19,7 +19,7 @@ CostTable default_costs() {
     // round-3 measurements (fsnp_measure_costs on an MI355X, profiles/r03_planner_costs.json - after the arrival counters got a
     // 128-byte line each, which took 35 % off a full K-split launch at 8 units and 14 % at 16): K split (serial schedule at 8
     // units, layer-skewed from 16 up): a full launch / one row tile; three-way split at 85 / 170 row tiles
-    const double ks[4] = {9.4, 14.2, 24.8, 49.2}, k1[4] = {8.9, 13.3, 22.7, 45.6}, cn[2] = {84.0, 154.0};
+    const double ks[4] = {8.4, 14.2, 24.8, 49.2}, k1[4] = {8.0, 13.3, 22.7, 45.6}, cn[2] = {84.0, 154.0};
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
     t.rowtile = 206.0; t.rowtile_ex = 0.11; t.rowtile16 = 103.0;
@@ -62,8 +62,8 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
         if (c.rpg) {             // role-split schedule: priced relative to the same shape on the one-set kernels (kSplitRatio)
             const int cap = h.num_cus_real / (2 * (h.H / c.units));
             const double r = h.coop_split == 2 ? 0.01 : kSplitRatio[ui];
-            // 8 units: measured directly (1 tile 8.2 us, 2 tiles 10.0 - the one-set kernel: 8.7 / 13.2), scaled with the table
-            if (ui == 0 && c.num_tiles <= 2 && h.coop_split != 2) return (c.num_tiles == 1 ? 8.2 : 10.0) * h.cost.ksplit1[0] / 8.7;
+            // 8 units: measured directly against the one-set (layer-skewed) kernel, scaled with the table
+            if (ui == 0 && c.num_tiles <= 2 && h.coop_split != 2) return (c.num_tiles == 1 ? 0.93 : 1.13) * h.cost.ksplit1[0];     // (8.2 / 10.0 us against 8.8 / 8.85 layer-skewed)
             if (cap <= 1) return r * h.cost.ksplit1[ui];
             const double f = (double)(c.num_tiles - 1) / (cap - 1);
             return r * (h.cost.ksplit1[ui] + (h.cost.ksplit[ui][0] - h.cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0));
@@ -167,7 +167,8 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
         if (rg > 0) push(SbChunk{7, 0, num_rows, cdiv(num_rows, rg), 0, rg, 0, 0, rg, 0, 0});
         return p;
     }
-    auto cost_of = [&](const std::vector<SbChunk>& v) { double c = 0; for (const SbChunk& k : v) c += est_step_us(h, k); return c; };
+    // (+ 1.2 us per launch, as inside plan_columns: prologue / drain amortised over ~100 steps - fewer launches win near-ties)
+    auto cost_of = [&](const std::vector<SbChunk>& v) { double c = 0; for (const SbChunk& k : v) c += est_step_us(h, k) + 1.2; return c; };
     const bool rowtile_ok = h.rowtile_ok;                     // a one-tile-per-CU kernel exists for this cell / size
     const bool coop_on = h.lstm_coop != 0 || !rowtile_ok;     // (without one the column-split kernels are the only path)
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
@@ -184,7 +185,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
         if (!cols.empty()) { best = cols; best_cost = cost_of(cols); }
     }
     if (rowtile_ok) {
-        const double cw = est_step_us(h, whole);
+        const double cw = est_step_us(h, whole) + 1.2;
         if (cw < best_cost) { best = {whole}; best_cost = cw; }
         if (q >= 1 && rem > 0) {
             std::vector<SbChunk> comp{SbChunk{0, 0, q * full, q * h.num_cus, 0, 32, 0, 0, 0, 0, 0}};
@@ -202,7 +203,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     if (h.lstm16_ok && h.ih_bf16 == 0) {
         const int per_round = h.num_cus * 16;
         const SbChunk all16{4, 0, num_rows, cdiv(num_rows, 16), 0, 16, 0, 0, 0, 0, 0};
-        const double c_all = est_step_us(h, all16);
+        const double c_all = est_step_us(h, all16) + 1.2;
         if (c_all < best_cost) { best = {all16}; best_cost = c_all; }
         if (num_rows > per_round) {
             std::vector<SbChunk> comp{SbChunk{4, 0, per_round, h.num_cus, 0, 16, 0, 0, 0, 0, 0}};

@@ -538,7 +538,7 @@ def test_subband_plan_choices_match_the_design():
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
     assert kinds(3084) == [(4, 3084)]                                               # B = 12: 193 half tiles, one round
     p = _plan(3084, gru=1)                                                          # (GRU: 97 tiles = one per group + the rest K split)
-    assert [c["kind"] for c in p] == [2, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 32 and sum(c["rows"] for c in p) == 3084
+    assert p[0]["kind"] == 2 and p[0]["rpg"] == 1 and p[0]["tiles"] == 85 and all(c["kind"] == 1 for c in p[1:]) and sum(c["rows"] for c in p) == 3084
     assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2
     p = _plan(1376)                                                                 # 43 tiles: a full K-split launch + a tiny one
     assert [c["kind"] for c in p] == [1, 1] and p[0]["par"] == 64 and p[1]["par"] == 8 and sum(c["rows"] for c in p) == 1376
