@@ -1302,7 +1302,7 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
     add("  FSNP_COOP_PP=%s -> ping-pong K split (lstm_pp.hip) %s\n", env("FSNP_COOP_PP"), !h->pp_ok ? "not built for this model" : h->coop_pp ? "planned" : "never");
     add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
-    add("  FSNP_COOP_SKEW=%s -> K-split schedule %s\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed from 16 units up" : "serial");
+    add("  FSNP_COOP_SKEW=%s -> K-split schedule %s (FSNP_SKEW_MIN_UNITS=%s: smallest units per workgroup that run it, default 8)\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial", env("FSNP_SKEW_MIN_UNITS"));
     add("  FSNP_COOP_SPLIT=%s -> role-split K split mode %d (0 never, 1 auto outside the pipelined loop, 2 wherever it fits, 3 auto also pipelined)\n", env("FSNP_COOP_SPLIT"), h->coop_split);
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
     add("  FSNP_COOP_XCD=%s (0 = no XCD-local workgroup placement)  FSNP_OWN_CU=%s (0 = deferred chunks do not claim their CUs' LDS)\n", env("FSNP_COOP_XCD"), env("FSNP_OWN_CU"));
