@@ -271,14 +271,14 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.sbt_x0 = take(sbt_x); w.sbt_x = take(sbt_x); w.sbt_fb = take(sbt_x); w.sbt_y1 = take(sbt_y); w.sbt_y2 = take(sbt_y);
     w.zero_begin = o;
     w.fsum = take(fsn ? 0 : (size_t)3 * B * h->FP * 8);
-    w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * 2 * 8);
+    w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * kGnStride * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
     w.coop_bar = take(coop_counter_bytes(plan.coop_tiles));      // two arrival counters per row tile (+ the padded copies: lstm_common.h)
     w.coop_abort = take(256);             // [0] sub-band launches, [16] full-band LSTM (FullSubNet)
     w.fb_hx = take(fsn ? lstm_coop_exchange_bytes(h->CH, fb_row_tiles(B)) : 0);
     w.fb_bar = take(fsn ? (size_t)fb_row_tiles(B) * 4 : 0);
-    w.sbt_gn = take(h->sb_tcn ? (size_t)8 * 2 * nrows_pad * 2 * 8 : 0);
+    w.sbt_gn = take(h->sb_tcn ? (size_t)8 * 2 * nrows_pad * kGnStride * 8 : 0);
     w.zero_end = o;
     w.dbg_tcn0 = take(h->debug ? (size_t)B * Tp * h->FP * 4 : 0);
     w.total = o;

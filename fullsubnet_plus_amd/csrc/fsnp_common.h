@@ -97,7 +97,7 @@ struct TcnBuffers {
     float* x;          // [3][B][Tp][FP]  running activation
     float* y1;         // [3][B][Tp][CH]
     float* y2;         // [3][B][Tp][CH]
-    double* gn;        // [NB][2][3][B][2] GroupNorm (sum, sumsq) accumulators, zeroed per forward
+    double* gn;        // [NB][2][3][B][kGnStride] GroupNorm (sum, sumsq) accumulators (one 128-byte line per pair), zeroed per forward
     float* fb;         // [3][B][Tp][FP]  output
     float* dbg_tcn0;   // optional [B][Tp][FP]: mag branch after block 0
 };
@@ -129,6 +129,9 @@ struct SubbandBuffers {
 };
 // one sub-band sequence slot.  b = utterance (gather mode) or sequence index (dense mode)
 struct RowDesc { int b, f, out_off, valid; };
+// GroupNorm(1, C) statistics of the TCN stacks: one {sum, sum of squares} fp64 pair per (block, norm, branch, utterance), fed by one
+// atomic pair per workgroup; doubles between consecutive pairs (a 128-byte line each: the atomics of different planes do not serialise on one line)
+constexpr int kGnStride = 16;
 
 void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& buf, const RowDesc* rows,
                           int num_slots, hipStream_t s);

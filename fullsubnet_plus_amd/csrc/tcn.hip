@@ -34,9 +34,9 @@ struct GemmArgs {
     const float* bias; long bias_bs;           // [branch][Npad]
     float* C; long c_bs; int ldc;              // C[branch][utt][t][ldc]
     const float* R; long r_bs; int ldr;        // residual (EPI_RESIDUAL)
-    const double* gn_in;                       // [branch][utt][2]   (PRO_GN)
+    const double* gn_in;                       // [branch][utt][kGnStride]: {sum, sum of squares} in a 128-byte line of their own   (PRO_GN)
     const float* gamma; const float* beta; long gb_bs;  // [branch][K] (PRO_GN)
-    double* gn_out;                            // [branch][utt][2]   (EPI_PRELU_STATS)
+    double* gn_out;                            // [branch][utt][kGnStride]: {sum, sum of squares} in a 128-byte line of their own   (EPI_PRELU_STATS)
     const float* prelu; long prelu_bs;         // [branch] scalar slope (EPI_PRELU_STATS)
     int K, N, Tp, B, act;
     double gn_count;                           // elements per GroupNorm plane (PRO_GN)
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
     const float* gamma = nullptr;
     const float* beta = nullptr;
     if constexpr (PRO == PRO_GN) {
-        const double* st = g.gn_in + ((long)branch * g.B + utt) * 2;
+        const double* st = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
         const double m = st[0] / g.gn_count;
         const double var = st[1] / g.gn_count - m * m;
         mean = (float)m;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
         if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
         __syncthreads();
         if (tid == 0) {
-            double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+            double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
             atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
             atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
         }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
     float slope = 0.f, rstd = 1.f, mr = 0.f;
     if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
     if constexpr (EPI == EPI_RESIDUAL) {
-        const double* stt = g.gn_in + ((long)branch * g.B + utt) * 2;
+        const double* stt = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
         const double m = stt[0] / g.gn_count;
         const double var = stt[1] / g.gn_count - m * m;
         const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
         if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
         __syncthreads();
         if (tid == 0) {
-            double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+            double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
             atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
             atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
         }
@@ -502,7 +502,7 @@ static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hi
 // GroupNorm1 -> depthwise dilated conv (k=3, zero padding = dilation) -> PReLU2 (+ GroupNorm2 statistics)
 struct DwArgs {
     const float* Y1; float* Y2; long y_bs;      // [branch][utt][t][CH]
-    const double* gn_in; double* gn_out;        // [branch][utt][2]
+    const double* gn_in; double* gn_out;        // [branch][utt][kGnStride]: {sum, sum of squares} in a 128-byte line of their own
     const float* gamma; const float* beta;      // [branch][CH]
     const float* w; const float* b;             // [branch][3][CH], [branch][CH]
     const float* prelu;                         // [branch]
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void tcn_dwconv_kernel(DwArgs g) {
     int plane, chunk;
     if (!xcd_decode(blockIdx.x, g.chunks, g.planes, plane, chunk)) return;
     const int branch = plane / g.B, utt = plane % g.B, t0 = chunk * DW_ROWS;
-    const double* st = g.gn_in + ((long)branch * g.B + utt) * 2;
+    const double* st = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
     const double m = st[0] / g.gn_count;
     const double var = st[1] / g.gn_count - m * m;
     const float mean = (float)m;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void tcn_dwconv_kernel(DwArgs g) {
     if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
     __syncthreads();
     if (tid == 0) {
-        double* out = g.gn_out + ((long)branch * g.B + utt) * 2;
+        double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
         atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
         atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
     }
@@ -575,7 +575,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
     const long y_bs = (long)d.B * d.Tp * d.CH;
     const int row_tiles = cdiv(d.Tp, BM) * d.B;
     const double gn_count = (double)d.CH * d.Tp;
-    auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * branches) * d.B * 2; };
+    auto gn_slot = [&](int blk, int which) { return buf.gn + ((long)(blk * 2 + which) * branches) * d.B * kGnStride; };
     // DMA GEMMs: the full-band stacks only (their input `att` has zero pad columns; the sub-band TCN's buffers make no such promise)
     const bool dma = branches == 3 && w.gemm_dma;
     const bool relu_fused = dma && w.NB > 0 && !(w.NB == 1 && buf.dbg_tcn0);     // the last sconv stores max(x, 0) for the final Linear
