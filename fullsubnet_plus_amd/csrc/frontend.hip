@@ -162,11 +162,12 @@ __global__ __launch_bounds__(256) void fe_scan_kernel(const double* __restrict__
     }
 }
 
-constexpr int FSUM_ROWS = 32;
+// frames per workgroup of fe_fsum_kernel: 32 with many utterances, fewer with few (B = 1: 12 workgroups took 13 us)
+static int fsum_rows_per_wg(int B) { return B >= 8 ? 32 : B >= 4 ? 16 : B >= 2 ? 8 : 4; }
 __global__ __launch_bounds__(256) void fe_fsum_kernel(const float* __restrict__ raw, const NormMD* __restrict__ md,
-                                                      double* __restrict__ fsum, int B, int Tp, int F, int FP) {
+                                                      double* __restrict__ fsum, int B, int Tp, int F, int FP, int rows) {
     const long ub = (long)blockIdx.z * B + blockIdx.y;
-    const int t0 = blockIdx.x * FSUM_ROWS, t1 = min(t0 + FSUM_ROWS, Tp);
+    const int t0 = blockIdx.x * rows, t1 = min(t0 + rows, Tp);
     for (int f = threadIdx.x; f < F; f += 256) {
         double s = 0.0;
         for (int t = t0; t < t1; ++t) {
@@ -404,8 +405,9 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
     if (phase == FE_PHASE_REPACK) return;
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
-    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, FSUM_ROWS), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,
-                       d.B, d.Tp, d.F, d.FP);
+    const int frows = fsum_rows_per_wg(d.B);
+    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,
+                       d.B, d.Tp, d.F, d.FP, frows);
     GateArgs g;
     g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;
     g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;

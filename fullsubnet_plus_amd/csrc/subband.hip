@@ -32,14 +32,16 @@ __device__ __forceinline__ NormMD sb_norm_md(int norm_type, double sum, double s
     return r;
 }
 
-constexpr int SB_ROWS = 16;
+// frames per workgroup: 16 with many utterances; fewer with few, so that a small batch still launches >= ~64 workgroups (B = 1: 8
+// workgroups took 25 us, latency-bound)
+static int sb_rows_per_wg(int B) { return B >= 8 ? 16 : B >= 4 ? 8 : B >= 2 ? 4 : 2; }
 __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
                                                                const float* __restrict__ fb, long fb_bs, int nfb,
                                                                const float* __restrict__ refl_w,
                                                                const float* __restrict__ refl_wfb,
-                                                               double* __restrict__ acc, int Tp, int F, int FP) {
+                                                               double* __restrict__ acc, int Tp, int F, int FP, int rows) {
     __shared__ double red[8];
-    const int b = blockIdx.y, t0 = blockIdx.x * SB_ROWS, t1 = min(t0 + SB_ROWS, Tp);
+    const int b = blockIdx.y, t0 = blockIdx.x * rows, t1 = min(t0 + rows, Tp);
     double s = 0.0, q = 0.0;
     for (int f = threadIdx.x; f < F; f += 256) {
         const double wr = refl_w[f], wfb = refl_wfb[f];
@@ -125,8 +127,9 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
                           int num_slots, hipStream_t s) {
     const long fb_bs = (long)d.B * d.Tp * d.FP;
     if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
-        hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, SB_ROWS), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
-                           fb_bs, (d.NIN - d.NSB) / (2 * buf.NFBN + 1), buf.refl_w, buf.refl_wfb, buf.acc, d.Tp, d.F, d.FP);
+        const int rows = sb_rows_per_wg(d.B);
+        hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, rows), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
+                           fb_bs, (d.NIN - d.NSB) / (2 * buf.NFBN + 1), buf.refl_w, buf.refl_wfb, buf.acc, d.Tp, d.F, d.FP, rows);
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);
     } else {
