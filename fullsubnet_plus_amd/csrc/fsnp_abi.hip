@@ -1339,7 +1339,7 @@ int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 1) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel) or 1 (DMA kernel where it applies)"); return 1; }
+    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply) or 2 (as 1, never the small-batch split-K kernel)"); return 1; }
     h->tw.gemm_dma = mode;
     drop_graphs(h);          // a captured full-band chain holds the other kernels
     return 0;

@@ -89,7 +89,8 @@ struct TcnWeights {
     int NB, N1P, K1P, N2P, K2P;
     int num_cus;         // for the per-launch column-tile choice (N1P, N2P are multiples of 384: any BN fits)
     int dilation[16];
-    int gemm_dma;        // 1 = the full-band GEMMs run on tcn_gemm_dma_kernel where its requirements hold (fsnp_debug_set_gemm_dma)
+    int gemm_dma;        // 1 = the full-band GEMMs run on tcn_gemm_dma_kernel / (small batches) tcn_gemm_sk_kernel where their requirements hold,
+                         // 2 = never the small-batch kernel, 0 = the general kernel (fsnp_debug_set_gemm_dma)
 };
 
 struct TcnBuffers {

@@ -448,15 +448,201 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tcn_gemm_sk_kernel: the DMA GEMM for SMALL problems (round 3) - the reference CLI's B = 1 up to B = 16.  There a launch of tcn_gemm_dma_kernel is 15-24 workgroups whose serial k-loop (17 / 32 k-tiles x 0.43 us of MFMAs)
+// IS the launch: conv1x1 17.6 us, sconv 25.6 us at B = 1 with 232 CUs idle (profiles/r03_fullband.md).  Here a workgroup owns a
+// 32 x 64 output tile and its four waves split K (wave w multiplies k-tiles w, w + 4, ...): four times the workgroups, a quarter of
+// the k-loop each.  A wave stages ITS k-tiles in a private double buffer (same slot layout / swizzle as above with 32 rows), so
+// the loop has no workgroup barrier at all - the wave waits for its own DMA only; the four partial tiles are added in a fixed order
+// (wave 0 + 1 + 2 + 3) through the staging LDS and wave w finishes rows [8 w, 8 w + 8) with the same epilogues.  K is summed in another
+// order than by tcn_gemm_dma_kernel: same tolerance, not bit-identical to it.
+constexpr int BMS = 32;
+template <int EPI>
+__global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
+    constexpr int BN = 64;
+    constexpr int A_SLOTS = BMS * 4, B_SLOTS = BN * 4, STAGE = A_SLOTS + B_SLOTS;     // float4 slots per stage of ONE wave (6 KiB)
+    __shared__ __attribute__((aligned(16))) float4 smem[4 * 2 * STAGE];                // 48 KiB; re-used for the partial tiles (32 KiB)
+    __shared__ double red[8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int row_tile_all, ntile;
+    if (!xcd_decode(blockIdx.x, g.ntiles_n, g.row_tiles_all, row_tile_all, ntile)) return;
+    const int branch = row_tile_all / g.row_tiles, row_tile = row_tile_all % g.row_tiles;
+    const int tiles_per_utt = cdiv(g.Tp, BMS);
+    const int utt = row_tile / tiles_per_utt;
+    const int t0 = (row_tile % tiles_per_utt) * BMS;
+    const int n0 = ntile * BN;
+    const int rows_valid = min(BMS, g.Tp - t0);
+
+    const float* A = g.A + branch * g.a_bs + ((long)utt * g.Tp + t0) * g.lda;
+    const float* W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
+    const int a_bytes = rows_valid * g.lda * 4, w_bytes = BN * g.ldw * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, w_bytes, 0x00020000);
+
+    // DMA pieces of one k-tile (per wave): A slots [0, 128) = two pieces, B slots [0, 256) = four.  Slot s = row s >> 2, k-quad (s & 3) ^ swz(row)
+    const int ktiles = g.ldw / BK;
+    int va[2], va_last[2], vb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = i * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        va[i] = row * g.lda * 4 + kq * 16;                                    // rows >= rows_valid: beyond a_bytes -> zeros
+        va_last[i] = ((ktiles - 1) * BK + kq * 4 < g.lda) ? va[i] : a_bytes;   // last k-tile: k-quads beyond the row -> zeros
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sl = i * 64 + lane, n = sl >> 2, kq = (sl & 3) ^ ((n >> 2) & 3);
+        vb[i] = n * g.ldw * 4 + kq * 16;
+    }
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    float4* mine = smem + wave * 2 * STAGE;
+    auto issue = [&](int kt, int stage) {
+        float4* st = mine + stage * STAGE;
+        const bool last = kt == ktiles - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + 0), 16, last ? va_last[0] : va[0], kt * (BK * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + 64), 16, last ? va_last[1] : va[1], kt * (BK * 4), 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(st + A_SLOTS + i * 64), 16, vb[i], kt * (BK * 4), 0, 0);
+    };
+    const int r = lane & 31, kh = lane >> 5, sw = (r >> 2) & 3;
+    int aoff[2], boff[2][2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        aoff[kg] = r * 4 + ((kg * 2 + kh) ^ sw);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) boff[kg][jn] = A_SLOTS + (jn * 32 + r) * 4 + ((kg * 2 + kh) ^ sw);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    // the wave's k-tiles: kt = wave, wave + 4, ... (hipcc waits vmcnt(0) in front of the ds_reads that follow a DMA: exactly the
+    // wave's own DMA here - no other wave touches this buffer, so no barrier)
+    if (wave < ktiles) issue(wave, 0);
+    int stage = 0;
+    for (int kt = wave; kt < ktiles; kt += 4) {
+        const float4* st = mine + stage * STAGE;
+        float4 a4[2], b4[2][2];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            a4[kg] = st[aoff[kg]];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) b4[kg][jn] = st[boff[kg][jn]];
+        }
+        if (kt + 4 < ktiles) issue(kt + 4, stage ^ 1);
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].x, b4[kg][jn].x, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].y, b4[kg][jn].y, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].z, b4[kg][jn].z, acc[jn], 0, 0, 0);
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].w, b4[kg][jn].w, acc[jn], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        stage ^= 1;
+    }
+    // ---- add the four partial tiles: part[wave][j][q][lane]; wave w then owns accumulator registers q in [4 w, 4 w + 4) = rows 8 w ... 8 w + 7
+    __syncthreads();                                  // every wave is done with its staging buffers
+    float* part = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[((wave * 2 + j) * 16 + q) * 64 + lane] = acc[j][q];
+    __syncthreads();
+    float sum[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = wave * 4 + qq;
+            float v = part[((0 * 2 + j) * 16 + q) * 64 + lane];
+            v += part[((1 * 2 + j) * 16 + q) * 64 + lane];
+            v += part[((2 * 2 + j) * 16 + q) * 64 + lane];
+            v += part[((3 * 2 + j) * 16 + q) * 64 + lane];
+            sum[j][qq] = v;
+        }
+
+    // ---- epilogue (as tcn_gemm_dma_kernel): C/D layout of 32x32: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
+    double s = 0.0, q2 = 0.0;
+    float slope = 0.f, rstd = 1.f, mr = 0.f;
+    if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
+    if constexpr (EPI == EPI_RESIDUAL) {
+        const double* stt = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
+        const double m = stt[0] / g.gn_count;
+        const double var = stt[1] / g.gn_count - m * m;
+        const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
+        rstd = (float)rs;
+        mr = (float)(m * rs);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool col_ok = col < g.N;
+        const float bias = g.bias[branch * g.bias_bs + col];
+        float c2 = 0.f;
+        if constexpr (EPI == EPI_RESIDUAL) c2 = g.c2[branch * g.c2_bs + col];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int t = t0 + qq + 8 * wave + 4 * (lane >> 5);
+            if (t < g.Tp && col_ok) {
+                float v;
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    v = sum[j][qq] + bias;
+                    v = v >= 0.f ? v : slope * v;
+                    s += (double)v;
+                    q2 += (double)v * (double)v;
+                } else if constexpr (EPI == EPI_RESIDUAL) {
+                    v = rstd * sum[j][qq] + (bias - mr * c2);
+                    v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
+                    if (g.relu_out) v = fmaxf(v, 0.f);
+                } else {
+                    v = sum[j][qq] + bias;
+                    if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
+                }
+                C[(long)t * g.ldc + col] = v;
+            } else if (t < g.Tp && col < g.ldc) {
+                C[(long)t * g.ldc + col] = 0.f;          // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
+            }
+        }
+    }
+    if constexpr (EPI == EPI_PRELU_STATS) {
+        s = wave_sum(s);
+        q2 = wave_sum(q2);
+        if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
+        __syncthreads();
+        if (tid == 0) {
+            double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
+            atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
+            atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
+        }
+    }
+}
+
 // true (and launched) when the DMA kernel's requirements hold
 template <int EPI>
-static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, hipStream_t s, int branches) {
+static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches, bool allow_splitk) {
     if (g.a_us || g.a_cols || g.lda % 4 || g.ldw % BK || g.ldw < g.K || g.lda < g.K) return false;
     if (g.ldw - g.lda >= BK) return false;                 // only the LAST k-tile may reach beyond a row of A
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15 || (g.a_bs * 4) % 16 || (g.w_bs * 4) % 16) return false;
     if ((long)BM * g.lda * 4 >= (1L << 31) || (long)64 * g.ldw * 4 >= (1L << 31)) return false;
     GemmArgs ga = g;
     ga.ntiles_n = cdiv(n, 64); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
+    // small problems: 32-row tiles whose four waves split K (tcn_gemm_sk_kernel) while that launch has at most 6 workgroups per CU
+    // (B <= 16 at 2 s clips; measured B = 1 ... 32, profiles/r03_fullband.md: full-band stage B = 1 0.47 -> 0.27 ms, B = 4 0.53 -> 0.32,
+    // B = 8 0.56 -> 0.41, B = 16 0.66 -> 0.65, B = 32 0.92 -> 1.05: not there).  FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never
+    static const int sk = [] { const char* e = getenv("FSNP_GEMM_SPLITK"); return e ? atoi(e) : 6; }();
+    const int row_tiles32 = cdiv(g.Tp, BMS) * g.B;
+    if (allow_splitk && sk && (long)ga.ntiles_n * row_tiles32 * branches <= (long)sk * num_cus && row_tiles == cdiv(g.Tp, BM) * g.B) {
+        ga.row_tiles = row_tiles32; ga.row_tiles_all = row_tiles32 * branches;
+        hipLaunchKernelGGL((tcn_gemm_sk_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
+        return true;
+    }
     hipLaunchKernelGGL((tcn_gemm_dma_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
     return true;
 }
@@ -591,7 +777,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             g.gn_out = gn_slot(blk, 0);
             g.prelu = w.a1 + blk; g.prelu_bs = w.NB;
             g.K = d.F; g.N = d.CH; g.Tp = d.Tp; g.B = d.B;
-            if (!(dma && launch_gemm_dma<EPI_PRELU_STATS>(g, d.CH, row_tiles, s, branches)))
+            if (!(dma && launch_gemm_dma<EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s, branches, w.gemm_dma == 1)))
                 launch_gemm<PRO_NONE, EPI_PRELU_STATS>(g, d.CH, row_tiles, w.num_cus, s, branches);
         }
         {   // GN1 -> depthwise -> PReLU2 (+ GN2 stats)
@@ -625,7 +811,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             gf.W = w.w2g + (long)blk * w.N2P * w.K2P;
             gf.bias = w.c1 + (long)blk * w.N2P;
             gf.c2 = w.c2 + (long)blk * w.N2P; gf.c2_bs = (long)w.NB * w.N2P;
-            if (!(dma && w.w2g && launch_gemm_dma<EPI_RESIDUAL>(gf, d.F, row_tiles, s, branches)))
+            if (!(dma && w.w2g && launch_gemm_dma<EPI_RESIDUAL>(gf, d.F, row_tiles, w.num_cus, s, branches, w.gemm_dma == 1)))
                 launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s, branches);
         }
         if (blk == 0 && buf.dbg_tcn0)
@@ -639,7 +825,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
         g.C = buf.fb; g.c_bs = x_bs; g.ldc = d.FP;
         g.K = d.F; g.N = d.F; g.Tp = d.Tp; g.B = d.B; g.act = fb_act;
         // (PRO_RELU of the general kernel is idempotent on an operand that was stored ReLU'd)
-        if (!(relu_fused && launch_gemm_dma<EPI_ACT>(g, d.F, row_tiles, s, branches)))
+        if (!(relu_fused && launch_gemm_dma<EPI_ACT>(g, d.F, row_tiles, w.num_cus, s, branches, w.gemm_dma == 1)))
             launch_gemm<PRO_RELU, EPI_ACT>(g, d.F, row_tiles, w.num_cus, s, branches);
     }
 }

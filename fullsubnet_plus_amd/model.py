@@ -446,8 +446,8 @@ class _HipModel(nn.Module):
         self.__dict__["_lstm_coop_mode"] = int(mode)
 
     def debug_set_gemm_dma(self, mode, device="cuda"):
-        """Tuning hook: 1 = full-band TCN GEMMs on the LDS-DMA kernel with GroupNorm folded into the weights (default),
-        0 = the general GEMM kernel."""
+        """Tuning hook: 1 = full-band TCN GEMMs on the LDS-DMA kernels with GroupNorm folded into the weights (default; small
+        batches: the split-K kernel tcn_gemm_sk_kernel), 2 = as 1 but never the small-batch kernel, 0 = the general GEMM kernel."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_gemm_dma(self._handle, int(mode)), "fsnp_debug_set_gemm_dma")
 

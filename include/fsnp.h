@@ -325,7 +325,9 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but t
 /* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
  * LDS DMA, GroupNorm folded into the sconv weights at fsnp_create; csrc/tcn.hip) where its layout requirements hold;
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
- * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it). */
+ * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it).  Small batches (at most 6 workgroups per CU
+ * on 32-row tiles: B <= 16 at 2 s clips) run the same GEMMs on tcn_gemm_sk_kernel - 32 x 64 tiles whose four waves split K, no
+ * workgroup barrier in the k-loop (FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never); mode 2 = as 1 but never that kernel. */
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
 /* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
  * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph

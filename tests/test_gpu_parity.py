@@ -695,8 +695,9 @@ def test_b32_full_vs_oracle(b32):
 
 @pytest.mark.parametrize("profile,B,T", [("default", 3, 126), ("harsh", 2, 37), ("default", 2, 300), ("harsh", 1, 1)])
 def test_dma_gemm_equals_general_gemm(profile, B, T):
-    """csrc/tcn.hip: tcn_gemm_dma_kernel (operands by LDS DMA, XOR-swizzled image, GroupNorm folded into the sconv weights)
-    against the general tcn_gemm_kernel on the same handle, and both against the oracle: T' = 128 (one full row tile per
+    """csrc/tcn.hip: the DMA GEMM kernels (operands by LDS DMA, XOR-swizzled image, GroupNorm folded into the sconv weights; at these
+    batch sizes tcn_gemm_sk_kernel, then tcn_gemm_dma_kernel through debug mode 2) against the general tcn_gemm_kernel on the same
+    handle, and all three against the oracle: T' = 128 (one full row tile per
     plane), 39 (ragged: rows beyond the plane are out of the DMA descriptor's range), 302 (three row tiles, ragged last), 3."""
     sd = make_state_dict(21, profile)
     m = _model(DEFAULT_MODEL_ARGS, sd, mode="full")
@@ -713,6 +714,14 @@ def test_dma_gemm_equals_general_gemm(profile, B, T):
     assert np.array_equal(fast, again)
     assert e_fast < TOL and e_gen < TOL and e_pair < 1e-4, (e_fast, e_gen, e_pair)
     assert not np.array_equal(fast, general)      # the two kernels really are different code paths
+    # small batches run the GEMMs on tcn_gemm_sk_kernel (32 x 64 tiles, four waves split K); mode 2 = the 128-row DMA kernel instead
+    m.debug_set_gemm_dma(2)
+    big_tiles = m(*g).cpu().numpy()
+    m.debug_set_gemm_dma(1)
+    e_big = rel_err(big_tiles, want)
+    _record(f"dma_gemm_{profile}_B{B}_T{T}_128_row_tiles", rel=e_big, rel_vs_splitk=rel_err(big_tiles, fast))
+    assert e_big < TOL and rel_err(big_tiles, fast) < 1e-4
+    assert not np.array_equal(big_tiles, fast)    # (another k order)
 
 
 def test_b32_10s_full_vs_oracle():

@@ -297,6 +297,19 @@ def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
         assert l["scratch"] == 0 and l["acc_moves"] == 0 and l["ds_write"] == 0 and l["valu"] <= 12, (key, l)
 
 
+def test_splitk_gemm_has_no_barrier_in_its_k_loop():
+    """tcn_gemm_sk_kernel (csrc/tcn.hip, small batches): a wave multiplies ITS k-tiles out of a private double buffer - 16 MFMAs per
+    k-tile, 6 + 6 DMA pieces, no scratch, no workgroup barrier between the first and the last MFMA."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_splitk_gemm()
+    assert len(res) == 3, sorted(res)
+    for key, l in res.items():
+        assert l["mfma"] == 16 and l["dma"] == 12 and l["scratch"] == 0 and l["barriers_between_mfmas"] == 0, (key, l)
+
+
 def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
     """lstm2_fc16_kernel (csrc/lstm16.hip): every k-group loop is 96 MFMAs + 24 weight loads, no scratch, no drain and no
     AGPR<->VGPR shuttling of the 24 accumulator tiles (the asm pins in the kernel exist for exactly that)."""

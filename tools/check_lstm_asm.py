@@ -109,6 +109,25 @@ def analyse_half_tile_ping_pong(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_splitk_gemm(flags=("-fno-slp-vectorize",)):
+    """tcn_gemm_sk_kernel (tcn.hip), per instantiation: one k-tile body per wave (16 MFMAs, 6 fragment reads, 6 DMA pieces + the 6 of the
+    first tile), no scratch, and NO workgroup barrier between the first and the last MFMA (a wave waits for its own DMA only)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "tcn.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp18tcn_gemm_sk_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), [l for l in m.group(2).split("\n") if l.strip() and not l.strip().startswith(";")]
+        cnt = lambda seg, pat: sum(1 for x in seg if re.search(pat, x))
+        idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+        res[name] = dict(mfma=cnt(body, r"v_mfma"), dma=cnt(body, r"buffer_load_dwordx4 .* lds"), scratch=cnt(body, r"scratch_"),
+                         barriers_between_mfmas=cnt(body[idx[0]:idx[-1] + 1], r"s_barrier"))
+    return res
+
+
 def analyse_generic(flags=("-fno-slp-vectorize",)):
     """lstm2_generic_kernel (lstm_generic.hip): fp32 FMAs only - no MFMA - and no scratch in any instantiation."""
     with tempfile.TemporaryDirectory() as td:
