@@ -1312,7 +1312,7 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_COMPOSITE_GAIN=%s -> %.3f\n", env("FSNP_COMPOSITE_GAIN"), h->composite_gain);
     add("  FSNP_DEFER_SMALL=%s -> %d  FSNP_SIDE_PRIO=%s\n", env("FSNP_DEFER_SMALL"), h->defer_small, env("FSNP_SIDE_PRIO"));
     add("  FSNP_GRAPH=%s -> %d (0 plain launches, 1 / 2 hipGraph replay of the full-band stages)\n", env("FSNP_GRAPH"), h->use_graph);
-    add("  FSNP_GEMM_DMA=%s -> %d  FSNP_GEMM_BN=%s FSNP_GEMM_PF=%s (tuning of the general GEMM kernel)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma, env("FSNP_GEMM_BN"), env("FSNP_GEMM_PF"));
+    add("  FSNP_GEMM_DMA=%s -> %d  FSNP_GEMM_BN=%s FSNP_GEMM_PF=%s (tuning of the general GEMM kernel)  FSNP_GEMM_SPLITK=%s (small-batch split-K GEMM up to this many workgroups per CU, default 6, 0 = never)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma, env("FSNP_GEMM_BN"), env("FSNP_GEMM_PF"), env("FSNP_GEMM_SPLITK"));
     add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
     add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, ping-pong %.1f / %.1f / %.1f / %.1f\n",
         h->cost.ksplit[0][0], h->cost.ksplit[1][0], h->cost.ksplit[2][0], h->cost.ksplit[3][0], h->cost.ksplit1[0], h->cost.ksplit1[1],
