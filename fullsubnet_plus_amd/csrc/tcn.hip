@@ -278,6 +278,57 @@ __global__ __launch_bounds__(256) void tcn_gemm_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- epilogues shared by tcn_gemm_dma_kernel and tcn_gemm_sk_kernel: per-plane scalars, one output element, the statistics tail
+struct EpiCtx { float slope, rstd, mr; };
+template <int EPI>
+__device__ __forceinline__ EpiCtx epi_ctx(const GemmArgs& g, int branch, int utt) {
+    EpiCtx e{0.f, 1.f, 0.f};
+    if constexpr (EPI == EPI_PRELU_STATS) e.slope = g.prelu[branch * g.prelu_bs];
+    if constexpr (EPI == EPI_RESIDUAL) {
+        const double* stt = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
+        const double m = stt[0] / g.gn_count;
+        const double var = stt[1] / g.gn_count - m * m;
+        const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
+        e.rstd = (float)rs;
+        e.mr = (float)(m * rs);
+    }
+    return e;
+}
+// acc = the k-sum of element (t, col); bias / c2 = the column's constants; s / q2 collect the GroupNorm statistics (EPI_PRELU_STATS)
+template <int EPI>
+__device__ __forceinline__ float epi_value(const GemmArgs& g, const EpiCtx& e, float acc, float bias, float c2, int branch, int utt, int t, int col,
+                                           double& s, double& q2) {
+    float v;
+    if constexpr (EPI == EPI_PRELU_STATS) {
+        v = acc + bias;
+        v = v >= 0.f ? v : e.slope * v;
+        s += (double)v;
+        q2 += (double)v * (double)v;
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+        v = e.rstd * acc + (bias - e.mr * c2);
+        v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
+        if (g.relu_out) v = fmaxf(v, 0.f);
+    } else {                                   // EPI_ACT: the final Linear (its operand was stored ReLU'd by the last sconv)
+        v = acc + bias;
+        if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+        else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
+    }
+    return v;
+}
+// one fp64 atomic pair per workgroup into the plane's {sum, sum of squares} slot
+__device__ __forceinline__ void epi_stats_finish(const GemmArgs& g, double s, double q2, double* red, int branch, int utt, int tid, int lane, int wave) {
+    s = wave_sum(s);
+    q2 = wave_sum(q2);
+    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
+    __syncthreads();
+    if (tid == 0) {
+        double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
+        atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
 // tcn_gemm_dma_kernel: the two GEMMs of a TCNBlock with the k-loop stripped to what the matrix pipe needs.
 // tcn_gemm_kernel above issues ~200 VALU/SALU instructions per 16 MFMAs (bounds checks, the GroupNorm prologue, the
 // fragment-order shuffle, LDS stores): on this chip they do not overlap a wave's fp32 MFMAs, so it ran at 45 % of the
@@ -392,16 +443,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5) ----
     float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
     double s = 0.0, q2 = 0.0;
-    float slope = 0.f, rstd = 1.f, mr = 0.f;
-    if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
-    if constexpr (EPI == EPI_RESIDUAL) {
-        const double* stt = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
-        const double m = stt[0] / g.gn_count;
-        const double var = stt[1] / g.gn_count - m * m;
-        const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
-        rstd = (float)rs;
-        mr = (float)(m * rs);
-    }
+    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + j * 32 + (lane & 31);
@@ -412,40 +454,11 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int t = t0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            if (t < g.Tp && col_ok) {
-                float v;
-                if constexpr (EPI == EPI_PRELU_STATS) {
-                    v = acc[j][q] + bias;
-                    v = v >= 0.f ? v : slope * v;
-                    s += (double)v;
-                    q2 += (double)v * (double)v;
-                } else if constexpr (EPI == EPI_RESIDUAL) {
-                    v = rstd * acc[j][q] + (bias - mr * c2);
-                    v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
-                    if (g.relu_out) v = fmaxf(v, 0.f);
-                } else {                                   // EPI_ACT: the final Linear (its operand was stored ReLU'd by the last sconv)
-                    v = acc[j][q] + bias;
-                    if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-                    else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
-                }
-                C[(long)t * g.ldc + col] = v;
-            } else if (t < g.Tp && col < g.ldc) {
-                C[(long)t * g.ldc + col] = 0.f;          // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
-            }
+            if (t < g.Tp && col_ok) C[(long)t * g.ldc + col] = epi_value<EPI>(g, ec, acc[j][q], bias, c2, branch, utt, t, col, s, q2);
+            else if (t < g.Tp && col < g.ldc) C[(long)t * g.ldc + col] = 0.f;      // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
         }
     }
-    if constexpr (EPI == EPI_PRELU_STATS) {
-        s = wave_sum(s);
-        q2 = wave_sum(q2);
-        if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
-        __syncthreads();
-        if (tid == 0) {
-            double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
-            atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
-            atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
-        }
-    }
+    if constexpr (EPI == EPI_PRELU_STATS) epi_stats_finish(g, s, q2, red, branch, utt, tid, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,16 +581,7 @@ __global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
     // ---- epilogue (as tcn_gemm_dma_kernel): C/D layout of 32x32: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
     float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
     double s = 0.0, q2 = 0.0;
-    float slope = 0.f, rstd = 1.f, mr = 0.f;
-    if constexpr (EPI == EPI_PRELU_STATS) slope = g.prelu[branch * g.prelu_bs];
-    if constexpr (EPI == EPI_RESIDUAL) {
-        const double* stt = g.gn_in + ((long)branch * g.B + utt) * kGnStride;
-        const double m = stt[0] / g.gn_count;
-        const double var = stt[1] / g.gn_count - m * m;
-        const double rs = 1.0 / sqrt((var > 0 ? var : 0) + (double)g.gn_eps);
-        rstd = (float)rs;
-        mr = (float)(m * rs);
-    }
+    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + j * 32 + (lane & 31);
@@ -588,40 +592,11 @@ __global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int t = t0 + qq + 8 * wave + 4 * (lane >> 5);
-            if (t < g.Tp && col_ok) {
-                float v;
-                if constexpr (EPI == EPI_PRELU_STATS) {
-                    v = sum[j][qq] + bias;
-                    v = v >= 0.f ? v : slope * v;
-                    s += (double)v;
-                    q2 += (double)v * (double)v;
-                } else if constexpr (EPI == EPI_RESIDUAL) {
-                    v = rstd * sum[j][qq] + (bias - mr * c2);
-                    v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
-                    if (g.relu_out) v = fmaxf(v, 0.f);
-                } else {
-                    v = sum[j][qq] + bias;
-                    if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-                    else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
-                }
-                C[(long)t * g.ldc + col] = v;
-            } else if (t < g.Tp && col < g.ldc) {
-                C[(long)t * g.ldc + col] = 0.f;          // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
-            }
+            if (t < g.Tp && col_ok) C[(long)t * g.ldc + col] = epi_value<EPI>(g, ec, sum[j][qq], bias, c2, branch, utt, t, col, s, q2);
+            else if (t < g.Tp && col < g.ldc) C[(long)t * g.ldc + col] = 0.f;      // pad columns [N, ldc)
         }
     }
-    if constexpr (EPI == EPI_PRELU_STATS) {
-        s = wave_sum(s);
-        q2 = wave_sum(q2);
-        if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q2; }
-        __syncthreads();
-        if (tid == 0) {
-            double* out = g.gn_out + ((long)branch * g.B + utt) * kGnStride;
-            atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
-            atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
-        }
-    }
+    if constexpr (EPI == EPI_PRELU_STATS) epi_stats_finish(g, s, q2, red, branch, utt, tid, lane, wave);
 }
 
 // true (and launched) when the DMA kernel's requirements hold
