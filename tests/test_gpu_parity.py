@@ -223,19 +223,21 @@ def _hp_only_costs():
     return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0]
 
 
-@pytest.mark.parametrize("n,steps,hidden", [(1, 1, 384), (16, 2, 384), (17, 3, 384), (32, 40, 384), (33, 5, 384), (257, 41, 384), (300, 7, 384),
-                                            (320, 128, 384), (500, 9, 384), (48, 300, 384), (257, 33, 256), (40, 2, 256)])
-def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden):
+@pytest.mark.parametrize("n,steps,hidden,fbn", [(1, 1, 384, 0), (16, 2, 384, 0), (17, 3, 384, 0), (32, 40, 384, 0), (33, 5, 384, 0), (257, 41, 384, 0),
+                                                (300, 7, 384, 0), (320, 128, 384, 0), (500, 9, 384, 0), (48, 300, 384, 0), (257, 33, 256, 0), (40, 2, 256, 0),
+                                                (257, 9, 384, 2), (40, 3, 256, 3)])
+def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden, fbn):
     """csrc/lstm_hp.hip: 16 hidden units per workgroup (24 workgroups per row tile, one XCD), the four waves split the GATES over
     the whole K (v_mfma_f32_16x16x4_f32, weights resident, no partial tiles to reduce), every row tile worked on as two half
     tiles of 16 sequences in turn (the hand-off of one half is in flight while the other computes), operands by LDS DMA, fused
     two-layer phase.  The 16x16x4 MFMA sums K in another order than the 32x32x2 kernels: same oracle tolerance as every other
-    recurrent kernel, bitwise repeatable; 1 ... 300 steps, ragged tiles (second half empty / one row), two launches (500)."""
-    args = {**DEFAULT_MODEL_ARGS, "sb_model_hidden_size": hidden}
-    sd = make_state_dict(3, "harsh", sb_hidden=hidden)
+    recurrent kernel, bitwise repeatable; 1 ... 300 steps, ragged tiles (second half empty / one row), two launches (500), sub-band
+    inputs of 46 / 52 features (fb_num_neighbors 2 / 3: the K = 64 instantiations)."""
+    args = {**DEFAULT_MODEL_ARGS, "sb_model_hidden_size": hidden, "fb_num_neighbors": fbn}
+    sd = make_state_dict(3, "harsh", sb_hidden=hidden, fb_num_neighbors=fbn)
     m = _model(args, sd)
     rng = np.random.Generator(np.random.PCG64(977 + n + steps))
-    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, 31 + 3 * (2 * fbn + 1), steps)).astype(np.float32)).cuda()
     m.lstm2_fc(x[:1])
     m.debug_set_lstm_coop(4)
     m.debug_set_costs(_hp_only_costs(), 1)
