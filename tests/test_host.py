@@ -297,6 +297,45 @@ def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
         assert l["scratch"] == 0 and l["acc_moves"] == 0 and l["ds_write"] == 0 and l["valu"] <= 12, (key, l)
 
 
+def test_half_tile_ping_pong_index_arithmetic():
+    """csrc/lstm_hp.hip, index arithmetic restated: (1) hp_a16 puts element (row, k) of a half-tile image where lane (k & 3) * 16 + row
+    of k-group k >> 4 reads component (k >> 2) & 3 - the A operand of v_mfma_f32_16x16x4_f32 number j = (k >> 2) & 3 of that group;
+    (2) a wave's accumulator (lane l, register i = row 4 (l >> 4) + i, column l & 15), stored as one float4 per lane, is read back by
+    the cell thread (wave = row quad, lane = (row & 3) * 16 + unit) at float (wave * 16 + unit) * 4 + (lane >> 4): all 256 threads
+    distinct, 64 distinct banks per wave; (3) the staged h slice lands in hp_a16 order of the workgroup's own k-group; (4) the Linear
+    partials are found where the summing workgroup looks for them."""
+    a16 = lambda row, k: ((((k >> 4) * 4) + (k & 3)) * 16 + row) * 4 + ((k >> 2) & 3)
+    seen = set()
+    for k in range(48):
+        for row in range(16):
+            idx = a16(row, k)
+            g, lane, j = idx // 256, (idx // 4) % 64, idx % 4
+            assert g == k >> 4 and lane == (k & 3) * 16 + row and j == (k >> 2) & 3
+            assert k == 16 * g + 4 * j + (lane >> 4)                 # = the k of the B fragment lstm_hp_pack_weights puts in (f = g, lane, j)
+            seen.add(idx)
+    assert seen == set(range(48 * 16))
+    read_idx = {}
+    for wave in range(4):
+        banks = set()
+        for lane in range(64):
+            cu, crow = lane & 15, 4 * wave + (lane >> 4)
+            gidx = (wave * 16 + cu) * 4 + (lane >> 4)
+            producer_lane, reg = (crow >> 2) * 16 + cu, crow & 3      # MFMA D layout: row 4 (l >> 4) + i, column l & 15
+            assert gidx == producer_lane * 4 + reg
+            read_idx[(crow, cu)] = gidx
+            banks.add(gidx % 64)
+            sdst = ((cu & 3) * 16 + crow) * 4 + (cu >> 2)
+            assert sdst == a16(crow, cu)                              # k-group 0 of the staging image = the workgroup's 16 units
+        assert len(banks) == 64
+    assert sorted(read_idx.values()) == list(range(256))
+    S = 24
+    for cs in range(16):                                              # summing workgroup cs (row cs): lane tid < 2 S reads partial (cs', o)
+        for tid in range(2 * S):
+            csp, o = tid % S, tid // S
+            voff = csp * 128 + (o * 16 + cs) * 4
+            assert voff == csp * 128 + 4 * (o * 16 + cs) and voff // 128 == csp and (voff % 128) // 4 == o * 16 + cs   # stage[512 + o * 16 + row]
+
+
 def test_splitk_gemm_has_no_barrier_in_its_k_loop():
     """tcn_gemm_sk_kernel (csrc/tcn.hip, small batches): a wave multiplies ITS k-tiles out of a private double buffer - 16 MFMAs per
     k-tile, 6 + 6 DMA pieces, no scratch, no workgroup barrier between the first and the last MFMA."""
