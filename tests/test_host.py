@@ -347,6 +347,14 @@ def test_splitk_gemm_has_no_barrier_in_its_k_loop():
     assert len(res) == 3, sorted(res)
     for key, l in res.items():
         assert l["mfma"] == 16 and l["dma"] == 12 and l["scratch"] == 0 and l["barriers_between_mfmas"] == 0, (key, l)
+    # after the partial tiles are added, wave w finishes accumulator registers q in [4 w, 4 w + 4): with the 32x32 C/D layout
+    # (row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)) that is rows t0 + qq + 8 w + 4 (lane >> 5) - every row of the tile exactly once
+    rows = sorted((q & 3) + 8 * (q >> 2) + 4 * half for w in range(4) for q in range(4 * w, 4 * w + 4) for half in (0, 1))
+    assert rows == list(range(32))
+    assert all((q & 3) + 8 * (q >> 2) == (q - 4 * w) + 8 * w for w in range(4) for q in range(4 * w, 4 * w + 4))
+    # k-tiles w, w + 4, ... of the four waves partition [0, ktiles) for the two GEMM shapes (K = 257 -> 17 tiles, K = 512 -> 32)
+    for ktiles in (17, 32, 1, 3):
+        assert sorted(kt for w in range(4) for kt in range(w, ktiles, 4)) == list(range(ktiles))
 
 
 def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
