@@ -298,10 +298,12 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         for (; k < k1; ++k) a0 += wT[(long)k * stride] * x[k];
         return (a0 + a1) + (a2 + a3);
     };
-    float* part = edge;                                      // [slices][Fr] partial sums (the staged edge frames are no longer needed;
-    float* part2 = edge + 256;                               //  CBAM keeps its max vector in edge[0, FP): its partials sit behind it)
-    if (att == FSNP_ATT_CBAM) { part = edge + FP; part2 = edge + FP + 256; }
-    const int ns1 = Fr >= 256 ? 1 : 256 / Fr, chunk = cdiv(F, ns1);
+    // [slices][Fr] partial sums in `edge` (the staged edge frames are no longer needed; CBAM keeps its max vector in edge[0, FP): its
+    // partials sit behind it).  part2 follows part's ns1 * Fr floats (a fixed + 256 aliased them from num_freqs = 514 up); the
+    // slice count is capped so that FP + 2 ns1 Fr floats always fit edge's 32 FP (tiny num_freqs)
+    const int ns1 = Fr >= 256 ? 1 : min(256 / Fr, (31 * FP) / (2 * Fr)), chunk = cdiv(F, ns1);
+    float* part = att == FSNP_ATT_CBAM ? edge + FP : edge;
+    float* part2 = part + ns1 * Fr;
     __syncthreads();                                         // every thread is done with `edge`
     for (int item = tid; item < Fr * ns1; item += 256) {
         const int o = item % Fr, sl = item / Fr;
@@ -411,6 +413,10 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
     GateArgs g;
     g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;
     g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
+    // 34 FP floats of dynamic LDS: beyond 64 KiB (num_freqs > 480) the kernel needs the opt-in; beyond a CU's LDS the launch fails
+    // loudly (hipGetLastError in fsnp_forward)
+    static PerDeviceOnce gate_once;
+    gate_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fe_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
     hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(256), (size_t)(2 + 2 * 16) * d.FP * sizeof(float), s, g);
     const long rows = 3L * d.B * d.Tp;
     const long total = rows * d.FP;

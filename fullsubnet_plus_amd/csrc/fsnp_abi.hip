@@ -168,7 +168,20 @@ static void launch_coop_chained(int dev, hipStream_t s, F launch) {
 
 // The planner itself (cost table, launch shapes, shortest path over tile counts) is host-only code: planner.h / planner.cpp.
 static PlannerCtx pctx(const fsnp_handle* h);
-static SbPlan plan_sb(const fsnp_handle* h, int num_rows) { return plan_sb(pctx(h), num_rows); }
+// gather_bytes: the furthest byte a recurrent kernel's input gather reaches from its base pointer.  The half-tile ping-pong kernel
+// (lstm_hp.hip) addresses its input through ONE buffer descriptor with 32-bit BYTE offsets (2 GiB), the other kernels with 32-bit
+// FLOAT offsets from a 64-bit pointer (8 GiB): beyond 2 GiB the planner is told not to use it (its loads would
+// otherwise return zeros - out of the descriptor's range - and the sequences run on zero input without any error).
+static SbPlan plan_sb(const fsnp_handle* h, int num_rows, double gather_bytes = 0.0) {
+    PlannerCtx c = pctx(h);
+    if (gather_bytes >= 2147483644.0) c.coop_hp = 0;
+    return plan_sb(c, num_rows);
+}
+// forward: rows are gathered from att_mag [B][Tp][FP] and the full-band planes behind it (plan_workspace: att, fb adjacent)
+static double forward_gather_bytes(const fsnp_handle* h, int B, int T) {
+    const double nbr = h->model == FSNP_MODEL_FULLSUBNET ? 1 : 3;
+    return 2.0 * ((double)align_up((size_t)(nbr * B * ((double)T + h->cfg.look_ahead) * h->FP * 4), 256));
+}
 static int chunk_workgroups(const fsnp_handle* h, const SbChunk& c) { return chunk_workgroups(pctx(h), c); }
 // Launches chunks [first, last) of the plan on stream s.  `bar` = per-tile arrival counters followed (at bar +
 // plan.coop_tiles, 64-byte aligned by the caller) by the launch-abort word.
@@ -197,6 +210,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_bar_stride = kCoopCounterStride;
         ca.coop_bar2 = nullptr;
         ca.coop_skew = h->coop_skew;
+        ca.coop_chaos = h->coop_chaos;
         ca.coop_split = c.kind == 1 && c.rpg ? 1 : 0;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
@@ -260,7 +274,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.gate = take(fsn ? 0 : (size_t)3 * B * h->FP * 4);
     w.md = take(nbr * B * Tp * sizeof(NormMD));
     w.md_utt = take((size_t)B * sizeof(NormMD));
-    const SbPlan plan = plan_sb(h, B * rows_per_utt(h, mode));
+    const SbPlan plan = plan_sb(h, B * rows_per_utt(h, mode), forward_gather_bytes(h, B, T));
     const size_t nrows_pad = (size_t)plan.total_slots;
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
     w.md_row = take(cumulative ? nrows_pad * Tp * sizeof(NormMD) : 0);
@@ -740,7 +754,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     FSNP_ON_DEVICE(h);
     if (calibrate_costs(h)) return 4;            // first planning call of the process for this kind of handle only (~0.1 s)
     const int num_rows = batch * rows_per_utt(h, mode);
-    const SbPlan plan = plan_sb(h, num_rows);
+    const SbPlan plan = plan_sb(h, num_rows, forward_gather_bytes(h, batch, frames));
     if (plan.chunks.empty()) {
         set_error("no kernel plan for %d sub-band sequences on this device (%d CUs): the %s sub-band model needs at least %d",
                   num_rows, h->num_cus_real, h->gru ? "GRU" : "LSTM", h->H / 128);
@@ -824,7 +838,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fa.num_rows = batch; fa.num_tiles = fb_tiles; fa.Tp = d.Tp; fa.LA = 0; fa.FP = d.FP; fa.F = d.F;
         fa.coop_hx = fptr(w.fb_hx); fa.coop_bar = reinterpret_cast<unsigned*>(base + w.fb_bar); fa.coop_err = h->d_err;
         fa.coop_abort = reinterpret_cast<unsigned*>(base + w.coop_abort) + 16;
-        fa.coop_units = fb_units;
+        fa.coop_units = fb_units; fa.coop_chaos = h->coop_chaos;
         const int chp = (int)align_up(d.CH, 4);           // row stride of the h1 sequence (a float4 multiple; pad columns written as zeros)
         fa.seq_stride = chp;
         if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
@@ -938,6 +952,7 @@ int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t 
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     FSNP_ON_DEVICE(h);
     if (order_after_last_forward(h, s)) return 4;
+    if (calibrate_costs(h)) return 4;            // FSNP_CALIBRATE=1: size the workspace for the plans the ADOPTED cost table will make
     // every batch size up to max_batch plans its own launches (the exchange region of a column-split plan can exceed the one of
     // the chip-filling batch): take the largest workspace over all of them - host arithmetic only
     size_t need = 0;
@@ -976,7 +991,7 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     FSNP_ON_DEVICE(h);
     if ((double)num_seq * steps * h->NIN > 2.0e9) { set_error("fsnp_lstm2_fc: input too large for 32-bit offsets"); return 2; }
     if (calibrate_costs(h)) return 4;
-    const SbPlan plan = plan_sb(h, num_seq);
+    const SbPlan plan = plan_sb(h, num_seq, (double)num_seq * steps * h->NIN * 4.0);
     if (plan.chunks.empty()) { set_error("fsnp_lstm2_fc: no kernel plan for %d sequences on this device", num_seq); return 2; }
     return run_dense_plan(h, plan, x, out, num_seq, steps, s);
 }
@@ -1329,6 +1344,12 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
 int fsnp_debug_inject_error(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
     *reinterpret_cast<volatile unsigned*>(h->d_err) = 1u;
+    return 0;
+}
+
+int fsnp_debug_set_chaos(fsnp_handle* h, int32_t seed) {
+    if (!h) { set_error("null handle"); return 1; }
+    h->coop_chaos = seed;
     return 0;
 }
 

@@ -208,6 +208,8 @@ struct LstmArgs {
                                // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
     int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2; lstm_pp.hip: 1..4 row tiles per group
+    int coop_chaos;            // test hook (fsnp_debug_set_chaos): != 0 = seed of pseudo-random, workgroup-uniform delays at the phase boundaries
+                               // of the column-split kernels, so that the workgroups of a launch drift apart instead of running in lockstep
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
@@ -250,6 +252,7 @@ void launch_lstm_generic(const LstmWeights& w, const LstmArgs& a, bool seq, hipS
 size_t lstm_generic_pack_floats(int H, int NIN);
 void lstm_generic_pack_weights(int H, int NIN, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 int lstm_generic_rows_per_group(int H, int NIN, int num_seq, int num_cus);   // 0 = the sizes do not fit a CU's LDS
+int lstm_generic_check(int H, int NIN, bool seq);   // commit time: LDS opt-in + residency of every instantiation; != 0 (error set) on failure
 // lstm_coopn.hip: 3 workgroups x 128 hidden units share 1-2 row tiles (43..170 row tiles)
 void launch_lstm_coopn(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm_coopn_pack_floats(int H, int KX);

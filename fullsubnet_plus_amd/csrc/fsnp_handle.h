@@ -101,6 +101,7 @@ struct fsnp_handle {
     int num_cus_real = 256;   // never overridden: residency of the cooperative kernel depends on the real chip
     int ih_bf16 = 0;             // 1 = BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
+    int coop_chaos = 0;          // fsnp_debug_set_chaos: drift injection seed for the column-split kernels (0 = off)
     int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
     int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
     bool generic_sb = false;     // the sub-band recurrent model runs on the runtime-sized kernel (lstm_generic.hip): a hidden size or an

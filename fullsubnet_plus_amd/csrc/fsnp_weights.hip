@@ -420,6 +420,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
         for (int ui = 0; ui < 4; ++ui) h->occ_ksplit[ui] = std::max(1, lstm_coop_occupancy(h->lw, 8 << ui));
         for (int rpg = 1; rpg <= 2; ++rpg) h->occ_coopn[rpg - 1] = std::max(1, lstm_coopn_occupancy(h->lw, rpg));
     }
+    if (h->generic_sb && lstm_generic_check(h->H, h->NIN, false)) return 2;
+    if (h->generic_fb && lstm_generic_check(h->CH, h->F, true)) return 2;
     h->committed = true;
     (void)Fr;
     return 0;

@@ -138,4 +138,21 @@ __device__ __forceinline__ bool xchg_wait(const unsigned* bar, unsigned target, 
     return true;
 }
 
+// ---- drift injection (LstmArgs::coop_chaos, fsnp_debug_set_chaos).  On an otherwise idle chip the workgroups of a column-split
+// launch run in near lockstep, so a hand-off whose correctness silently depends on that lockstep (a buffer overwritten while a
+// slow peer still reads it, a counter target off by one phase) passes every short test and shows only when workgroups drift -
+// clocks ramping after an idle period, a neighbour kernel, thousands of steps.  With a seed set, every workgroup sleeps a
+// pseudo-random time (hash of seed, workgroup, step, phase; uniform per workgroup) at each phase boundary: nothing on 7 of 8
+// boundaries, 3 ... 24 us otherwise, ~200 us once in 1024 - drifts of many whole steps.  Results must not change by one bit
+// (tests/test_gpu_parity.py::test_column_split_kernels_under_drift).
+__device__ __forceinline__ void chaos_delay(int seed, int t, int phase) {
+    if (seed == 0) return;
+    unsigned h = (unsigned)seed * 2654435761u ^ (unsigned)blockIdx.x * 40503u ^ (unsigned)t * 2246822519u ^ (unsigned)phase * 3266489917u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    int n = 0;
+    if ((h & 7u) == 0) n = 1 + (int)((h >> 3) & 7u);
+    if ((h & 1023u) == 1u) n = 64;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles ~ 3.4 us
+}
+
 }  // namespace fsnp

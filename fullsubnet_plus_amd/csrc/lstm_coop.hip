@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
 
     for (int t = 0; t < Tp; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
+        chaos_delay(a.coop_chaos, t, 0);
         // prefetch x(t+1)
         float xr[NG];
         NormMD mdn = md;
@@ -379,7 +380,9 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = x_valid(i) ? (xr[i] - mdn.m) / mdn.d : 0.0f;
         }
+        chaos_delay(a.coop_chaos, t, 1);
         if (!inter_wg_barrier((unsigned)S * (unsigned)(t + 1))) return;   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
+        chaos_delay(a.coop_chaos, t, 2);
 
         if constexpr (!SEQ) { if (t > 0) fc_epilogue(t - 1); }
 
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
     // A_t; with_c: C_{t-1} follows - its b1 wait and the prefill of its first operand groups happen in here, between the
     // stores of h0_t and the drain + arrival, so that their round trips overlap.  Returns false once the launch is aborted.
     auto phase_a = [&](int t, int m3, int pm3, bool with_c) -> bool {
+        chaos_delay(a.coop_chaos, t, 0);
         float xr[NG];
         NormMD mdn = md;
         const bool have_next = t + 1 < Tp;
@@ -694,12 +698,14 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
                                                           [&](int i) -> float4 { return hload(h0c, i); });
             }
         }
+        chaos_delay(a.coop_chaos, t, 1);
         arrive(bar0);
         return true;
     };
     // C_t: layer 1 of step t over [h1_{t-1} | h0_t]
     auto phase_c = [&](int t, int m3, bool prefilled) {
         const int cur = t & 1, prv = cur ^ 1;
+        chaos_delay(a.coop_chaos, t, 2);
         f32x16 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
                 xchg_store(part + 32 + prow[i], p1);
             }
         });
+        chaos_delay(a.coop_chaos, t, 3);
         arrive(bar1);
     };
 
@@ -920,6 +927,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, Ls
         __syncthreads();
         int m3 = 0, pm3 = 2;                               // t % 3, (t - 1) % 3; h0_{-1} = the (zeroed) third image
         for (int t = 0; t < Tp; ++t) {
+            chaos_delay(a.coop_chaos, t, 0);
             float xr[NG];
             NormMD mdn = md;
             const bool have_next = t + 1 < Tp;
@@ -946,6 +954,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, Ls
 #pragma unroll
                 for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
             }
+            chaos_delay(a.coop_chaos, t, 1);
             arrive(bar0);
             pm3 = m3;
             m3 = m3 == 2 ? 0 : m3 + 1;
@@ -979,6 +988,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, Ls
     int m3 = 0;
     for (int t = 0; t < Tp; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
+        chaos_delay(a.coop_chaos, t, 2);
         if (!wait_both((unsigned)S * (unsigned)(t + 1), (unsigned)S * (unsigned)t)) return;     // h0_t; h1_{t-1} + partials of t-1
         if (t > 0) fc_epilogue(t - 1);
         f32x16 acc[NT];
@@ -1003,6 +1013,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, Ls
                 xchg_store(part + 32 + prow[i], p1);
             }
         });
+        chaos_delay(a.coop_chaos, t, 3);
         arrive(bar1);
         m3 = m3 == 2 ? 0 : m3 + 1;
     }

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
     for (int t = 0; t < Tp; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         const bool have_next = t + 1 < Tp;
+        chaos_delay(a.coop_chaos, t, 0);
         // ---------------- layer 0 of every row tile: [x_t | h0_{t-1}] ----------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
                 for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[r][i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
             }
         }
+        chaos_delay(a.coop_chaos, t, 1);
         if (!inter_wg_barrier((unsigned)S * (unsigned)(t + 1))) return;   // h0_t, h1_{t-1} and the FC partials of step t-1 are now visible
+        chaos_delay(a.coop_chaos, t, 2);
 
         // ---------------- layer 1 of every row tile: [h1_{t-1} | h0_t] ----------------
 #pragma unroll

@@ -203,20 +203,55 @@ int lstm_generic_rows_per_group(int H, int NIN, int num_seq, int num_cus) {
     return gen_smem_floats(rg, H, NIN) * 4 <= (size_t)150 * 1024 ? rg : 0;
 }
 
+// LDS opt-in of one instantiation (per device) + a residency check: 1024 threads with `smem` bytes of dynamic LDS must fit a CU.
+// Returns hipSuccess, or the error of the attribute call / hipErrorLaunchOutOfResources when no workgroup fits.
+template <int RG, bool SEQ>
+static hipError_t generic_prepare(size_t smem) {
+    auto k = lstm2_generic_kernel<RG, SEQ>;
+    static PerDeviceOnce once;
+    static hipError_t attr_err = hipSuccess;
+    once.run([&] { attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
+    if (attr_err != hipSuccess) return attr_err;
+    if (smem == 0) return hipSuccess;
+    int blocks = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(k), kGenThreads, smem);
+    if (e != hipSuccess) return e;
+    return blocks >= 1 ? hipSuccess : hipErrorLaunchOutOfResources;
+}
+
 template <int RG>
 static void launch_generic_rg(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s) {
     const size_t smem = gen_smem_floats(RG, w.H, w.NIN) * 4;
     if (seq) {
-        auto k = lstm2_generic_kernel<RG, true>;
-        static PerDeviceOnce once;
-        once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
-        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
+        (void)generic_prepare<RG, true>(0);
+        hipLaunchKernelGGL((lstm2_generic_kernel<RG, true>), dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     } else {
-        auto k = lstm2_generic_kernel<RG, false>;
-        static PerDeviceOnce once;
-        once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
-        hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
+        (void)generic_prepare<RG, false>(0);
+        hipLaunchKernelGGL((lstm2_generic_kernel<RG, false>), dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     }
+}
+
+// Commit-time check (fsnp_commit_weights): every instantiation a plan may launch for these sizes gets its LDS opt-in and must be
+// resident with its real LDS size; a failure is reported THERE with a clear message instead of surfacing as an asynchronous launch error.
+int lstm_generic_check(int H, int NIN, bool seq) {
+    hipError_t e = hipSuccess;
+    auto one = [&](int rg) -> hipError_t {
+        const size_t smem = gen_smem_floats(rg, H, NIN) * 4;
+        if (smem > (size_t)150 * 1024) return hipSuccess;           // never planned (lstm_generic_rows_per_group)
+        switch (rg) {
+            case 8: return seq ? generic_prepare<8, true>(smem) : generic_prepare<8, false>(smem);
+            case 4: return seq ? generic_prepare<4, true>(smem) : generic_prepare<4, false>(smem);
+            case 2: return seq ? generic_prepare<2, true>(smem) : generic_prepare<2, false>(smem);
+            default: return seq ? generic_prepare<1, true>(smem) : generic_prepare<1, false>(smem);
+        }
+    };
+    for (int rg = 1; rg <= 8 && e == hipSuccess; rg *= 2) e = one(rg);
+    if (e != hipSuccess) {
+        set_error("runtime-sized recurrent kernel (hidden %d, %d inputs): a 1024-thread workgroup with its LDS does not fit a CU of this device: %s",
+                  H, NIN, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
 }
 
 // a.num_tiles workgroups of a.coop_rows_per_group (1, 2, 4 or 8) sequences each; a.rows holds num_tiles * rows-per-group slots

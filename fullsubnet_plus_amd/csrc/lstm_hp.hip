@@ -316,6 +316,7 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
                 else fetch(std::integral_constant<int, 0>{}, nt);
             };
             FSNP_HP_STAMP(0);
+            chaos_delay(a.coop_chaos, t, hf);
             // ---- operands of this half-phase are in LDS once every DMA wave has drained its queue
             if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -407,6 +408,7 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
                     if (goff[hf][i] >= 0) Xf[hf * GX * 256 + xdst0 + i * 256] = (xr[i] - mdn.m) / mdn.d;
             }
             if (fc_now) fc_finish(hf, t - 1);
+            chaos_delay(a.coop_chaos, t, 2 + hf);
             FSNP_HP_STAMP(6);
             if (!two) {                           // one half only: the next wait is for this very half - publish and arrive now
                 __syncthreads();

@@ -23,6 +23,20 @@ from . import _lib
 
 _TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
 
+# Generation counter of the process's module trees: bumped whenever ANY module registers a parameter or a submodule
+# (torch's global registration hooks fire for `module.p = nn.Parameter(...)`, load_state_dict(assign=True), add_module,
+# replacing a submodule, parametrize).  _HipModel._weights_key re-walks its tree when the counter has moved since it cached its
+# parameter list, so a swapped Parameter OBJECT can never leave the handle on the previous checkpoint's weights.
+_TREE_GENERATION = [0]
+
+
+def _bump_tree_generation(*_args, **_kwargs):
+    _TREE_GENERATION[0] += 1
+
+
+nn.modules.module.register_module_parameter_registration_hook(_bump_tree_generation)
+nn.modules.module.register_module_module_registration_hook(_bump_tree_generation)
+
 
 class _TSSEParams(nn.Module):
     """Parameter holder named like ChannelTimeSenseSELayer (attention_model.py:49-76)."""
@@ -166,12 +180,17 @@ class _HipModel(nn.Module):
     def _weights_key(self):
         # (storage pointer, version) of every parameter: changes on load_state_dict, .to(), in-place updates.  The parameter
         # LIST is cached - walking the module tree (340 parameters) was 0.56 ms per forward, a quarter of a B = 1 step - and
-        # rebuilt whenever _apply (.to / .float / .cuda ...) may have replaced Parameter objects.
-        plist = self.__dict__.get("_fsnp_plist")
-        if plist is None:
-            plist = list(self.parameters())
-            self.__dict__["_fsnp_plist"] = plist
-        return tuple([(p.data_ptr(), p._version) for p in plist])
+        # rebuilt whenever Parameter OBJECTS may have been replaced: _apply (.to / .float / .cuda ...), and any parameter /
+        # submodule registration anywhere in the process since the list was cached (_TREE_GENERATION: assigning a new
+        # nn.Parameter to a submodule attribute, load_state_dict(assign=True), replacing a submodule, parametrize).  Deleting
+        # a parameter fires no hook: every 256th call re-walks the tree regardless.
+        cached = self.__dict__.get("_fsnp_plist")
+        calls = self.__dict__.get("_fsnp_plist_calls", 0) + 1
+        self.__dict__["_fsnp_plist_calls"] = calls
+        if cached is None or cached[0] != _TREE_GENERATION[0] or calls % 256 == 0:
+            cached = (_TREE_GENERATION[0], list(self.parameters()))
+            self.__dict__["_fsnp_plist"] = cached
+        return tuple([(p.data_ptr(), p._version) for p in cached[1]])
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_fsnp_plist", None)
@@ -462,6 +481,11 @@ class _HipModel(nn.Module):
         assert mode in ("fp32", "bf16_ih", "bf16x3")
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_set_precision(self._handle, {"fp32": 0, "bf16_ih": 1, "bf16x3": 2}[mode]), "fsnp_set_precision")
+
+    def debug_set_chaos(self, seed, device="cuda"):
+        """Test hook: drift injection for the column-split recurrent kernels (fsnp_debug_set_chaos); 0 = off."""
+        lib = self._ensure_handle(_resolve_device(device))
+        _lib.check(lib.fsnp_debug_set_chaos(self._handle, int(seed)), "fsnp_debug_set_chaos")
 
     def debug_inject_error(self):
         """Test hook: pretend an inter-workgroup wait timed out (see fsnp_debug_inject_error)."""

@@ -338,6 +338,12 @@ int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode);
  * fsnp_check_errors on the handle must then fail, once). */
 int fsnp_debug_inject_error(fsnp_handle* h);
 
+/* Test hook (round 4): drift injection for the column-split recurrent kernels.  seed != 0: every workgroup of such a launch
+ * sleeps a pseudo-random, workgroup-uniform time (nothing on 7 of 8 phase boundaries, 3 ... 24 us otherwise, ~200 us once in
+ * 1024) so that the workgroups that share a row tile drift apart by whole steps instead of running in the lockstep an idle
+ * chip gives them; results must stay bit-identical (csrc/lstm_common.h: chaos_delay).  0 = off (default). */
+int fsnp_debug_set_chaos(fsnp_handle* h, int32_t seed);
+
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
  * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the
  * environment variable FSNP_LSTM_WAVES at fsnp_create time. */

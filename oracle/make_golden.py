@@ -111,6 +111,10 @@ CASES = [
     dict(name="b1_t20_fbn6", wseed=37, profile="default", args={"fb_num_neighbors": 6}, inp=("spec", 1, 20, 38), stages=False),
     dict(name="gru_b3_t16_h190", wseed=38, profile="default", args={"sb_model_hidden_size": 190, "sequence_model": "GRU"},
          inp=("spec", 3, 16, 39), stages=False),
+    # CBAM with more than 512 bins: fc1's K is no longer sliced (F / 2 > 256) - the two partial-sum vectors of fe_gate_kernel
+    # (mean and max squeeze) must not alias
+    dict(name="b1_t16_cbam_f521", wseed=40, profile="harsh", args={"channel_attention_model": "CBAM", "num_freqs": 521},
+         inp=("spec", 1, 16, 41), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]

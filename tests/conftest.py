@@ -12,7 +12,38 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+# Order of the GPU suite (round 4): the driver runs `pytest -m gpu -x`, so whatever sits behind a failure is never seen.  Boundary
+# and configuration-level tests (BASELINE.json configs, the C ABI, STFT path, multi-rank) first, kernel sweeps in the middle, the
+# long soaks last.  Within a class the definition order is kept.
+_FIRST = ("test_forward_from_plain_c", "test_c_abi_argument_errors_are_loud", "test_forward_vs_reference_golden",
+          "test_fullsubnet_forward_vs_reference_golden", "test_stages_vs_reference",
+          "test_b32_full_vs_oracle", "test_b32_parity_vs_oracle_and_subselection", "test_b32_10s_full_vs_oracle",
+          "test_b32_10s_cumulative_norms_vs_oracle", "test_bf16_ih_forward_b32", "test_b32_batch_independence",
+          "test_forward_complex_equals_three_plane_forward", "test_stft_istft_vs_torch", "test_enhance_wave_vs_oracle",
+          "test_enhance_epilogue_vs_oracle", "test_fullsubnet_batch_vs_oracle", "test_fullsubnet_enhance_wave_vs_oracle",
+          "test_forward_sharded_two_ranks_equals_single_process", "test_forward_sharded_over_rccl_world_size_1",
+          "test_bench_under_torchrun_initialises_rccl_at_world_size_1", "test_sharded_parity_mode_on_one_gpu")
+_LAST = ("test_column_split_exchange_under_load", "test_column_split_kernels_under_drift", "test_long_recurrence_kernels",
+         "test_long_recurrence_forward")
+
+
+def _gpu_rank(item):
+    name = item.originalname if hasattr(item, "originalname") and item.originalname else item.name.split("[")[0]
+    if name in _FIRST:
+        return (0, _FIRST.index(name))
+    if name in _LAST:
+        return (2, _LAST.index(name))
+    return (1, 0)
+
+
 def pytest_collection_modifyitems(config, items):
+    gpu = [it for it in items if "gpu" in it.keywords]
+    if gpu:
+        order = {id(it): k for k, it in enumerate(items)}
+        gpu_sorted = sorted(gpu, key=lambda it: (_gpu_rank(it), order[id(it)]))
+        slots = [k for k, it in enumerate(items) if "gpu" in it.keywords]
+        for k, it in zip(slots, gpu_sorted):
+            items[k] = it
     try:
         import torch
         has_gpu = torch.cuda.is_available()

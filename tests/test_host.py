@@ -73,6 +73,40 @@ def test_module_has_reference_parameter_tree_and_strict_load():
     assert m2._hip is not m._hip
 
 
+def test_weights_key_sees_every_way_of_replacing_a_parameter():
+    """The handle re-packs its device weights when _weights_key changes.  The key walks a CACHED parameter list, so every way of
+    swapping Parameter objects must drop that cache - not only .to() / _apply: load_state_dict(assign=True), assigning a new
+    nn.Parameter to a submodule attribute, replacing a submodule (the forward would otherwise silently keep the
+    previous checkpoint's weights), in-place updates, and - every 256th call - a deleted parameter."""
+    import torch.nn as nn
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    keys = [m._weights_key()]
+    assert m._weights_key() == keys[0]
+
+    def changed():
+        k = m._weights_key()
+        assert k not in keys
+        keys.append(k)
+        assert m._weights_key() == k                     # stable again
+
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
+    changed()
+    m.sb_model.fc_output_layer.weight = nn.Parameter(torch.zeros_like(m.sb_model.fc_output_layer.weight))
+    changed()
+    m.sb_model.fc_output_layer = nn.Linear(384, 2)
+    changed()
+    with torch.no_grad():
+        m.fb_model.fc_output_layer.bias.add_(1.0)          # in place: same object, version bumped
+    changed()
+    m.double()
+    changed()
+    del m.sb_model.fc_output_layer.bias                   # no registration hook fires for a deletion ...
+    n_before = len(m._weights_key())
+    for _ in range(256):
+        k = m._weights_key()                              # ... the periodic full walk catches it
+    assert len(k) == n_before - 1
+
+
 def test_subband_num_follows_the_reference():
     """fullsubnet_plus.py:47-50,146-163: subband_num > 1 only runs with ECA in the reference (its other attention layers are
     sized num_freqs // subband_num + 1 but the real / imag branches feed them num_freqs); the HIP model accepts exactly that."""
