@@ -105,7 +105,7 @@ static int run_graphed(fsnp_handle* h, const GraphKey& key, hipStream_t s, F mid
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
 // base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
 __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
-                                  int batch_offset, int global_batch, int dense_out, int n_base, int groups) {
+                                  int batch_offset, int global_batch, int dense_out, int n_base, int groups, int OC) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= num_tiles * rt) return;
     const int tile = slot / rt, sl = slot % rt;
@@ -115,11 +115,11 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
     RowDesc r{0, 0, 0, 0};
     if (sl < cnt) {
         r.valid = 1;
-        if (dense_out) {               // fsnp_lstm2_fc: x[n][t][:] -> out[n][o][t]
-            r.b = n; r.f = 0; r.out_off = n * 2 * T;
+        if (dense_out) {               // fsnp_lstm2_fc: x[n][t][:] -> out[n][o][t], o < OC = output_size (fullsubnet_plus.py:104,206)
+            r.b = n; r.f = 0; r.out_off = n * OC * T;
         } else if (mode == FSNP_MODE_FULL) {
             r.b = n / F; r.f = n % F;
-            r.out_off = ((r.b * 2) * F + r.f) * T;
+            r.out_off = ((r.b * OC) * F + r.f) * T;
         } else {                       // drop_band (feature.py:254-285) with G = num_groups_in_drop_band groups:
             // global sample s keeps bins p + G i (p = s % G, i < (F - F % G) / G); output rows = group 0's samples, group 1's, ...
             const int G = groups, Fh = F / G;
@@ -129,7 +129,7 @@ __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, in
             int orow = s / G;
             for (int q = 0; q < p; ++q) orow += (global_batch - q + G - 1) / G;     // samples of the groups in front
             r.f = p + G * i;
-            r.out_off = ((orow * 2) * Fh + i) * T;
+            r.out_off = ((orow * OC) * Fh + i) * T;
         }
     }
     rows[slot] = r;
@@ -238,11 +238,11 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
     if (after_first && last_chunk == nchunks) (void)hipEventRecord(after_first, s);
 }
 static void launch_build_rows(const SbPlan& plan, RowDesc* rows, int F, int T, int mode, int batch_offset, int global_batch,
-                              int dense_out, int groups, hipStream_t s) {
+                              int dense_out, int groups, int out_channels, hipStream_t s) {
     for (const SbChunk& c : plan.chunks) {
         const int slots = c.num_tiles * c.rps;
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, s, rows + c.slot0, c.nrows, c.num_tiles, c.rps,
-                           F, T, mode, batch_offset, global_batch, dense_out, c.row0, groups);
+                           F, T, mode, batch_offset, global_batch, dense_out, c.row0, groups, out_channels);
     }
 }
 // full-band LSTM of the original FullSubNet: B sequences, always the cooperative kernel (units in {8, 16, 32})
@@ -395,7 +395,7 @@ static int run_dense_plan(fsnp_handle* h, const SbPlan& plan, const float* x, fl
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     h->have_last = false;   // the workspace no longer holds a forward's stages
     if (coop) FSNP_HIP_CHECK(hipMemsetAsync(h->ws + coop_off, 0, coop_bytes, s));
-    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, s);
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, h->cfg.output_size, s);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;
@@ -566,7 +566,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (cfg->look_ahead < 0) { set_error("look_ahead must be >= 0"); return 2; }
     if (cfg->sb_num_neighbors < 0 || cfg->fb_num_neighbors < 0) { set_error("sb_num_neighbors / fb_num_neighbors must be >= 0"); return 2; }
     if (cfg->num_groups_in_drop_band < 1) { set_error("num_groups_in_drop_band must be >= 1"); return 2; }
-    if (cfg->output_size != 2) { set_error("output_size must be 2"); return 2; }
+    // output_size is a constructor argument of the reference (fullsubnet_plus.py:30,104,206: the sub-band model's Linear(H, output_size)
+    // and the final reshape); every configuration file uses 2 (the cIRM) and the tuned kernels fuse exactly that Linear(H, 2).  Other
+    // values run the sub-band recurrence on the runtime-sized kernel (lstm_generic.hip: OUT is a run-time argument there).
+    if (cfg->output_size < 1 || cfg->output_size > 64) { set_error("output_size must be in [1, 64]"); return 2; }
+    if (cfg->model == FSNP_MODEL_FULLSUBNET && cfg->output_size != 2) { set_error("FullSubNet has no output_size argument (fullsubnet.py:13-26): 2"); return 2; }
     if (cfg->sb_hidden < 1 && cfg->sequence_model != FSNP_SEQ_TCN) { set_error("sb_model_hidden_size must be >= 1"); return 2; }
     if (cfg->num_tcn_blocks < 0 || cfg->num_tcn_blocks > 8) { set_error("num_tcn_blocks must be in [0,8]"); return 2; }
     if (cfg->model != FSNP_MODEL_FULLSUBNET && cfg->tcn_hidden % 64 != 0) { set_error("tcn_hidden must be a multiple of 64"); return 2; }      // (TCN GEMM tiles; the reference hard-codes 512)
@@ -588,7 +592,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     const int nin = 2 * cfg->sb_num_neighbors + 1 + (fsn ? 1 : 3) * (2 * cfg->fb_num_neighbors + 1);
     // sizes without a tuned (MFMA) instantiation run on the runtime-sized kernel (lstm_generic.hip) - as long as one sequence's
     // state fits a CU's LDS
-    const bool generic_sb = cfg->sequence_model != FSNP_SEQ_TCN && ((cfg->sb_hidden != 384 && cfg->sb_hidden != 256 && cfg->sb_hidden != 512) || nin > 64);
+    const bool generic_sb = cfg->sequence_model != FSNP_SEQ_TCN && ((cfg->sb_hidden != 384 && cfg->sb_hidden != 256 && cfg->sb_hidden != 512) || nin > 64 || cfg->output_size != 2);
+    if (cfg->sequence_model == FSNP_SEQ_TCN && cfg->output_size > nin) {      // the sub-band TCN's final Linear runs as an nin-column GEMM
+        set_error("sequence_model=TCN: output_size %d exceeds the sub-band input width %d (not supported)", cfg->output_size, nin);
+        return 2;
+    }
     const bool generic_fb = fsn && (cfg->tcn_hidden != 512 || cfg->num_freqs > 264);
     if (generic_sb && lstm_generic_rows_per_group(cfg->sb_hidden, nin, 1, 1) == 0) { set_error("sb_model_hidden_size %d is too large for the runtime-sized kernel (LDS)", cfg->sb_hidden); return 2; }
     if (generic_fb && lstm_generic_rows_per_group(cfg->tcn_hidden, cfg->num_freqs, 1, 1) == 0) { set_error("fb_model_hidden_size %d is too large for the runtime-sized kernel (LDS)", cfg->tcn_hidden); return 2; }
@@ -791,7 +799,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     // workspace-only prologue shared by both models: zero the accumulators, describe the sub-band rows
     auto prologue = [&](hipStream_t st) {
         launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
-        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, st);
+        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, h->cfg.output_size, st);
     };
 
     if (!fsn) {
@@ -831,7 +839,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int fb_tiles = h->generic_fb ? cdiv(batch, fb_rg) : fb_row_tiles(batch);
         RowDesc* fb_rows = reinterpret_cast<RowDesc*>(base + w.fb_rows);
         hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(fb_tiles * fb_rg, 256)), dim3(256), 0, s, fb_rows, batch, fb_tiles, fb_rg,
-                           1, frames, 0, 0, 1, 1, 0, 2);
+                           1, frames, 0, 0, 1, 1, 0, 2, 2);
         LstmArgs fa{};
         fa.rows = fb_rows; fa.dense = fptr(w.att); fa.dense_stride = d.FP; fa.md_seq = fbuf.md;
         fa.seq_out = fptr(w.y1);
@@ -866,7 +874,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         tb.gn = reinterpret_cast<double*>(base + w.sbt_gn); tb.fb = fptr(w.sbt_fb);
         h->sbt.num_cus = h->num_cus;
         launch_tcn(ds, h->cfg.sb_act, h->sbt, tb, s, 1);
-        launch_sb_scatter(fptr(w.sbt_fb), h->XS, rows, out, (long)rows_per_utt(h, mode) * frames, num_slots, d.Tp, d.LA, s);
+        launch_sb_scatter(fptr(w.sbt_fb), h->XS, rows, out, (long)rows_per_utt(h, mode) * frames, num_slots, d.Tp, d.LA, h->cfg.output_size, s);
         if (h->timing) {
             FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
             FSNP_HIP_CHECK(hipEventRecord(rec.e[3], s));
@@ -1179,7 +1187,7 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
     unsigned long long* dprof = reinterpret_cast<unsigned long long*>(h->ws + stamp_off);
     h->have_last = false;
     hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(num_slots, 256)), dim3(256), 0, 0, rows, num_seq, lp.num_tiles,
-                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, 0, 2);
+                       lp.rows_per_slot_tile, 1, steps, 0, 0, 1, 1, 0, 2, 2);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.num_tiles = lp.num_tiles; a.ex = lp.ex; a.Tp = steps; a.LA = 0; a.F = 1;
@@ -1210,7 +1218,7 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
     h->have_last = false;
     RowDesc* rows = reinterpret_cast<RowDesc*>(h->ws);
     FSNP_HIP_CHECK(hipMemsetAsync(h->ws + rows_b, 0, hx_b + bar_b + 256 + st_b, nullptr));
-    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, nullptr);
+    launch_build_rows(plan, rows, 1, steps, 0, 0, 1, 1, 2, h->cfg.output_size, nullptr);
     LstmArgs a{};
     a.rows = rows; a.dense = x; a.dense_stride = h->NIN; a.out = out; a.out_stride_o = steps;
     a.num_rows = num_seq; a.Tp = steps; a.LA = 0; a.FP = 0; a.F = 1; a.NSBN = 0; a.act = h->cfg.sb_act;

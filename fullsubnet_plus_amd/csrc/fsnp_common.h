@@ -146,7 +146,7 @@ struct SbGatherArgs {
 };
 void launch_sb_gather(const SbGatherArgs& a, hipStream_t s);
 void launch_sb_scatter(const float* y, int ystride, const RowDesc* rows, float* out, long out_stride_o, int num_slots,
-                       int Tp, int LA, hipStream_t s);
+                       int Tp, int LA, int out_channels, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // lstm.hip : fused 2-layer LSTM + Linear over 32-sequence tiles, one workgroup per tile

@@ -156,11 +156,11 @@ __global__ __launch_bounds__(256) void sb_gather_kernel(SbGatherArgs a) {
 }
 
 __global__ void sb_scatter_kernel(const float* __restrict__ y, int ystride, const RowDesc* __restrict__ rows,
-                                  float* __restrict__ out, long out_stride_o, int num_slots, int Tp, int LA) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (slot, o, t)
+                                  float* __restrict__ out, long out_stride_o, int num_slots, int Tp, int LA, int OC) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (slot, o, t), o < OC = output_size
     const int T = Tp - LA;
-    if (i >= (long)num_slots * 2 * T) return;
-    const int t = (int)(i % T), o = (int)((i / T) % 2), slot = (int)(i / (2 * T));
+    if (i >= (long)num_slots * OC * T) return;
+    const int t = (int)(i % T), o = (int)((i / T) % OC), slot = (int)(i / ((long)OC * T));
     const RowDesc rd = rows[slot];
     if (rd.valid) out[(size_t)rd.out_off + (size_t)o * out_stride_o + t] = y[((size_t)slot * Tp + t + LA) * ystride + o];
 }
@@ -170,10 +170,10 @@ void launch_sb_gather(const SbGatherArgs& a, hipStream_t s) {
 }
 
 void launch_sb_scatter(const float* y, int ystride, const RowDesc* rows, float* out, long out_stride_o, int num_slots,
-                       int Tp, int LA, hipStream_t s) {
-    const long n = (long)num_slots * 2 * (Tp - LA);
+                       int Tp, int LA, int out_channels, hipStream_t s) {
+    const long n = (long)num_slots * out_channels * (Tp - LA);
     hipLaunchKernelGGL(sb_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, ystride, rows, out,
-                       out_stride_o, num_slots, Tp, LA);
+                       out_stride_o, num_slots, Tp, LA, out_channels);
 }
 
 }  // namespace fsnp

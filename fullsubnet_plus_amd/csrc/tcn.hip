@@ -294,28 +294,6 @@ __device__ __forceinline__ EpiCtx epi_ctx(const GemmArgs& g, int branch, int utt
     }
     return e;
 }
-// acc = the k-sum of element (t, col); bias / c2 = the column's constants; s / q2 collect the GroupNorm statistics (EPI_PRELU_STATS)
-template <int EPI>
-__device__ __forceinline__ float epi_value(const GemmArgs& g, const EpiCtx& e, float acc, float bias, float c2, int branch, int utt, int t, int col,
-                                           double& s, double& q2) {
-    float v;
-    if constexpr (EPI == EPI_PRELU_STATS) {
-        v = acc + bias;
-        v = v >= 0.f ? v : e.slope * v;
-        s += (double)v;
-        q2 += (double)v * (double)v;
-    } else if constexpr (EPI == EPI_RESIDUAL) {
-        v = e.rstd * acc + (bias - e.mr * c2);
-        v += g.R[branch * g.r_bs + ((long)utt * g.Tp + t) * g.ldr + col];
-        if (g.relu_out) v = fmaxf(v, 0.f);
-    } else {                                   // EPI_ACT: the final Linear (its operand was stored ReLU'd by the last sconv)
-        v = acc + bias;
-        if (g.act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (g.act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-        else if (g.act == FSNP_ACT_TANH) v = tanhf(v);
-    }
-    return v;
-}
 // one fp64 atomic pair per workgroup into the plane's {sum, sum of squares} slot
 __device__ __forceinline__ void epi_stats_finish(const GemmArgs& g, double s, double q2, double* red, int branch, int utt, int tid, int lane, int wave) {
     s = wave_sum(s);
@@ -327,6 +305,75 @@ __device__ __forceinline__ void epi_stats_finish(const GemmArgs& g, double s, do
         atomicAdd(out, red[0] + red[2] + red[4] + red[6]);
         atomicAdd(out + 1, red[1] + red[3] + red[5] + red[7]);
     }
+}
+
+// ---- float4 epilogue of the DMA GEMM kernels (round 4).  The accumulator layout of v_mfma_f32_32x32x2_f32 gives a lane ONE column
+// and 16 scattered rows: stored from there, a tile leaves as 32 (sconv: 32 + 32 residual loads, each load -> add -> store a dependent
+// round trip because the residual aliases the output: the in-place x += ...) 4-byte instructions per lane.  Here a wave first
+// transposes its R rows x 64 columns through a private LDS slice (row-major, 256 B per row: ds_write_b32 of 32 consecutive columns
+// and ds_read_b128 of whole rows are both conflict-free) so that a lane owns float4s along the row: ALL residual loads are issued
+// up front as 16-byte loads, waited for ONCE, and the tile leaves in 16-byte stores of whole 256-byte row segments.
+// Lane l -> column quad (l & 15), row (l >> 4) + 4 i of the slice.
+template <int EPI, int ROWS>      // ROWS = rows of the wave's slice (32: 128-row kernel, 8: split-K kernel)
+struct EpiF4 {
+    static constexpr int NV = ROWS / 4;
+    float4 rv[NV];
+    int colv, er;
+    bool f4_ok;
+    __device__ __forceinline__ void init(const GemmArgs& g, int n0, int lane) {
+        er = lane >> 4;
+        colv = n0 + (lane & 15) * 4;
+        f4_ok = colv < g.ldc;                   // ldc is a float4 multiple: columns [N, ldc) are the zero pad the next GEMM's DMA reads
+    }
+    // the residual operand of rows [trow0, trow0 + ROWS) - issued long before it is needed (EPI_RESIDUAL only)
+    __device__ __forceinline__ void load_residual(const GemmArgs& g, int branch, int utt, int trow0) {
+        if constexpr (EPI == EPI_RESIDUAL) {
+            const float* Rp = g.R + branch * g.r_bs + ((long)utt * g.Tp) * g.ldr + colv;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int t = trow0 + i * 4 + er;
+                rv[i] = (t < g.Tp && f4_ok) ? *reinterpret_cast<const float4*>(Rp + (long)t * g.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // slice: the wave's [ROWS][64] floats, already holding the finished values EXCEPT the residual / ReLU
+    __device__ __forceinline__ void store(const GemmArgs& g, const float* slice, float* C, int trow0, int lane) {
+        const float4* s4 = reinterpret_cast<const float4*>(slice);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int t = trow0 + i * 4 + er;
+            float4 v = s4[(i * 4 + er) * 16 + (lane & 15)];
+            if constexpr (EPI == EPI_RESIDUAL) {
+                v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+                if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (colv + 3 >= g.N) {               // the tile that holds column N - 1: pad columns are written as zeros
+                if (colv >= g.N) v.x = 0.f;
+                if (colv + 1 >= g.N) v.y = 0.f;
+                if (colv + 2 >= g.N) v.z = 0.f;
+                v.w = 0.f;
+            }
+            if (t < g.Tp && f4_ok) *reinterpret_cast<float4*>(C + (long)t * g.ldc + colv) = v;
+        }
+    }
+};
+// one accumulator element in the register layout: everything but the residual (added in the float4 phase)
+template <int EPI>
+__device__ __forceinline__ float epi_stage_value(const EpiCtx& e, float acc, float cb, int act, bool counted, double& s, double& q2) {
+    float v;
+    if constexpr (EPI == EPI_PRELU_STATS) {
+        v = acc + cb;
+        v = v >= 0.f ? v : e.slope * v;
+        if (counted) { s += (double)v; q2 += (double)v * (double)v; }
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+        v = e.rstd * acc + cb;                   // cb = c1[n] - m r c2[n]  (GroupNorm folded, see tcn_gemm_dma_kernel)
+    } else {
+        v = acc + cb;
+        if (act == FSNP_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == FSNP_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+        else if (act == FSNP_ACT_TANH) v = tanhf(v);
+    }
+    return v;
 }
 
 // tcn_gemm_dma_kernel: the two GEMMs of a TCNBlock with the k-loop stripped to what the matrix pipe needs.
@@ -349,7 +396,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
     constexpr int BN = 64;
     constexpr int A_SLOTS = BM * 4, B_SLOTS = BN * 4, STAGE = A_SLOTS + B_SLOTS;      // float4 slots per stage (12 KiB)
-    __shared__ __attribute__((aligned(16))) float4 smem[2 * STAGE];
+    constexpr int EPI_SLOTS = BM * BN / 4;                                             // the epilogue's transposition slices: 4 waves x [32][64] floats
+    __shared__ __attribute__((aligned(16))) float4 smem[2 * STAGE > EPI_SLOTS ? 2 * STAGE : EPI_SLOTS];      // 32 KiB
     __shared__ double red[8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -361,6 +409,16 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
     const int t0 = (row_tile % tiles_per_utt) * BM;
     const int n0 = ntile * BN;
     const int rows_valid = min(BM, g.Tp - t0);
+    // the plane's scalars (EPI_RESIDUAL: two loads + an fp64 rsqrt / divide chain) and the columns' constants: fetched and computed
+    // here, under the first DMA round trips, instead of at the head of the epilogue
+    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
+    float cb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        cb[j] = g.bias[branch * g.bias_bs + col];
+        if constexpr (EPI == EPI_RESIDUAL) cb[j] -= ec.mr * g.c2[branch * g.c2_bs + col];
+    }
 
     const float* A = g.A + branch * g.a_bs + ((long)utt * g.Tp + t0) * g.lda;
     const float* W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
@@ -440,24 +498,26 @@ __global__ __launch_bounds__(256) void tcn_gemm_dma_kernel(GemmArgs g) {
         asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));
     }
 
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5) ----
+    // ---- epilogue (EpiF4): residual loads first, the wave's 32 x 64 slice transposed through LDS (the k-loop's last barrier has
+    // passed: no wave reads the operand stages any more; a wave touches only its own 8 KiB), 16-byte stores
     float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
     double s = 0.0, q2 = 0.0;
-    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
+    EpiF4<EPI, 32> ef;
+    ef.init(g, n0, lane);
+    ef.load_residual(g, branch, utt, t0 + wave * 32);
+    float* slice = reinterpret_cast<float*>(smem) + wave * (32 * 64);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + j * 32 + (lane & 31);
-        const bool col_ok = col < g.N;
-        const float bias = g.bias[branch * g.bias_bs + col];
-        float c2 = 0.f;
-        if constexpr (EPI == EPI_RESIDUAL) c2 = g.c2[branch * g.c2_bs + col];
+        const bool col_ok = n0 + j * 32 + (lane & 31) < g.N;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int t = t0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            if (t < g.Tp && col_ok) C[(long)t * g.ldc + col] = epi_value<EPI>(g, ec, acc[j][q], bias, c2, branch, utt, t, col, s, q2);
-            else if (t < g.Tp && col < g.ldc) C[(long)t * g.ldc + col] = 0.f;      // pad columns [N, ldc): the next GEMM's DMA reads them (times zero weights)
+            const int rl = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const bool counted = col_ok && t0 + wave * 32 + rl < g.Tp;
+            slice[rl * 64 + j * 32 + (lane & 31)] = epi_stage_value<EPI>(ec, acc[j][q], cb[j], g.act, counted, s, q2);
         }
     }
+    __builtin_amdgcn_wave_barrier();            // (LDS operations of one wave execute in order; this only pins the compiler's order)
+    ef.store(g, slice, C, t0 + wave * 32, lane);
     if constexpr (EPI == EPI_PRELU_STATS) epi_stats_finish(g, s, q2, red, branch, utt, tid, lane, wave);
 }
 
@@ -558,6 +618,18 @@ __global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
         stage ^= 1;
     }
     // ---- add the four partial tiles: part[wave][j][q][lane]; wave w then owns accumulator registers q in [4 w, 4 w + 4) = rows 8 w ... 8 w + 7
+    // (the epilogue's scalars, column constants and residual rows are fetched first: their round trips pass under the reduction)
+    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
+    float cb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        cb[j] = g.bias[branch * g.bias_bs + col];
+        if constexpr (EPI == EPI_RESIDUAL) cb[j] -= ec.mr * g.c2[branch * g.c2_bs + col];
+    }
+    EpiF4<EPI, 8> ef;
+    ef.init(g, n0, lane);
+    ef.load_residual(g, branch, utt, t0 + wave * 8);
     __syncthreads();                                  // every wave is done with its staging buffers
     float* part = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -578,24 +650,23 @@ __global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
             sum[j][qq] = v;
         }
 
-    // ---- epilogue (as tcn_gemm_dma_kernel): C/D layout of 32x32: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    // ---- epilogue (EpiF4, as tcn_gemm_dma_kernel): the wave's 8 x 64 slice transposed through LDS behind the partial tiles (32 KiB
+    // of the 48; that area was wave 2's staging buffer - idle since the barriers above), 16-byte residual loads and stores
     float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
     double s = 0.0, q2 = 0.0;
-    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
+    float* slice = reinterpret_cast<float*>(smem) + 4 * 2 * 16 * 64 + wave * (8 * 64);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + j * 32 + (lane & 31);
-        const bool col_ok = col < g.N;
-        const float bias = g.bias[branch * g.bias_bs + col];
-        float c2 = 0.f;
-        if constexpr (EPI == EPI_RESIDUAL) c2 = g.c2[branch * g.c2_bs + col];
+        const bool col_ok = n0 + j * 32 + (lane & 31) < g.N;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const int t = t0 + qq + 8 * wave + 4 * (lane >> 5);
-            if (t < g.Tp && col_ok) C[(long)t * g.ldc + col] = epi_value<EPI>(g, ec, sum[j][qq], bias, c2, branch, utt, t, col, s, q2);
-            else if (t < g.Tp && col < g.ldc) C[(long)t * g.ldc + col] = 0.f;      // pad columns [N, ldc)
+            const int rl = qq + 4 * (lane >> 5);
+            const bool counted = col_ok && t0 + wave * 8 + rl < g.Tp;
+            slice[rl * 64 + j * 32 + (lane & 31)] = epi_stage_value<EPI>(ec, sum[j][qq], cb[j], g.act, counted, s, q2);
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    ef.store(g, slice, C, t0 + wave * 8, lane);
     if constexpr (EPI == EPI_PRELU_STATS) epi_stats_finish(g, s, q2, red, branch, utt, tid, lane, wave);
 }
 
@@ -606,6 +677,9 @@ static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus
     if (g.ldw - g.lda >= BK) return false;                 // only the LAST k-tile may reach beyond a row of A
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15 || (g.a_bs * 4) % 16 || (g.w_bs * 4) % 16) return false;
     if ((long)BM * g.lda * 4 >= (1L << 31) || (long)64 * g.ldw * 4 >= (1L << 31)) return false;
+    // float4 epilogue: 16-byte rows of C (and of the residual)
+    if (g.ldc % 4 || (reinterpret_cast<uintptr_t>(g.C) & 15) || (g.c_bs * 4) % 16) return false;
+    if (EPI == EPI_RESIDUAL && (g.ldr % 4 || (reinterpret_cast<uintptr_t>(g.R) & 15) || (g.r_bs * 4) % 16)) return false;
     GemmArgs ga = g;
     ga.ntiles_n = cdiv(n, 64); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
     // small problems: 32-row tiles whose four waves split K (tcn_gemm_sk_kernel) while that launch has at most 6 workgroups per CU

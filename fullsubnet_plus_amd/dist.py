@@ -48,7 +48,7 @@ def forward_sharded(model, noisy_mag, noisy_real=None, noisy_imag=None, gather=T
         out = model(*ins, batch_offset=lo, global_batch=B)
     else:
         F = model.num_freqs // groups if parity else model.num_freqs
-        out = torch.zeros((B if parity else 0, 2, F, noisy_mag.shape[-1]), dtype=torch.float32, device=noisy_mag.device)
+        out = torch.zeros((B if parity else 0, getattr(model, "output_size", 2), F, noisy_mag.shape[-1]), dtype=torch.float32, device=noisy_mag.device)
     if not gather or not dist.is_initialized():
         return out                              # (a process group of ONE rank still runs the collective: the RCCL path is
                                                 #  the same call at every world size, tests/test_gpu_multirank.py exercises it)

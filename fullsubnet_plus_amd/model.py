@@ -256,7 +256,7 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(device)
         out_f = num_freqs // self.num_groups_in_drop_band if parity else num_freqs
         standalone = global_batch is None
-        out = torch.empty((gb if parity else batch_size, 2, out_f, num_frames), dtype=torch.float32, device=device)
+        out = torch.empty((gb if parity else batch_size, self.output_size, out_f, num_frames), dtype=torch.float32, device=device)
         if parity and not standalone:
             out.zero_()     # a shard writes only its own rows of the global tensor
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -351,6 +351,7 @@ class _HipModel(nn.Module):
         original FullSubNet): noisy_complex [B,F,T] complex64 (torch.stft output, any strides) -> enhanced complex
         [B,F,T] ready for torch.istft.  Always keeps all bins (batch_mode "full")."""
         assert noisy_complex.dim() == 3 and noisy_complex.is_complex()
+        assert self.output_size == 2, "the cIRM epilogue needs the two mask channels (decompress_cIRM, acoustics/mask.py:60-63)"
         mode, self.batch_mode = self.batch_mode, "full"
         try:
             mask = self.forward_complex(noisy_complex)
@@ -402,6 +403,7 @@ class _HipModel(nn.Module):
         `mag_complex_full_band_crm_mask`; `full_band_crm_mask` of fullsubnet/inferencer/inferencer.py for the original
         FullSubNet): noisy waveform [B, samples] -> enhanced waveform [B, samples]; STFT, model (all bins), cIRM
         decompression, complex multiply and iSTFT all run in HIP on the caller's stream."""
+        assert self.output_size == 2, "the cIRM epilogue needs the two mask channels (decompress_cIRM, acoustics/mask.py:60-63)"
         wav, lib, stream = self._wave_args(noisy)
         B, L = wav.shape
         out = torch.empty((B, L), dtype=torch.float32, device=wav.device)
@@ -431,7 +433,7 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(x.device)
         n, _, steps = x.shape
         xt = x.permute(0, 2, 1).contiguous().float()
-        out = torch.empty((n, 2, steps), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, self.output_size, steps), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(lib.fsnp_lstm2_fc(self._handle, xt.data_ptr(), out.data_ptr(), n, steps,

@@ -115,6 +115,12 @@ CASES = [
     # (mean and max squeeze) must not alias
     dict(name="b1_t16_cbam_f521", wseed=40, profile="harsh", args={"channel_attention_model": "CBAM", "num_freqs": 521},
          inp=("spec", 1, 16, 41), stages=False),
+    # output_size off its default (fullsubnet_plus.py:30,104,206): the Linear(H, output_size) of the sub-band model and the final
+    # reshape; B = 3 also in the reference's drop_band row order
+    dict(name="b1_t20_out3", wseed=41, profile="harsh", args={"output_size": 3}, inp=("spec", 1, 20, 42), stages=False),
+    dict(name="b3_t16_out1", wseed=42, profile="default", args={"output_size": 1}, inp=("spec", 3, 16, 43), stages=False),
+    dict(name="gru_b3_t16_out5", wseed=43, profile="harsh", args={"output_size": 5, "sequence_model": "GRU"}, inp=("spec", 3, 16, 44), stages=False),
+    dict(name="tcn_b1_t20_out3", wseed=44, profile="default", args={"output_size": 3, "sequence_model": "TCN"}, inp=("spec", 1, 20, 45), stages=False),
     dict(name="b1_10s_default", wseed=0, profile="default", args={}, inp=("stft", 1, 10.0, 11), stages=False,
          subsample_f=4),
 ]
@@ -166,7 +172,7 @@ def run_case(case, FullSubNet_Plus):
     sd = make_state_dict(case["wseed"], case["profile"], attention=args["channel_attention_model"],
                          sequence_model=args["sequence_model"], fb_num_neighbors=args["fb_num_neighbors"],
                          num_freqs=args["num_freqs"], sb_num_neighbors=args["sb_num_neighbors"], kersize=tuple(args["kersize"]),
-                         sb_hidden=args["sb_model_hidden_size"])
+                         sb_hidden=args["sb_model_hidden_size"], output_size=args.get("output_size", 2))
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     kind, B, t, iseed = case["inp"]
@@ -306,7 +312,7 @@ def main():
                   num_groups_in_drop_band=args["num_groups_in_drop_band"],
                   channel_attention_model=args["channel_attention_model"], subband_num=args.get("subband_num", 1),
                   fb_output_activate_function=args["fb_output_activate_function"],
-                  sb_output_activate_function=args["sb_output_activate_function"])
+                  sb_output_activate_function=args["sb_output_activate_function"], output_size=args.get("output_size", 2))
         sub = case.get("subsample_f") or 1
         ot = fsnp_torch.forward(sd, mag, real, imag, **kw).numpy()[:, :, ::sub, :]
         scale = np.abs(payload["out"]).max()

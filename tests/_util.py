@@ -46,7 +46,8 @@ class Golden:
                                num_freqs=self.args.get("num_freqs", 257),
                                sb_num_neighbors=self.args.get("sb_num_neighbors", 15),
                                kersize=tuple(self.args.get("kersize", (3, 5, 10))),
-                               sb_hidden=self.args.get("sb_model_hidden_size", 384))
+                               sb_hidden=self.args.get("sb_model_hidden_size", 384),
+                               output_size=self.args.get("output_size", 2))
 
     def inputs(self):
         inp = self.meta["inp"]
@@ -72,7 +73,8 @@ class Golden:
                     channel_attention_model=a.get("channel_attention_model", "TSSE"),
                     subband_num=a.get("subband_num", 1),
                     fb_output_activate_function=a.get("fb_output_activate_function", "ReLU"),
-                    sb_output_activate_function=a.get("sb_output_activate_function", False))
+                    sb_output_activate_function=a.get("sb_output_activate_function", False),
+                    output_size=a.get("output_size", 2))
 
 
 def rel_err(a, b):

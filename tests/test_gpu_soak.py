@@ -104,7 +104,12 @@ def test_long_recurrence_kernels(n, steps):
         m.check_errors()
         assert torch.equal(again, first), (rep, _first_difference(again, first))
     sel = _sample_rows(n, 12)
-    want = fsnp_torch.lstm2_fc(x[sel].cpu(), sd).numpy()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                 # 8192 dependent steps of tiny matrix products: a thread pool only adds hand-over time
+    try:
+        want = fsnp_torch.lstm2_fc(x[sel].cpu(), sd).numpy()
+    finally:
+        torch.set_num_threads(threads)
     got = first[sel].cpu().numpy()
     per_step = np.abs(got - want).max(axis=(0, 1)) / np.abs(want).max()
     assert per_step.max() < 2e-5, (per_step.max(), int(per_step.argmax()))
@@ -129,17 +134,21 @@ def test_long_recurrence_forward(B, seconds):
     def run(mode, chaos=0):
         m.debug_set_gemm_dma(mode)
         m.debug_set_chaos(chaos)
-        out = m(*g)
-        return out, {s: m.read_stage(s, B, T) for s in STAGES}
+        return m(*g)
 
-    ref, ref_stages = run(1)
+    def read_stages():                        # the stage buffers of the LAST forward stay in the workspace until the next one
+        return {s: m.read_stage(s, B, T) for s in STAGES}
+
+    ref = run(1)
+    ref_stages = read_stages()
     assert rel_err(ref.cpu().numpy(), want) < TOL
     for k, (mode, chaos) in enumerate([(0, 0), (1, 0), (2, 0), (2, 0), (1, 5)]):
-        out, stages = run(mode, chaos)
+        out = run(mode, chaos)
         if mode == 0:
             assert rel_err(out.cpu().numpy(), want) < TOL
             continue
         if not torch.equal(out, ref):
+            stages = read_stages()
             d = (out != ref)
             rows = torch.nonzero(d.any(dim=3).any(dim=1))            # [utterance, bin]
             frames = torch.nonzero(d.any(dim=2).any(dim=1).any(dim=0)).flatten()

@@ -43,7 +43,7 @@ def test_create_fails_loudly_without_gpu():
                                              ("sb_num_neighbors", -1, b"neighbors"), ("fb_num_neighbors", 300, b"exceed"),
                                              ("subband_num", 2, b"ECA"), ("subband_num", -1, b"subband_num"),
                                              ("num_groups_in_drop_band", 0, b"num_groups_in_drop_band"),
-                                             ("output_size", 3, b"output_size"), ("sb_hidden", 0, b"sb_model_hidden_size"),
+                                             ("output_size", 0, b"output_size"), ("sb_hidden", 0, b"sb_model_hidden_size"),
                                              ("sb_hidden", 6000, b"too large"),
                                              ("norm_type", 7, b"norm_type"), ("attention", 9, b"attention"),
                                              ("model", 5, b"model"), ("sequence_model", 3, b"sequence_model")])
@@ -329,6 +329,10 @@ def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
     for key, l in res.items():
         assert l["mfma"] >= 32 and l["dma"] >= 3 and l["ds_read"] >= 6, (key, l)
         assert l["scratch"] == 0 and l["acc_moves"] == 0 and l["ds_write"] == 0 and l["valu"] <= 12, (key, l)
+        # round 4: the epilogue moves 16-byte rows only (the tile is transposed through LDS) and drains vmcnt at most twice - the
+        # sconv epilogue used to be 32 dependent 4-byte load -> add -> store round trips per lane
+        assert l["epi_store16"] == 8 and l["epi_store4"] == 0 and l["epi_load4"] == 0 and l["epi_drains"] <= 2 and l["epi_scratch"] == 0, (key, l)
+        assert l["epi_load16"] == (8 if "ILi1E" in key else 0), (key, l)             # EPI_RESIDUAL: the eight residual rows
 
 
 def test_half_tile_ping_pong_index_arithmetic():

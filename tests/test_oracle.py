@@ -7,7 +7,7 @@ import torch
 from oracle import fsnp_numpy, fsnp_torch, ref_loader
 from tests._util import Golden, golden_names, rel_err
 
-SMALL = [n for n in golden_names() if "2s" not in n and "10s" not in n and "_att_" not in n and "_eca_" not in n and "gru" not in n and "tcn" not in n and "fbn" not in n]
+SMALL = [n for n in golden_names() if "2s" not in n and "10s" not in n and "_att_" not in n and "_eca_" not in n and "_cbam_" not in n and "gru" not in n and "tcn" not in n and "fbn" not in n]
 
 
 @pytest.mark.parametrize("name", golden_names())

@@ -192,6 +192,13 @@ def analyse_dma_gemm(flags=("-fno-slp-vectorize",)):
         cnt = lambda pat: sum(1 for x in seg if re.search(pat, x))
         res[name] = dict(mfma=cnt(r"v_mfma"), ds_read=cnt(r"ds_read_b128"), dma=cnt(r"buffer_load_dwordx4 .* lds"), scratch=cnt(r"scratch_"),
                          acc_moves=cnt(r"v_accvgpr"), valu=cnt(r"^\s+v_(?!mfma)"), ds_write=cnt(r"ds_write"))
+        # the epilogue = everything behind the last MFMA: 16-byte global traffic only, at most two full vmcnt drains (round 4: the
+        # accumulator tile is transposed through LDS so that a lane owns float4s along a row; before, the sconv epilogue was 32
+        # dependent 4-byte load -> add -> store round trips per lane)
+        epi = body[idx[-1] + 1:]
+        ecnt = lambda pat: sum(1 for x in epi if re.search(pat, x))
+        res[name].update(epi_drains=ecnt(r"vmcnt\(0\)"), epi_load16=ecnt(r"global_load_dwordx4"), epi_load4=ecnt(r"global_load_dword\s"),
+                         epi_store16=ecnt(r"global_store_dwordx4"), epi_store4=ecnt(r"global_store_dword\s"), epi_scratch=ecnt(r"scratch_"))
     return res
 
 
