@@ -41,10 +41,10 @@ static PlannerCtx pctx(const fsnp_handle* h) {
     PlannerCtx c;
     c.H = h->H; c.NIN = h->NIN; c.num_cus = h->num_cus; c.num_cus_real = h->num_cus_real;
     c.gru = h->gru != 0; c.sb_tcn = h->sb_tcn != 0; c.generic_sb = h->generic_sb; c.rowtile_ok = h->rowtile_ok; c.lstm16_ok = h->lstm16_ok;
-    c.pp_ok = h->pp_ok; c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
+    c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
     for (int i = 0; i < 4; ++i) c.occ_ksplit[i] = h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) c.occ_coopn[i] = h->occ_coopn[i];
-    c.coop_split = h->coop_split; c.coop_pp = h->coop_pp; c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
+    c.coop_split = h->coop_split; c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
     c.cost = h->cost;
     return c;
 }
@@ -229,8 +229,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             ca.coop_xcd = c.kind != 6 && xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
-            if (c.kind == 6) launch_lstm_pp(h->lw, ca, s);
-            else if (c.kind == 8) launch_lstm_hp(h->lw, ca, s);
+            if (c.kind == 8) launch_lstm_hp(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
         });
@@ -474,7 +473,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     auto time_shape = [&](SbChunk c) -> double {
         c.row0 = 0; c.nrows = c.num_tiles * c.rps; c.slot0 = 0; c.coop_tile0 = 0;
         SbPlan plan;
-        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 6 || c.kind == 8) ? c.num_tiles : 0;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 8) ? c.num_tiles : 0;
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
@@ -517,12 +516,6 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         const double us0 = time_shape(SbChunk{0, 0, 0, h->num_cus_real, 0, 32, 0, 0, 0, 0, 0});
         if (us0 < 0) rc = 4;
         else t.rowtile = us0;           // the VALU-row surcharge keeps its measured ratio (0.11 per row)
-    }
-    for (int rpg = 1; rpg <= 4 && rc == 0 && h->pp_ok; ++rpg) {
-        const int groups = h->num_cus_real / (h->H / 8);
-        if (groups <= 0) break;
-        const double us = time_shape(SbChunk{6, 0, 0, groups * rpg, 0, 32, 8, groups, rpg, 0, 0});
-        if (us < 0) rc = 4; else t.pp[rpg - 1] = us;
     }
     if (rc == 0 && h->hp_ok && h->num_cus_real / (h->H / 16) > 0) {
         const int cap = h->num_cus_real / (h->H / 16);
@@ -663,19 +656,14 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     if (csp && csp[0] >= '0' && csp[0] <= '3') h->coop_split = csp[0] - '0';
     h->coop_split_cfg = h->coop_split;
     {
-        // The ping-pong K-split kernel (lstm_pp.hip) is OPT-IN (FSNP_COOP_PP=1): measured (profiles/r03_column_split.md) it only
-        // beats the round-2 kernels at exactly 10 row tiles (15.7 vs 16.7 us per step); everywhere else its fixed cost per
-        // tile-phase (cell phase 1.0 us, operand fetch issue 1.1 us, barriers 0.5 us on top of 4.4 us of MFMAs) loses
-        const char* pe = getenv("FSNP_COOP_PP");
-        h->coop_pp = pe && pe[0] == '1' ? 1 : 0;
-        h->coop_pp_cfg = h->coop_pp;
-        h->pp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
+        // (The round-3 ping-pong K-split kernel lstm_pp.hip - opt-in, ahead of the other kernels at exactly 10 row tiles - was removed in
+        // round 4; its measurements stay in profiles/r03_column_split.md and profiles/r03_pp_*.txt.)
         // The half-tile ping-pong kernel (lstm_hp.hip) is planned wherever the cost table says it pays (6 ... 10 row tiles: B = 1);
         // FSNP_COOP_HP=0: never
         const char* he = getenv("FSNP_COOP_HP");
         h->coop_hp = he && he[0] == '0' ? 0 : 1;
         h->coop_hp_cfg = h->coop_hp;
-        h->hp_ok = h->pp_ok;
+        h->hp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
     }
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
@@ -1069,10 +1057,8 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
         for (int i = 0; i < 4; ++i) h.cost.pp[i] = costs[20 + i];
         h.cost.hp[0] = costs[24]; h.cost.hp[1] = costs[25];
     }
-    h.pp_ok = gru == 0 && (hidden == 384 || hidden == 256);
-    h.hp_ok = h.pp_ok;
+    h.hp_ok = gru == 0 && (hidden == 384 || hidden == 256);
     h.coop_hp = 1;
-    h.coop_pp = costs != nullptr;          // (a caller's table prices the ping-pong launches in or out; the built-in plans do not use them)
     h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
@@ -1145,7 +1131,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
         if (n >= max_chunks) break;
         // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel,
         // 12 = half-tile ping-pong (lstm_hp.hip)
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 6 ? 6 + c.rpg : c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
@@ -1201,14 +1187,17 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
                           uint64_t* host_stamps, int64_t num_stamps) {
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_pp_profile: null argument"); return 1; }
-    if (!h->committed || !h->pp_ok) { set_error("fsnp_debug_pp_profile: no ping-pong K-split kernel for this handle"); return 2; }
-    const bool hp = tiles_per_group == 0;           // 0 = the half-tile ping-pong kernel (lstm_hp.hip): 2 halves x 16 stamps per step
-    if (tiles_per_group < 0 || tiles_per_group > 4 || num_stamps != (int64_t)steps * (hp ? 4 : tiles_per_group) * 8) { set_error("fsnp_debug_pp_profile: need steps * tiles_per_group * 8 stamps (tiles_per_group 0: steps * 32)"); return 2; }
-    const int tiles = cdiv(num_seq, 32), groups = hp ? tiles : cdiv(tiles, tiles_per_group);
-    if (num_seq <= 0 || groups * (h->H / (hp ? 16 : 8)) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
+    if (!h->committed || !h->hp_ok) { set_error("fsnp_debug_pp_profile: no half-tile ping-pong kernel for this handle"); return 2; }
+    // tiles_per_group: 0 = the half-tile ping-pong kernel (lstm_hp.hip: 2 halves x 16 stamps per step) - the only kernel left that stamps
+    // (1..4 used to select the round-3 ping-pong K-split kernel lstm_pp.hip, removed in round 4)
+    if (tiles_per_group != 0 || num_stamps != (int64_t)steps * 32) { set_error("fsnp_debug_pp_profile: tiles_per_group must be 0 (half-tile ping-pong kernel) with steps * 32 stamps"); return 2; }
+    const bool hp = true;
+    const int tiles = cdiv(num_seq, 32), groups = tiles;
+    if (num_seq <= 0 || groups * (h->H / 16) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
     FSNP_ON_DEVICE(h);
     SbPlan plan;
-    plan.chunks = {hp ? SbChunk{8, 0, num_seq, tiles, 0, 32, 16, 0, 0, 0, 0} : SbChunk{6, 0, num_seq, tiles, 0, 32, 8, groups, tiles_per_group, 0, 0}};
+    (void)hp; (void)groups;
+    plan.chunks = {SbChunk{8, 0, num_seq, tiles, 0, 32, 16, 0, 0, 0, 0}};
     plan.total_slots = tiles * 32; plan.coop_tiles = tiles;
     const size_t rows_b = align_up((size_t)plan.total_slots * sizeof(RowDesc), 256), hx_b = align_up(lstm_coop_exchange_bytes(h->H, tiles), 256);
     const size_t bar_b = align_up(coop_counter_bytes(tiles), 256), st_b = (size_t)num_stamps * 8;
@@ -1323,7 +1312,6 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
         (int)h->committed, h->ih_bf16, h->pipeline, (int)h->timing, h->ws_bytes, h->ws_slots);
     add("effective settings (environment variable as read at fsnp_create = value in force):\n");
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
-    add("  FSNP_COOP_PP=%s -> ping-pong K split (lstm_pp.hip) %s\n", env("FSNP_COOP_PP"), !h->pp_ok ? "not built for this model" : h->coop_pp ? "planned" : "never");
     add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
     add("  FSNP_COOP_SKEW=%s -> K-split schedule %s (FSNP_SKEW_MIN_UNITS=%s: smallest units per workgroup that run it, default 8)\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial", env("FSNP_SKEW_MIN_UNITS"));
     add("  FSNP_COOP_SPLIT=%s -> role-split K split mode %d (0 never, 1 auto outside the pipelined loop, 2 wherever it fits, 3 auto also pipelined)\n", env("FSNP_COOP_SPLIT"), h->coop_split);
@@ -1368,18 +1356,17 @@ int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply) or 2 (as 1, never the small-batch split-K kernel)"); return 1; }
+    if (!h || mode < 0 || mode > 3) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply), 2 (as 1, never the small-batch split-K kernel) or 3 (the 128-row DMA kernel only)"); return 1; }
     h->tw.gemm_dma = mode;
     drop_graphs(h);          // a captured full-band chain holds the other kernels
     return 0;
 }
 
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule, no opt-in kernels), 3 (auto + the ping-pong K split) or 4 (auto + the half-tile ping-pong kernel)"); return 1; }
+    if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule), 3 (= 1; selected the ping-pong K split lstm_pp.hip until round 4 removed it) or 4 (auto + the half-tile ping-pong kernel even where FSNP_COOP_HP=0)"); return 1; }
     h->lstm_coop = mode != 0;
     h->coop_skew = mode == 1 || mode >= 3;
     h->coop_split = mode == 1 || mode >= 3 ? h->coop_split_cfg : 0;
-    h->coop_pp = mode == 3 ? 1 : mode == 1 ? h->coop_pp_cfg : 0;
     h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);

@@ -90,7 +90,8 @@ struct TcnWeights {
     int num_cus;         // for the per-launch column-tile choice (N1P, N2P are multiples of 384: any BN fits)
     int dilation[16];
     int gemm_dma;        // 1 = the full-band GEMMs run on tcn_gemm_dma_kernel / (small batches) tcn_gemm_sk_kernel where their requirements hold,
-                         // 2 = never the small-batch kernel, 0 = the general kernel (fsnp_debug_set_gemm_dma)
+                         // 2 = never the small-batch kernel, 3 = the 128-row DMA kernel only (neither the small-batch nor the 64-row sconv
+                         // kernel), 0 = the general kernel (fsnp_debug_set_gemm_dma)
 };
 
 struct TcnBuffers {
@@ -207,7 +208,7 @@ struct LstmArgs {
     int coop_own_cu;           // lstm_coop.hip: > 0 = claim this many bytes of dynamic LDS (the whole CU's) so that no workgroup of a
                                // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
-    int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2; lstm_pp.hip: 1..4 row tiles per group
+    int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2 row tiles per group; lstm_generic.hip: sequences per workgroup
     int coop_chaos;            // test hook (fsnp_debug_set_chaos): != 0 = seed of pseudo-random, workgroup-uniform delays at the phase boundaries
                                // of the column-split kernels, so that the workgroups of a launch drift apart instead of running in lockstep
 };
@@ -236,10 +237,6 @@ size_t lstm_coop_pack_floats(int H, int KX, int units);
 void lstm_coop_pack_weights(int H, int NIN, int KX, int units, const float* wih0, const float* whh0, const float* wih1,
                             const float* whh1, float* wpack);
 size_t lstm_coop_exchange_bytes(int H, int row_tiles);
-// lstm_pp.hip: K split at 8 units per workgroup, fused two-layer phase, a.coop_rows_per_group (1..4) independent row tiles per
-// group of H / 8 workgroups worked on in turn (hand-off latency of one tile hidden behind the others); weights = wpack_coop[0]
-void launch_lstm_pp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
-bool lstm_pp_available(const LstmWeights& w);
 // lstm_hp.hip: 16 units per workgroup (S = H / 16 workgroups per row tile, one XCD), waves split the gates, weights resident,
 // every row tile worked on as two half tiles of 16 sequences in turn (the hand-off of one half hidden behind the other)
 void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);

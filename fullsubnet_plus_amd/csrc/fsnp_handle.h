@@ -107,8 +107,6 @@ struct fsnp_handle {
     bool generic_sb = false;     // the sub-band recurrent model runs on the runtime-sized kernel (lstm_generic.hip): a hidden size or an
                                  // input width no tuned kernel is instantiated for
     bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
-    bool pp_ok = false;          // the ping-pong K-split kernel (lstm_pp.hip) exists for this handle's sub-band model
-    int coop_pp = 0, coop_pp_cfg = 0;
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
     int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0 / 1; fsnp_debug_set_lstm_coop(h, 4) = only it)   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
     int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups

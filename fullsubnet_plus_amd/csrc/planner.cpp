@@ -51,7 +51,6 @@ static const double kSplitRatio[4] = {0.85, 1.0, 1.1, 1.25};
 int chunk_workgroups(const PlannerCtx& h, const SbChunk& c) {
     if (c.kind == 1) return c.num_tiles * (h.H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
     if (c.kind == 2) return c.groups * (h.H / 128);
-    if (c.kind == 6) return cdiv(c.num_tiles, c.rpg) * (h.H / 8);
     if (c.kind == 8) return c.num_tiles * (h.H / 16);
     return c.num_tiles;
 }
@@ -74,7 +73,6 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
         return h.cost.ksplit1[ui] + (h.cost.ksplit[ui][0] - h.cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0);
     }
     if (c.kind == 2) return h.cost.coopn[c.rpg == 1 ? 0 : 1][dbl];
-    if (c.kind == 6) return h.cost.pp[(c.num_tiles < c.rpg ? c.num_tiles : c.rpg) - 1];      // a step lasts as long as the fullest group's turn
     if (c.kind == 8) {
         const int cap = h.num_cus_real / (h.H / 16);
         if (cap <= 1) return h.cost.hp[0];
@@ -113,14 +111,11 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
         if (occ == 1 && !h.gru && (h.coop_split >= 2 || (h.coop_split == 1 && !h.pipeline)))      // (3 = auto, also when pipelined: tuning)
             for (int u = 8; u <= 64; u *= 2)
                 if (h.H % u == 0 && slots / (2 * (h.H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h.H / u)), 0});
-        // ping-pong K split (lstm_pp.hip): groups of H / 8 workgroups, 1..4 row tiles per group
-        if (occ == 1 && h.pp_ok && h.coop_pp && slots / (h.H / 8) > 0)
-            for (int rpg = 1; rpg <= 4; ++rpg) shapes.push_back({6, 8, rpg, (slots / (h.H / 8)) * rpg, 0});
         // half-tile ping-pong (lstm_hp.hip): H / 16 workgroups per row tile
         if (occ == 1 && h.hp_ok && h.coop_hp && slots / (h.H / 16) > 0) shapes.push_back({8, 16, 0, slots / (h.H / 16), 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
-        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
+        SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
         return est_step_us(h, c) + 1.2;                         // + a launch (prologue / drain, amortised over ~100 steps): fewer chunks win near-ties
     };
     std::vector<double> best(T + 1, 0.0);
@@ -147,7 +142,7 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
     for (const auto& tk : taken) {
         const Shape& sh = shapes[tk.second];
         const int rows = tk.first * 32 < left ? tk.first * 32 : left;
-        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 || sh.kind == 6 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
+        SbChunk c{sh.kind, r0, rows, tk.first, 0, 32, sh.units, sh.kind == 2 ? cdiv(tk.first, sh.rpg) : 0, sh.rpg, 0, 0};
         out.push_back(c);
         r0 += rows; left -= rows;
     }
@@ -158,7 +153,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
         c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 6 || c.kind == 8) p.coop_tiles += c.num_tiles;
+        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 8) p.coop_tiles += c.num_tiles;
         p.chunks.push_back(c);
     };
     if (h.sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel

@@ -12,7 +12,8 @@ struct CostTable {
     double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
     double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
-    double pp[4];                 // ping-pong K split at 8 units (lstm_pp.hip) with 1 / 2 / 3 / 4 row tiles per group
+    double pp[4];                 // (values 20..23 of the 26-value table: the round-3 ping-pong K split lstm_pp.hip, removed in round 4; the
+                                  //  slots stay so that the table layout of fsnp_get_costs / fsnp_debug_set_costs does not move)
     double hp[2];                 // half-tile ping-pong (lstm_hp.hip, 16 units): ONE row tile, a FULL launch (num_cus / (H / 16) tiles)
     int calibrated;
 };
@@ -28,7 +29,7 @@ struct CostTable {
 // column-split, of the exchange images and barrier counters (coop_tile0).
 struct SbChunk {
     int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn, 4 = half tile (lstm16.hip: 16-row tiles, rps = 16),
-                               // 6 = ping-pong K split (lstm_pp.hip), 7 = runtime-sized (lstm_generic.hip), 8 = half-tile ping-pong (lstm_hp.hip)
+                               // (6 = the removed ping-pong K split), 7 = runtime-sized (lstm_generic.hip), 8 = half-tile ping-pong (lstm_hp.hip)
     int row0, nrows;           // sequences [row0, row0 + nrows)
     int num_tiles, ex, rps;    // tiles, VALU rows per tile, slots per tile (32 + ex)
     int units, groups, rpg;    // column-split parameters
@@ -42,10 +43,10 @@ struct SbPlan {
 // what the planner needs to know of a handle (fsnp_abi.hip: pctx)
 struct PlannerCtx {
     int H = 0, NIN = 0, num_cus = 256, num_cus_real = 256;
-    bool gru = false, sb_tcn = false, generic_sb = false, rowtile_ok = true, lstm16_ok = false, pp_ok = false, hp_ok = false;
+    bool gru = false, sb_tcn = false, generic_sb = false, rowtile_ok = true, lstm16_ok = false, hp_ok = false;
     int ih_bf16 = 0, lstm_coop = 1, coop_occ = 1;
     int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};
-    int coop_split = 1, coop_pp = 0, coop_hp = 0, pipeline = 0;
+    int coop_split = 1, coop_hp = 0, pipeline = 0;
     double composite_gain = 0.97;
     CostTable cost{};
 };

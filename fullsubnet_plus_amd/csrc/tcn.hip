@@ -670,9 +670,196 @@ __global__ __launch_bounds__(256) void tcn_gemm_sk_kernel(GemmArgs g) {
     if constexpr (EPI == EPI_PRELU_STATS) epi_stats_finish(g, s, q2, red, branch, utt, tid, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tcn_gemm_dma64_kernel (round 4): the sconv GEMM [M][512] x [257][512]^T on 64 x 64 tiles.  N = 257 on 64-wide column tiles is FIVE
+// tiles, the last one all padding but one column: at B = 32 the 128-row kernel launches 96 x 5 = 480 workgroups on 256 CUs - two
+// rounds of a 13.6 us k-loop for 1.9 rounds of work, 20 % of it multiplying zeros.  Here
+//  * the lone column N - 1 leaves the matrix pipe: the workgroups of the LAST full column tile also form its dot products on the
+//    VALU out of the A tile they hold in LDS anyway (8 FMAs and two ds_read_b128 pairs per thread and k-tile; the column's weights
+//    are staged in LDS once) - FOUR column tiles;
+//  * tiles are 64 rows: 192 x 4 = 768 workgroups = exactly 3 per CU at B = 32 (three rounds of a 6.8 us k-loop: 20.4 us of MFMA time
+//    instead of 27.2); the four waves sit 2 x 2 on the tile (one 32 x 32 accumulator each);
+//  * a k-tile is 32 deep so that a wave still issues 16 MFMAs per barrier (as the 128-row kernel); the LDS image is [row][8 k-quads],
+//    XOR-swizzled by (row >> 1) & 7 on both sides (16 consecutive rows of one k-quad cover all 64 banks); 4 DMA pieces per wave and k-tile.
+// Same operands, GroupNorm fold and float4 epilogue as tcn_gemm_dma_kernel<EPI_RESIDUAL>; the k-sum of a column runs over the same k
+// in another association, column N - 1 is summed by fp32 FMAs: equal to the 128-row kernel within rounding, not bit for bit.
+// Requirements (launch_gemm_dma64): N % 64 == 1, K % 32 == 0, lda == ldw == K (no k tail), float4-aligned C / R rows.
+constexpr int BM64 = 64, BK64 = 32;
+template <int EPI>
+__global__ __launch_bounds__(256) void tcn_gemm_dma64_kernel(GemmArgs g) {
+    constexpr int BN = 64;
+    constexpr int A_SLOTS = BM64 * 8, B_SLOTS = BN * 8, STAGE = A_SLOTS + B_SLOTS;     // float4 slots per stage (16 KiB)
+    __shared__ __attribute__((aligned(16))) float4 smem[2 * STAGE];                     // 32 KiB; the epilogue's 64 x 64 tile re-uses 16
+    __shared__ __attribute__((aligned(16))) float wx[1024];                             // weights of column N - 1 (K <= 1024)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    int row_tile_all, ntile;
+    if (!xcd_decode(blockIdx.x, g.ntiles_n, g.row_tiles_all, row_tile_all, ntile)) return;
+    const int branch = row_tile_all / g.row_tiles, row_tile = row_tile_all % g.row_tiles;
+    const int tiles_per_utt = cdiv(g.Tp, BM64);
+    const int utt = row_tile / tiles_per_utt;
+    const int t0 = (row_tile % tiles_per_utt) * BM64;
+    const int n0 = ntile * BN;
+    const int rows_valid = min(BM64, g.Tp - t0);
+    const bool xcol = ntile == g.ntiles_n - 1;          // this workgroup also owns column N - 1 = ntiles_n * 64
+
+    const EpiCtx ec = epi_ctx<EPI>(g, branch, utt);
+    const int mycol = n0 + wc * 32 + (lane & 31);
+    float cb = g.bias[branch * g.bias_bs + mycol];
+    if constexpr (EPI == EPI_RESIDUAL) cb -= ec.mr * g.c2[branch * g.c2_bs + mycol];
+
+    const float* A = g.A + branch * g.a_bs + ((long)utt * g.Tp + t0) * g.lda;
+    const float* W = g.W + branch * g.w_bs + (long)n0 * g.ldw;
+    const int a_bytes = rows_valid * g.lda * 4, w_bytes = BN * g.ldw * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, w_bytes, 0x00020000);
+
+    // DMA pieces: wave w moves A slots [128 w, 128 w + 128) and B slots [128 w, 128 w + 128).  Slot s holds row s >> 3, k-quad (s & 7) ^ swz(row)
+    const int ktiles = g.ldw / BK64;
+    int va[2], vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = (wave * 2 + i) * 64 + lane, row = sl >> 3, kq = (sl & 7) ^ ((row >> 1) & 7);
+        va[i] = row * g.lda * 4 + kq * 16;               // rows >= rows_valid: beyond a_bytes -> zeros
+        vb[i] = row * g.ldw * 4 + kq * 16;
+    }
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    auto issue = [&](int kt, int stage) {
+        float4* st = smem + stage * STAGE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + 0) * 64), 16, va[0], kt * (BK64 * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + 1) * 64), 16, va[1], kt * (BK64 * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(st + A_SLOTS + (wave * 2 + 0) * 64), 16, vb[0], kt * (BK64 * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(st + A_SLOTS + (wave * 2 + 1) * 64), 16, vb[1], kt * (BK64 * 4), 0, 0);
+    };
+    // readers: lane = (r = lane & 31, kh = lane >> 5) takes k-quad 2 kg + kh of row 32 wr + r (A) / column 32 wc + r (B)
+    const int r = lane & 31, kh = lane >> 5;
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        const int ar = wr * 32 + r, br = wc * 32 + r;
+        aoff[kg] = ar * 8 + ((kg * 2 + kh) ^ ((ar >> 1) & 7));
+        boff[kg] = A_SLOTS + br * 8 + ((kg * 2 + kh) ^ ((br >> 1) & 7));
+    }
+    // column N - 1: thread -> A slots tid and tid + 256 of a stage = rows tid >> 3 and 32 + (tid >> 3), the k-quad that sits in position tid & 7
+    const int xrow = tid >> 3, xq0 = (tid & 7) ^ ((xrow >> 1) & 7), xq1 = (tid & 7) ^ (((xrow + 32) >> 1) & 7);
+    float xacc0 = 0.f, xacc1 = 0.f;
+    if (xcol) {
+        const float* wl = g.W + branch * g.w_bs + (long)(g.ntiles_n * BN) * g.ldw;
+        for (int k = tid; k < g.K; k += 256) wx[k] = wl[k];
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+    auto k_tile = [&](int stage, int kt, int kt_next) {
+        const float4* st = smem + stage * STAGE;
+        float4 a4[4], b4[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) { a4[kg] = st[aoff[kg]]; b4[kg] = st[boff[kg]]; }
+        float4 xa0, xa1, xw0, xw1;
+        if (xcol) {
+            xa0 = st[tid]; xa1 = st[tid + 256];
+            xw0 = *reinterpret_cast<const float4*>(wx + kt * BK64 + xq0 * 4);
+            xw1 = *reinterpret_cast<const float4*>(wx + kt * BK64 + xq1 * 4);
+        }
+        if (kt_next < ktiles) issue(kt_next, stage ^ 1);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].x, b4[kg].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].y, b4[kg].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].z, b4[kg].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kg].w, b4[kg].w, acc, 0, 0, 0);
+        }
+        if (xcol) {
+            xacc0 = fmaf(xa0.x, xw0.x, xacc0); xacc0 = fmaf(xa0.y, xw0.y, xacc0); xacc0 = fmaf(xa0.z, xw0.z, xacc0); xacc0 = fmaf(xa0.w, xw0.w, xacc0);
+            xacc1 = fmaf(xa1.x, xw1.x, xacc1); xacc1 = fmaf(xa1.y, xw1.y, xacc1); xacc1 = fmaf(xa1.z, xw1.z, xacc1); xacc1 = fmaf(xa1.w, xw1.w, xacc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    issue(0, 0);
+    __syncthreads();                                   // (also: wx is staged)
+    asm volatile("" : "+a"(acc));
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        k_tile(0, kt, kt + 1);
+        if (kt + 1 < ktiles) k_tile(1, kt + 1, kt + 2);
+        asm volatile("" : "+a"(acc));
+    }
+
+    // ---- epilogue: the 64 x 64 tile through LDS (all four waves write, then wave w owns rows 16 w ... 16 w + 15 as float4s)
+    float* C = g.C + branch * g.c_bs + ((long)utt * g.Tp) * g.ldc;
+    double s = 0.0, q2 = 0.0;
+    EpiF4<EPI, 16> ef;
+    ef.init(g, n0, lane);
+    ef.load_residual(g, branch, utt, t0 + wave * 16);
+    // column N - 1: the 8 threads that share a row add their partial dot products (lanes 8 i ... 8 i + 7 of a wave)
+    float xr0 = 0.f, xr1 = 0.f;
+    const int xcolumn = g.ntiles_n * BN;
+    if (xcol) {
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { xacc0 += __shfl_xor(xacc0, m); xacc1 += __shfl_xor(xacc1, m); }
+        if constexpr (EPI == EPI_RESIDUAL) {
+            if ((tid & 7) == 0) {
+                const float* Rp = g.R + branch * g.r_bs + ((long)utt * g.Tp) * g.ldr + xcolumn;
+                if (t0 + xrow < g.Tp) xr0 = Rp[(long)(t0 + xrow) * g.ldr];
+                if (t0 + xrow + 32 < g.Tp) xr1 = Rp[(long)(t0 + xrow + 32) * g.ldr];
+            }
+        }
+    }
+    float* tile = reinterpret_cast<float*>(smem);
+    {
+        const bool col_ok = mycol < g.N;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rl = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const bool counted = col_ok && t0 + wr * 32 + rl < g.Tp;
+            tile[(wr * 32 + rl) * 64 + wc * 32 + (lane & 31)] = epi_stage_value<EPI>(ec, acc[q], cb, g.act, counted, s, q2);
+        }
+    }
+    __syncthreads();
+    ef.store(g, tile + wave * 16 * 64, C, t0 + wave * 16, lane);
+    if (xcol && (tid & 7) == 0) {
+        float cx = g.bias[branch * g.bias_bs + xcolumn];
+        if constexpr (EPI == EPI_RESIDUAL) cx -= ec.mr * g.c2[branch * g.c2_bs + xcolumn];
+        double sd = 0.0, qd = 0.0;
+        float v0 = epi_stage_value<EPI>(ec, xacc0, cx, g.act, false, sd, qd) + xr0;
+        float v1 = epi_stage_value<EPI>(ec, xacc1, cx, g.act, false, sd, qd) + xr1;
+        if constexpr (EPI == EPI_RESIDUAL) { if (g.relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); } }
+        // the float4 at column N - 1 = {value, 0, 0, 0}: columns [N, ldc) are the zero pad the next GEMM's DMA reads
+        if (t0 + xrow < g.Tp) *reinterpret_cast<float4*>(C + (long)(t0 + xrow) * g.ldc + xcolumn) = make_float4(v0, 0.f, 0.f, 0.f);
+        if (t0 + xrow + 32 < g.Tp) *reinterpret_cast<float4*>(C + (long)(t0 + xrow + 32) * g.ldc + xcolumn) = make_float4(v1, 0.f, 0.f, 0.f);
+    }
+}
+
+// launched (true) when the 64-row kernel applies AND beats the 128-row kernel's round count
+template <int EPI>
+static bool launch_gemm_dma64(const GemmArgs& g, int n, int num_cus, hipStream_t s, int branches) {
+    if constexpr (EPI != EPI_RESIDUAL) return false;      // (sconv only: conv1x1 and the final Linear have K = 257 -> a 16-deep k tail)
+    else {
+    static const int on = [] { const char* e = getenv("FSNP_GEMM_BM64"); return e && e[0] == '0' ? 0 : 1; }();
+    if (!on) return false;
+    if (n % 64 != 1 || g.K % BK64 || g.lda != g.K || g.ldw != g.K || g.K > 1024 || g.a_us || g.a_cols) return false;
+    if (g.ldc % 4 || g.ldc < n + 3 || g.ldr % 4) return false;            // the float4 {column N - 1, three pad columns}
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W) | reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.R)) & 15) return false;
+    if ((g.a_bs * 4) % 16 || (g.w_bs * 4) % 16 || (g.c_bs * 4) % 16 || (g.r_bs * 4) % 16) return false;
+    if ((long)BM64 * g.lda * 4 >= (1L << 31) || (long)64 * g.ldw * 4 >= (1L << 31)) return false;
+    GemmArgs ga = g;
+    ga.ntiles_n = n / 64;
+    ga.row_tiles = cdiv(g.Tp, BM64) * g.B; ga.row_tiles_all = ga.row_tiles * branches;
+    // rounds of k-loop time, in units of a 64-row tile: the 128-row kernel's workgroups cost two
+    const long wg64 = (long)ga.ntiles_n * ga.row_tiles_all, wg128 = (long)cdiv(n, 64) * cdiv(g.Tp, BM) * g.B * branches;
+    const long cost64 = (wg64 + num_cus - 1) / num_cus, cost128 = 2 * ((wg128 + num_cus - 1) / num_cus);
+    if (cost64 > cost128) return false;
+    hipLaunchKernelGGL((tcn_gemm_dma64_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
+    return true;
+    }
+}
+
 // true (and launched) when the DMA kernel's requirements hold
 template <int EPI>
-static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches, bool allow_splitk) {
+static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches, bool allow_splitk, bool allow_bm64 = false) {
     if (g.a_us || g.a_cols || g.lda % 4 || g.ldw % BK || g.ldw < g.K || g.lda < g.K) return false;
     if (g.ldw - g.lda >= BK) return false;                 // only the LAST k-tile may reach beyond a row of A
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15 || (g.a_bs * 4) % 16 || (g.w_bs * 4) % 16) return false;
@@ -692,6 +879,7 @@ static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus
         hipLaunchKernelGGL((tcn_gemm_sk_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
         return true;
     }
+    if (allow_bm64 && launch_gemm_dma64<EPI>(g, n, num_cus, s, branches)) return true;
     hipLaunchKernelGGL((tcn_gemm_dma_kernel<EPI>), dim3(xcd_grid(ga.ntiles_n, ga.row_tiles_all)), dim3(256), 0, s, ga);
     return true;
 }
@@ -860,7 +1048,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
             gf.W = w.w2g + (long)blk * w.N2P * w.K2P;
             gf.bias = w.c1 + (long)blk * w.N2P;
             gf.c2 = w.c2 + (long)blk * w.N2P; gf.c2_bs = (long)w.NB * w.N2P;
-            if (!(dma && w.w2g && launch_gemm_dma<EPI_RESIDUAL>(gf, d.F, row_tiles, w.num_cus, s, branches, w.gemm_dma == 1)))
+            if (!(dma && w.w2g && launch_gemm_dma<EPI_RESIDUAL>(gf, d.F, row_tiles, w.num_cus, s, branches, w.gemm_dma == 1, w.gemm_dma != 3)))
                 launch_gemm<PRO_GN, EPI_RESIDUAL>(g, d.F, row_tiles, w.num_cus, s, branches);
         }
         if (blk == 0 && buf.dbg_tcn0)

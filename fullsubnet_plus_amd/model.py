@@ -460,15 +460,16 @@ class _HipModel(nn.Module):
 
     def debug_set_lstm_coop(self, mode, device="cuda"):
         """Tuning hook: 1 = use the column-split LSTM kernels for small batches (default), 0 = never, 2 = as 1 with the
-        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one, 3 = as 1 + the opt-in ping-pong
-        K split (csrc/lstm_pp.hip) where the cost table prefers it."""
+        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one, 4 = as 1 + the half-tile ping-pong
+        kernel even where FSNP_COOP_HP=0 (3 = 1: it selected the ping-pong K split removed in round 4)."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
         self.__dict__["_lstm_coop_mode"] = int(mode)
 
     def debug_set_gemm_dma(self, mode, device="cuda"):
         """Tuning hook: 1 = full-band TCN GEMMs on the LDS-DMA kernels with GroupNorm folded into the weights (default; small
-        batches: the split-K kernel tcn_gemm_sk_kernel), 2 = as 1 but never the small-batch kernel, 0 = the general GEMM kernel."""
+        batches: the split-K kernel tcn_gemm_sk_kernel; sconv of larger problems: the 64-row kernel tcn_gemm_dma64_kernel), 2 = as 1 but
+        never the small-batch kernel, 3 = the 128-row DMA kernel only, 0 = the general GEMM kernel."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_gemm_dma(self._handle, int(mode)), "fsnp_debug_set_gemm_dma")
 
@@ -522,8 +523,7 @@ class _HipModel(nn.Module):
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
                  5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
-                 12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)",
-                 **{6 + r: f"lstm2_coop_pp_kernel (K split, fused phase, {r} row tile{'s' if r > 1 else ''} per group in turn)" for r in (1, 2, 3, 4)}}
+                 12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)"}
         prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}
         return [{"kernel": names[buf[6 * i]], "sequences": buf[6 * i + 1], "tiles": buf[6 * i + 2], "valu_rows": buf[6 * i + 3],
                  "precision": prec[buf[6 * i + 4]], "workgroups": buf[6 * i + 5]} for i in range(n)]

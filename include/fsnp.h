@@ -207,9 +207,8 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
  *  half-tile: 16-row tiles, csrc/lstm16.hip, 5 = lstm2_coop_split K-split with one workgroup set per layer: planned for 1-2 row
- *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never, 7..10 = lstm2_coop_pp K-split at 8 units
- *  with the two layers fused into one phase and 1..4 row tiles per group of H / 8 workgroups worked on in turn, csrc/lstm_pp.hip;
- *  opt-in: FSNP_COOP_PP=1; 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
+ *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never; (7..10 were the round-3 ping-pong
+ *  K split csrc/lstm_pp.hip, removed in round 4;) 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
  *  gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row tiles;
  *  FSNP_COOP_HP=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
@@ -258,11 +257,9 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
 double fsnp_forward_flops(const fsnp_handle* h, int32_t batch, int32_t frames, int32_t mode);
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps);
 
-/* Profiling hook of the ping-pong K-split kernel (csrc/lstm_pp.hip): num_seq sequences as ONE launch with tiles_per_group row
- * tiles per group; workgroup 0 stamps the 100 MHz wall clock at 7 points of every tile-phase (0 pass start, 1 MFMA pass done,
- * 2 past the barrier, 3 partial tiles in LDS, 4 cell phase done, 5 past the barrier, 6 published / next operands issued) and
- * [7] = 1 if the next tile-phase's operands were fetched early.  host_stamps: steps * tiles_per_group * 8 values.  Synchronises.
- * tiles_per_group = 0: the half-tile ping-pong kernel (csrc/lstm_hp.hip) instead - steps * 2 * 16 stamps per (step, half): 0 phase start,
+/* Profiling hook of the half-tile ping-pong kernel (csrc/lstm_hp.hip): num_seq sequences as ONE launch; workgroup 0 stamps the
+ * 100 MHz wall clock.  tiles_per_group must be 0 (1..4 selected the round-3 ping-pong K-split kernel, removed in round 4).
+ * host_stamps: steps * 2 * 16 values per (step, half): 0 phase start,
  * 1 operands in LDS, 2 / 3 before / after the deferred arrival inside the pass, 4 MFMA pass done, 5 pre-activations exchanged,
  * 6 cells done, 7 past the barrier, 8 published / next operands issued, [15] = 1 if the next half-phase was fetched early. */
 int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
@@ -318,8 +315,8 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
                                                                   schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0);
-                                                                  3 = as 1 + the planner may use the opt-in ping-pong K split (csrc/lstm_pp.hip,
-                                                                  also FSNP_COOP_PP=1 at fsnp_create time);
+                                                                  3 = 1 (selected the ping-pong K split csrc/lstm_pp.hip until
+                                                                  round 4 removed it);
                                                                   4 = as 1 + the planner may use the half-tile ping-pong kernel
                                                                   (csrc/lstm_hp.hip, also FSNP_COOP_HP=1 at fsnp_create time) */
 /* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
@@ -327,7 +324,8 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but t
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
  * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it).  Small batches (at most 6 workgroups per CU
  * on 32-row tiles: B <= 16 at 2 s clips) run the same GEMMs on tcn_gemm_sk_kernel - 32 x 64 tiles whose four waves split K, no
- * workgroup barrier in the k-loop (FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never); mode 2 = as 1 but never that kernel. */
+ * workgroup barrier in the k-loop (FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never) and the sconv GEMMs of larger problems
+ * on the 64-row kernel (FSNP_GEMM_BM64=0: never); mode 2 = as 1 but never the split-K kernel; mode 3 = the 128-row DMA kernel only. */
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
 /* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
  * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph

@@ -180,44 +180,6 @@ def test_role_split_k_split_equals_serial_schedule(n, steps):
 _SERIAL_8_UNITS_COSTS = [5.0, 900.0] + [900.0] * 6 + [900.0] * 4 + [900.0, 0.11] + [5.0, 900.0, 900.0, 900.0] + [900.0, 0.0] + [1e9] * 4
 
 
-def _pp_only_costs(r):
-    """A cost table (fsnp_get_costs layout) under which every column-split launch is the ping-pong K split with r tiles per group."""
-    pp = [900.0] * 4
-    pp[r - 1] = 5.0
-    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + pp
-
-
-@pytest.mark.parametrize("n,steps,r", [(16, 1, 1), (32, 2, 1), (32, 300, 1), (33, 3, 2), (64, 25, 2), (257, 41, 2), (257, 9, 3),
-                                       (300, 7, 4), (514, 9, 4), (160, 128, 2), (640, 5, 4), (96, 11, 3)])
-def test_ping_pong_k_split_equals_serial_schedule(n, steps, r):
-    """csrc/lstm_pp.hip: lstm2_coop_pp_kernel fuses layer 1 of step t and layer 0 of step t + 1 into ONE pass over h0_t (one LDS
-    reduction, one cell phase for both layers), gives a group of H / 8 workgroups r independent row tiles to work on in turn
-    (the hand-off of one tile is in flight while the others compute, deferred arrival by the storing wave) and publishes h with
-    16-byte write-through stores from an LDS staging buffer.  Same k order in every accumulator, same operand order in every
-    sum: bit-identical to the serial K-split schedule, for 1, 2, 3 and many steps, ragged tiles, partially filled groups
-    (257 sequences = 9 tiles = groups of 2, 2, 2, 2, 1; 514 = 17 tiles at r = 4), a full launch (640 = 20 tiles = 5 groups of 4)."""
-    sd = make_state_dict(9, "harsh")
-    m = _model(DEFAULT_MODEL_ARGS, sd)
-    rng = np.random.Generator(np.random.PCG64(4242 + n + steps))
-    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
-    m.lstm2_fc(x[:1])
-    m.debug_set_lstm_coop(2)                  # serial schedule, no role split, no ping-pong ...
-    m.debug_set_costs(_SERIAL_8_UNITS_COSTS, 1)    # ... at 8 units per workgroup (launches of <= 5 row tiles): the Linear's partial
-    assert all(c["kernel"].startswith("lstm2_coop_kernel") for c in m.describe_plan(1))    # sums are per workgroup, so only equal widths are bit-comparable
-    serial = m.lstm2_fc(x).cpu().numpy()
-    m.check_errors()
-    m.debug_set_lstm_coop(3)                  # (the ping-pong kernel is opt-in: FSNP_COOP_PP=1 / mode 3)
-    m.debug_set_costs(_pp_only_costs(r), 1)
-    assert any(c["kernel"].startswith("lstm2_coop_pp_kernel") for c in m.describe_plan(1)) or r < 2
-    pp = m.lstm2_fc(x).cpu().numpy()
-    m.check_errors()
-    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
-    assert rel_err(pp, want) < 2e-5
-    assert np.array_equal(pp, serial), float(np.abs(pp - serial).max())
-    for _ in range(3):
-        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), pp)
-
-
 def _hp_only_costs():
     """A cost table (fsnp_get_costs layout, 26 values) under which every column-split launch is the half-tile ping-pong kernel."""
     return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0]
@@ -728,6 +690,16 @@ def test_dma_gemm_equals_general_gemm(profile, B, T):
     assert e_big < TOL and rel_err(big_tiles, fast) < 1e-4
     splitk = 8 * (-(-(mag.shape[-1] + 2) // 32)) * B * 3 <= 6 * 256       # csrc/tcn.hip launch_gemm_dma: at most 6 workgroups per CU
     assert np.array_equal(big_tiles, fast) != splitk, splitk              # another k order where the split-K kernel ran, the same kernel elsewhere
+    # mode 3 = the 128-row kernel for every GEMM; modes 1 / 2 run the sconv GEMMs on 64-row tiles (tcn_gemm_dma64_kernel: four column
+    # tiles + column 256 on the VALU) wherever that needs no more rounds of workgroups (csrc/tcn.hip launch_gemm_dma64)
+    m.debug_set_gemm_dma(3)
+    only128 = m(*g).cpu().numpy()
+    m.debug_set_gemm_dma(1)
+    _record(f"dma_gemm_{profile}_B{B}_T{T}_128_row_only", rel=rel_err(only128, want), rel_vs_mode2=rel_err(only128, big_tiles))
+    assert rel_err(only128, want) < TOL and rel_err(only128, big_tiles) < 1e-4
+    Tp = mag.shape[-1] + 2
+    cost64, cost128 = -(-(4 * (-(-Tp // 64)) * B * 3) // 256), 2 * (-(-(5 * (-(-Tp // 128)) * B * 3) // 256))
+    assert np.array_equal(only128, big_tiles) != (cost64 <= cost128), (cost64, cost128)
 
 
 def test_b32_10s_full_vs_oracle():

@@ -532,22 +532,13 @@ def test_column_split_kernels_keep_their_asm_invariants():
 
 
 def test_round3_kernels_keep_their_asm_invariants():
-    """Static checks of the round-3 kernels (tools/check_lstm_asm.py).  lstm2_coop_pp_kernel: no scratch, no cache maintenance, the
-    exchange images are written with 16-byte sc1 stores and read with 16-byte sc1 loads, and every
-    MFMA of the time loop takes its weights from an AGPR (the pinning survived the compiler).  lstm2_coop_hp_kernel: exactly the
+    """Static checks of the round-3 kernels (tools/check_lstm_asm.py).  lstm2_coop_hp_kernel: exactly the
     16x16x4 MFMAs of two unrolled half-phases, layer-1 weights from AGPRs, operands by LDS DMA, 16-byte sc1 stores, DPP row sums, no
     scratch.  lstm2_generic_kernel: plain FMAs, no MFMA, no scratch."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    pp = mod.analyse_ping_pong()
-    assert len(pp) == 16, sorted(pp)                          # H 256 / 384 x K 40 / 64 x 1..4 tiles per group
-    for name, r in pp.items():
-        assert r["scratch"] == 0 and r["cache_maint"] == 0, (name, r)
-        # (the only dword sc1 stores left are the abort / error words of the bounded waits: two per wait site, 3 + 2 R sites)
-        assert r["sc1_stores16"] >= 3 and r["sc1_loads16"] >= 16 and r["sc1_stores4"] <= 2 * (3 + 2 * int(re.search(r"ELi(\d)EEEv", name).group(1))), (name, r)
-        assert r["mfma"] >= 100 and r["mfma_b_in_agpr"] >= 0.9 * r["mfma"], (name, r)
     hp = mod.analyse_half_tile_ping_pong()
     assert len(hp) == 4, sorted(hp)                           # H 256 / 384 x K 40 / 64
     for name, r in hp.items():
@@ -673,18 +664,9 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100, 1000, 0]      # K split suddenly slow: 9 tiles move
     p = plan(257, 1, slow_k)
     assert p[0]["kind"] == 2
-    # the opt-in ping-pong K split (kernel 6: groups of 48 workgroups, 1..4 row tiles per group): planned where the table says
-    # it pays, never beyond 5 groups x tiles-per-group row tiles per launch
+    # (kernel 6, the round-3 ping-pong K split, was removed in round 4: however cheap its four table slots are made, it is never planned)
     cheap_pp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 9, 11, 15, 19]
-    p = plan(257, 1, cheap_pp)                   # 9 tiles: two per group on 5 groups
-    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["rpg"] == 2 and p[0]["par"] == 5 and p[0]["tiles"] == 9
-    p = plan(32, 1, cheap_pp)
-    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["tiles"] == 1
-    p = plan(640, 1, cheap_pp)                   # 20 tiles: one launch of 5 groups x 4
-    assert len(p) == 1 and p[0]["kind"] == 6 and p[0]["rpg"] == 4 and p[0]["par"] == 5
-    for c in plan(1285, 1, cheap_pp):            # 41 tiles: several launches, each within its capacity
-        assert c["kind"] != 6 or (c["par"] <= 5 and c["par"] * c["rpg"] >= c["tiles"])
-    assert all(c["kind"] != 6 for rows in (32, 257, 640, 8224) for c in plan(rows, 1))      # built-in plans: never
+    assert all(c["kind"] != 6 for rows in (32, 257, 640, 1285, 8224) for c in plan(rows, 1, cheap_pp))
     # the half-tile ping-pong kernel (kernel 8: 24 workgroups per row tile, at most 10 row tiles per launch)
     cheap_hp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 1e9, 1e9, 1e9, 1e9, 9, 11]
     p = plan(257, 1, cheap_hp)

@@ -68,26 +68,6 @@ def analyse_column_split(flags=("-fno-slp-vectorize",)):
     return res
 
 
-def analyse_ping_pong(flags=("-fno-slp-vectorize",)):
-    """Whole-kernel invariants of lstm2_coop_pp_kernel (lstm_pp.hip), per instantiation: MFMAs, how many of them take their B operand
-    (the weights) from an AGPR (`v_mfma ... a[..], v, a, a[..]`: the weights are pinned there so that the VGPRs hold a whole tile-phase
-    of A fragments), scratch, cache maintenance, 16-byte sc1 stores / loads of the exchange images, dword sc1 stores (must be none)."""
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "lstm_pp.hip")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
-                       check=True, capture_output=True)
-        text = open(out).read()
-    res = {}
-    for m in re.finditer(r"^(_ZN4fsnp20lstm2_coop_pp_kernelI\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):      # (early returns: several s_endpgm)
-        name, body = m.group(1), m.group(2).split("\n")
-        cnt = lambda pat: sum(1 for x in body if re.search(pat, x))
-        res[name] = dict(mfma=cnt(r"v_mfma"), mfma_b_in_agpr=cnt(r"v_mfma_f32_32x32x2_f32 a\[\d+:\d+\], v\d+, a\d+, a\["), scratch=cnt(r"scratch_"),
-                         cache_maint=cnt(r"buffer_wbl2|buffer_inv"), sc1_loads16=cnt(r"buffer_load_dwordx4.*sc1"),
-                         sc1_stores16=cnt(r"buffer_store_dwordx4.*sc1"), sc1_stores4=cnt(r"(global|buffer)_store_dword\b.*sc1"))
-    return res
-
-
 def analyse_half_tile_ping_pong(flags=("-fno-slp-vectorize",)):
     """Whole-kernel invariants of lstm2_coop_hp_kernel (lstm_hp.hip), per instantiation: 16x16x4 MFMAs (and how many take their B
     operand - a resident weight - from an AGPR), scratch, cache maintenance, LDS-DMA operand loads (sc1), 16-byte sc1 stores of the

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the ping-pong K-split kernel (csrc/lstm_pp.hip) from wall-clock stamps (fsnp_debug_pp_profile).
+"""Phase breakdown of the half-tile ping-pong kernel (csrc/lstm_hp.hip) from wall-clock stamps (fsnp_debug_pp_profile; until round 4 also of the
+ping-pong K-split kernel lstm_pp.hip, since removed - its profile is profiles/r03_pp_phase_profile.txt).
 usage: python tools/pp_phase_profile.py <sequences> <steps> <tiles per group>     (tiles per group 0 = the half-tile ping-pong kernel, csrc/lstm_hp.hip)"""
 import json
 import os
