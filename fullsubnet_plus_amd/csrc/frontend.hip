@@ -164,11 +164,12 @@ __global__ __launch_bounds__(256) void fe_scan_kernel(const double* __restrict__
 
 // frames per workgroup of fe_fsum_kernel: 32 with many utterances, fewer with few (B = 1: 12 workgroups took 13 us)
 static int fsum_rows_per_wg(int B) { return B >= 8 ? 32 : B >= 4 ? 16 : B >= 2 ? 8 : 4; }
-__global__ __launch_bounds__(256) void fe_fsum_kernel(const float* __restrict__ raw, const NormMD* __restrict__ md,
+// (blockDim = the smallest multiple of 64 that covers F up to 512: see sb_offline_stats_kernel)
+__global__ __launch_bounds__(512) void fe_fsum_kernel(const float* __restrict__ raw, const NormMD* __restrict__ md,
                                                       double* __restrict__ fsum, int B, int Tp, int F, int FP, int rows) {
     const long ub = (long)blockIdx.z * B + blockIdx.y;
     const int t0 = blockIdx.x * rows, t1 = min(t0 + rows, Tp);
-    for (int f = threadIdx.x; f < F; f += 256) {
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
         double s = 0.0;
         for (int t = t0; t < t1; ++t) {
             const NormMD r = md[ub * Tp + t];
@@ -408,7 +409,8 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
     const int frows = fsum_rows_per_wg(d.B);
-    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 3), dim3(256), 0, s, buf.raw, buf.md, buf.fsum,
+    const int fthreads = d.F <= 256 ? 256 : d.F >= 512 ? 512 : (d.F + 63) / 64 * 64;
+    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 3), dim3(fthreads), 0, s, buf.raw, buf.md, buf.fsum,
                        d.B, d.Tp, d.F, d.FP, frows);
     GateArgs g;
     g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;

@@ -35,15 +35,17 @@ __device__ __forceinline__ NormMD sb_norm_md(int norm_type, double sum, double s
 // frames per workgroup: 16 with many utterances; fewer with few, so that a small batch still launches >= ~64 workgroups (B = 1: 8
 // workgroups took 25 us, latency-bound)
 static int sb_rows_per_wg(int B) { return B >= 8 ? 16 : B >= 4 ? 8 : B >= 2 ? 4 : 2; }
-__global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
+// blockDim = the smallest multiple of 64 that covers F up to 512 (F = 257: 320): with 256 threads, frequency 256 was a second pass of
+// thread 0 alone and the whole workgroup waited for it (24 us at B = 1 for 17 MB of reads)
+__global__ __launch_bounds__(512) void sb_offline_stats_kernel(const float* __restrict__ att_mag,
                                                                const float* __restrict__ fb, long fb_bs, int nfb,
                                                                const float* __restrict__ refl_w,
                                                                const float* __restrict__ refl_wfb,
                                                                double* __restrict__ acc, int Tp, int F, int FP, int rows) {
-    __shared__ double red[8];
+    __shared__ double red[16];
     const int b = blockIdx.y, t0 = blockIdx.x * rows, t1 = min(t0 + rows, Tp);
     double s = 0.0, q = 0.0;
-    for (int f = threadIdx.x; f < F; f += 256) {
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
         const double wr = refl_w[f], wfb = refl_wfb[f];
         for (int t = t0; t < t1; ++t) {
             const long i = ((long)b * Tp + t) * FP + f;
@@ -63,8 +65,10 @@ __global__ __launch_bounds__(256) void sb_offline_stats_kernel(const float* __re
     if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(acc + b * 2, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(acc + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+        double ts = 0.0, tq = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += red[w * 2]; tq += red[w * 2 + 1]; }
+        atomicAdd(acc + b * 2, ts);
+        atomicAdd(acc + b * 2 + 1, tq);
     }
 }
 
@@ -128,7 +132,8 @@ void launch_subband_stats(const Dims& d, int norm_type, const SubbandBuffers& bu
     const long fb_bs = (long)d.B * d.Tp * d.FP;
     if (norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
         const int rows = sb_rows_per_wg(d.B);
-        hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, rows), d.B), dim3(256), 0, s, buf.att_mag, buf.fb,
+        const int threads = d.F <= 256 ? 256 : d.F >= 512 ? 512 : (d.F + 63) / 64 * 64;
+        hipLaunchKernelGGL(sb_offline_stats_kernel, dim3(cdiv(d.Tp, rows), d.B), dim3(threads), 0, s, buf.att_mag, buf.fb,
                            fb_bs, (d.NIN - d.NSB) / (2 * buf.NFBN + 1), buf.refl_w, buf.refl_wfb, buf.acc, d.Tp, d.F, d.FP, rows);
         hipLaunchKernelGGL(sb_offline_final_kernel, dim3(cdiv(d.B, 64)), dim3(64), 0, s, buf.acc, buf.md_utt, d.B,
                            (double)d.F * d.NIN * d.Tp, norm_type);

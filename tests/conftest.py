@@ -24,7 +24,7 @@ _FIRST = ("test_forward_from_plain_c", "test_c_abi_argument_errors_are_loud", "t
           "test_forward_sharded_two_ranks_equals_single_process", "test_forward_sharded_over_rccl_world_size_1",
           "test_bench_under_torchrun_initialises_rccl_at_world_size_1", "test_sharded_parity_mode_on_one_gpu")
 _LAST = ("test_column_split_exchange_under_load", "test_column_split_kernels_under_drift", "test_long_recurrence_kernels",
-         "test_long_recurrence_forward")
+         "test_dense_input_beyond_2gib_is_not_read_as_zeros", "test_long_recurrence_forward")
 
 
 def _gpu_rank(item):

@@ -115,6 +115,33 @@ def test_long_recurrence_kernels(n, steps):
     assert per_step.max() < 2e-5, (per_step.max(), int(per_step.argmax()))
 
 
+def test_dense_input_beyond_2gib_is_not_read_as_zeros():
+    """the half-tile ping-pong kernel (planned for 6..10 row tiles) addresses its input through ONE buffer descriptor with
+    32-bit BYTE offsets (2 GiB); rows that start beyond that used to be read as zeros - out of the descriptor's range - with no
+    error.  257 sequences x 62,000 steps x 34 features x 4 bytes = 2.17 GB: the planner now keeps that kernel away from such
+    inputs (fsnp_abi.hip plan_sb: gather_bytes), and the LAST rows - the ones past 2 GiB - match the oracle."""
+    n, steps = 257, 62000
+    sd = make_state_dict(9, "default")
+    m = _model(sd)
+    x = _dense_input(n, steps, 77)
+    assert x.numel() * 4 > 2 ** 31
+    out = m.lstm2_fc(x)
+    m.check_errors()
+    sel = [0, 128, 250, 255, 256]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        want = fsnp_torch.lstm2_fc(x[sel].cpu(), sd).numpy()
+    finally:
+        torch.set_num_threads(threads)
+    got = out[sel].cpu().numpy()
+    per_row = np.abs(got - want).max(axis=(1, 2)) / np.abs(want).max()
+    assert per_row.max() < 2e-5, per_row
+    small = m.lstm2_fc(x[:, :, :64].contiguous())          # the same handle still plans the half-tile ping-pong kernel for small inputs
+    assert any("hp" in c["kernel"] for c in m.describe_plan(1))
+    assert torch.equal(small[:, :, :8], out[:, :, :8]) or rel_err(small[:, :, :8].cpu().numpy(), out[:, :, :8].cpu().numpy()) < 2e-5
+
+
 STAGES = ["att_mag", "att_real", "att_imag", "fb_mag", "fb_real", "fb_imag"]
 
 
