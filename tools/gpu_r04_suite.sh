@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 sum0=$(cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h | sha256sum | cut -c1-16)
 {
-  echo "commit: $(cat gpurun_out/.head 2>/dev/null || echo unknown)   csrc sha256[:16] at start: $sum0   library stamp: $(cat fullsubnet_plus_amd/libfsnp_hip.so.stamp | cut -c1-16)"
+  echo "commit: ${FSNP_HEAD:-unknown}   csrc sha256[:16] at start: $sum0   library stamp: $(cat fullsubnet_plus_amd/libfsnp_hip.so.stamp | cut -c1-16)"
   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 2>&1 | tail -45
   sum1=$(cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h | sha256sum | cut -c1-16)
   echo "csrc sha256[:16] at end: $sum1"
