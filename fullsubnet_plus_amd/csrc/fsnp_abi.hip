@@ -1151,6 +1151,7 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
         // sequences that the plan hands to any other kernel run in fp32 whatever fsnp_set_precision says
         int prec = 0;
         if (!h->sb_tcn && !h->gru && c.kind == 0) prec = h->ih_bf16 == 1 ? 1 : (h->ih_bf16 == 2 && c.ex == 0) ? 2 : 0;
+        if (!h->sb_tcn && !h->gru && c.kind == 4 && h->ih_bf16 == 1 && h->lw.wpack16_bf) prec = 1;       // half-tile kernel: bf16 ih-GEMM too (round 4)
         out[6 * i + 4] = prec;
         out[6 * i + 5] = h->sb_tcn ? 0 : chunk_workgroups(h, c);
     }

@@ -159,6 +159,7 @@ struct LstmWeights {
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
     const float* wpack16;       // half-tile kernel (lstm16.hip): [wave][k-group of 16][24 tiles of 16 columns][lane][4]
+    const float* wpack16_bf;    // its bf16-ih stream: layer-1 W_ih as bf16 k-steps of 32 (configs[4]); nullptr = not packed
     const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     const float* wpack_hp;      // half-tile ping-pong kernel (lstm_hp.hip): [column slice of 16 units][gate][k-group of 16][lane][4]
@@ -219,6 +220,8 @@ void launch_lstm(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 // lstm16.hip: the same decomposition on 16-row tiles (v_mfma_f32_16x16x4_f32): 4096 sequences per round of 256 workgroups
 void launch_lstm16(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t lstm16_pack_floats(int H, int KX);
+size_t lstm16_pack_floats_bf16ih(int H, int KX);
+void lstm16_pack_weights_bf16ih(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack);
 void lstm16_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack);
 // lstm_bf3.hip: the same decomposition with every fp32 product emulated by three bf16 MFMAs (optional precision mode 2)
 void launch_lstm_bf3(const LstmWeights& w, const LstmArgs& a, hipStream_t s);

@@ -312,10 +312,16 @@ int fsnp_commit_weights(fsnp_handle* h) {
                                      blob.data() + o_wpack_bf[i]);
         }
     }
-    size_t o_wpack16 = 0;
+    size_t o_wpack16 = 0, o_wpack16_bf = 0;
+    bool have16_bf = false;
     if (h->lstm16_ok) {
         o_wpack16 = alloc(lstm16_pack_floats(H, h->KX));
         lstm16_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack16);
+        if (h->KX == 40 && H == 384) {                 // bf16-ih stream of the half-tile kernel (configs[4], round 4)
+            o_wpack16_bf = alloc(lstm16_pack_floats_bf16ih(H, h->KX));
+            lstm16_pack_weights_bf16ih(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack16_bf);
+            have16_bf = true;
+        }
     }
     size_t o_wpack_bf3 = 0;
     if (!h->gru && tuned && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
@@ -402,6 +408,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack_bf3 = d + o_wpack_bf3;
     h->lw.wpack16 = d + o_wpack16;
+    h->lw.wpack16_bf = have16_bf ? d + o_wpack16_bf : nullptr;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
     h->lw.H = H; h->lw.NIN = h->NIN; h->lw.KX = h->KX; h->lw.OUT = h->cfg.output_size; h->lw.gru = h->gru;
     h->lw.wgen = d + o_wgen;

@@ -11,6 +11,8 @@
 // = 24 accumulator tiles of 16 columns (96 registers; i / f / g / o of a (row, unit) share lane and register index: lane-local
 // cell update, c in registers).  Cost: one 1 KiB weight fragment feeds 4 MFMAs of 32 cycles instead of 4 of 64, so the
 // fragment loads weigh twice as much per matrix-pipe cycle as in lstm.hip (measured: profiles/r02_column_split.md).
+#include <cstring>
+
 #include "fsnp_common.h"
 #include "lstm_common.h"
 
@@ -62,9 +64,44 @@ __device__ __forceinline__ void groups16(f32x4 (&acc)[NT], float4 (&b)[NT], cons
     }
 }
 
+// ---- bf16 ih-GEMM segment (BASELINE.json configs[4], round 4: the half-tile kernel too, so that `bf16_ih` means the same thing at
+// B = 16 / parity-mode B = 32 as at the chip-filling batch): layer 1's W_ih1 . h0_t as HID / 32 k-steps of ONE
+// v_mfma_f32_16x16x32_bf16 per tile (fp32 accumulate into the same tiles), operands = a bf16 A image of h0_t in LDS and bf16 weight
+// fragments that travel through the same 16-byte-per-lane register pipeline as the fp32 groups (a k-step of 32 is NT KiB per wave,
+// exactly one fp32 k-group's worth).  A / B operand: lane l holds the 8 elements k = 32 ks + 8 (l >> 4) + j of row / column l & 15.
+using bf16x8_16 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ unsigned short bf16_bits16(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);           // round to nearest even
+}
+// index (in 2-byte elements) of element (row < 16, k) inside the bf16 half-tile A image: [k-step of 32][k quarter of 8][row][8]
+__host__ __device__ __forceinline__ int a16_index_bf16(int row, int k) {
+    return (((k >> 5) * 64) + (((k >> 3) & 3) * 16) + row) * 8 + (k & 7);
+}
+template <int NT>
+__device__ __forceinline__ void groups16_bf16(f32x4 (&acc)[NT], float4 (&b)[NT], const float4* __restrict__ A, int nsteps, const S16& ws,
+                                              int& gnext, int groups_total) {
+    float4 a = A[0];
+    for (int g = 0; g < nsteps; ++g) {
+        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64];
+#pragma unroll
+        for (int n = 0; n < NT; n += 2) {
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b[n]), acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b[n + 1]), acc[n + 1], 0, 0, 0);
+            b[n] = w16load<NT>(ws, gnext, n);
+            b[n + 1] = w16load<NT>(ws, gnext, n + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
+        a = an;
+    }
+}
+
 // lane-local cell update: accumulator register r of tile (gate, s) <-> row 4 (lane >> 4) + r, unit wave UW + 16 s + (lane & 15)
+// (Hb != nullptr: h is also written, rounded to bf16, into the A image of the bf16 ih-GEMM segment)
 template <int SB, int UW>
-__device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], float* __restrict__ Hs, int wave, int lane) {
+__device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], float* __restrict__ Hs, int wave, int lane,
+                                       unsigned short* __restrict__ Hb = nullptr) {
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
         const int k = wave * UW + s * 16 + (lane & 15);
@@ -78,20 +115,24 @@ __device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], flo
             c[s][r] = cc.x; c[s][r + 1] = cc.y;
             Hs[a16_index(4 * (lane >> 4) + r, k)] = h.x;
             Hs[a16_index(4 * (lane >> 4) + r + 1, k)] = h.y;
+            if (Hb) { Hb[a16_index_bf16(4 * (lane >> 4) + r, k)] = bf16_bits16(h.x); Hb[a16_index_bf16(4 * (lane >> 4) + r + 1, k)] = bf16_bits16(h.y); }
         }
     }
 }
 
 }  // namespace
 
-template <int HID, int KX, int OUT>
+template <int HID, int KX, int OUT, bool BF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
     constexpr int NW = 4, UW = HID / NW, SB = UW / 16, NT = 4 * SB;      // 96 units, 6 blocks of 16, 24 tiles per wave
     static_assert(UW % 16 == 0 && HID % 128 == 0, "tile shapes");
-    constexpr int KGX = (KX + 15) / 16, KGH = HID / 16, KG0 = KGX + KGH, KGT = KG0 + 2 * KGH;   // k-groups of 16
+    constexpr int KGX = (KX + 15) / 16, KGH = HID / 16, KG0 = KGX + KGH;                         // k-groups of 16
+    constexpr int KSB = HID / 32;                                                                  // bf16 k-steps of 32 (BF only)
+    constexpr int KGT = KG0 + KGH + (BF ? KSB : KGH);                                              // weight-stream groups per step
     constexpr int XP = KGX * 16;
+    static_assert(!BF || HID % 32 == 0, "bf16 k-steps");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* Xs = reinterpret_cast<float4*>(smem_raw);   // [KGX][64] A image of x_t
@@ -100,6 +141,7 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
     float* Wfc = reinterpret_cast<float*>(H1s + KGH * 64);               // [OUT][HID]
     RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc + OUT * HID);       // [16]
     float* Bs = reinterpret_cast<float*>(rows_s + 16);                   // [2][NW][NT][16]
+    float4* H0b = reinterpret_cast<float4*>(Bs + 2 * NW * NT * 16);      // BF: [KSB][64] bf16 A image of h0_t
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,7 +256,7 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
         groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
-        cell16<SB, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane);
+        cell16<SB, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst[i]] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
@@ -232,7 +274,8 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         groups16<NT>(acc, breg, H1s + lane, KGH, ws, gnext, KGT);
 #pragma unroll
         for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
-        groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
+        if constexpr (BF) groups16_bf16<NT>(acc, breg, H0b + lane, KSB, ws, gnext, KGT);
+        else groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
         cell16<SB, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
     }
@@ -274,18 +317,67 @@ void lstm16_pack_weights(int H, int NIN, int KX, const float* wih0, const float*
                     }
 }
 
-// one 16-row tile per workgroup, any number of tiles (rounds of num_CUs run back to back)
-void launch_lstm16(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
-    if (a.num_tiles <= 0) return;
+// bf16-ih variant of the stream: layer 0 and the h1 part of layer 1 as above (fp32), then HID / 32 bf16 k-steps of W_ih1: lane l of
+// step ks / tile n holds the 8 weights k = 32 ks + 8 (l >> 4) + j of its column, 2 bytes each (16 bytes per lane, like an fp32 group)
+size_t lstm16_pack_floats_bf16ih(int H, int KX) {
+    const int NT = 4 * (H / 4 / 16);
+    const int KGT = (KX + 15) / 16 + 2 * (H / 16) + H / 32;
+    return (size_t)4 * KGT * NT * 64 * 4;
+}
+static unsigned short host_bf16_rne16(float v) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+void lstm16_pack_weights_bf16ih(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack) {
+    const int UW = H / 4, SB = UW / 16, NT = 4 * SB;
+    const int KGX = (KX + 15) / 16, KGH = H / 16, KG0 = KGX + KGH, KSB = H / 32, KGT = KG0 + KGH + KSB;
+    for (int wv = 0; wv < 4; ++wv)
+        for (int g = 0; g < KGT; ++g)
+            for (int n = 0; n < NT; ++n)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int gate = n / SB, s = n % SB;
+                    const int wrow = gate * H + wv * UW + s * 16 + (lane & 15);
+                    float* dst = wpack + ((((size_t)wv * KGT + g) * NT + n) * 64 + lane) * 4;
+                    if (g < KG0 + KGH) {
+                        for (int q = 0; q < 4; ++q) {
+                            float v = 0.0f;
+                            if (g < KGX) {
+                                const int k = 16 * g + 4 * q + (lane >> 4);
+                                if (k < NIN) v = wih0[(size_t)wrow * NIN + k];
+                            } else if (g < KG0) {
+                                v = whh0[(size_t)wrow * H + 16 * (g - KGX) + 4 * q + (lane >> 4)];
+                            } else {
+                                v = whh1[(size_t)wrow * H + 16 * (g - KG0) + 4 * q + (lane >> 4)];
+                            }
+                            dst[q] = v;
+                        }
+                    } else {
+                        const int ks = g - KG0 - KGH;
+                        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+                        for (int j = 0; j < 8; ++j) d16[j] = host_bf16_rne16(wih1[(size_t)wrow * H + 32 * ks + 8 * (lane >> 4) + j]);
+                    }
+                }
+}
+
+template <bool BF>
+static void launch_lstm16_bf(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
     constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int KGX = (KX + 15) / 16, KGH = HID / 16, NT = 4 * (HID / 4 / 16);
-    const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * HID * 4 + 16 * sizeof(RowDesc) + (size_t)2 * 4 * NT * 16 * 4;
-    auto kern = lstm2_fc16_kernel<HID, KX, OUT>;
+    const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * HID * 4 + 16 * sizeof(RowDesc) + (size_t)2 * 4 * NT * 16 * 4 +
+                        (BF ? (size_t)(HID / 32) * 64 * 16 : 0);
+    auto kern = lstm2_fc16_kernel<HID, KX, OUT, BF>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     LstmWeights wv = w;
-    wv.wpack = w.wpack16;
+    wv.wpack = BF ? w.wpack16_bf : w.wpack16;
     hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
+}
+// one 16-row tile per workgroup, any number of tiles (rounds of num_CUs run back to back); w.ih_bf16: the bf16 ih-GEMM variant
+void launch_lstm16(const LstmWeights& w, const LstmArgs& a, hipStream_t s) {
+    if (a.num_tiles <= 0) return;
+    if (w.ih_bf16 && w.wpack16_bf) launch_lstm16_bf<true>(w, a, s);
+    else launch_lstm16_bf<false>(w, a, s);
 }
 
 }  // namespace fsnp

@@ -570,6 +570,55 @@ def test_bf16_ih_forward_b32():
     assert max(e32.values()) < 6e-3 and max(e64.values()) < 6e-3, (e32, e64)
 
 
+@pytest.mark.parametrize("n", [4096, 4000, 4112])
+def test_bf16_ih_on_the_half_tile_kernel(n):
+    """configs[4] below the chip-filling batch (round 4): the half-tile kernel (csrc/lstm16.hip, 16-row tiles - B = 16 in full mode,
+    the reference's literal drop-band call at B = 32) runs its layer-1 ih-GEMM on v_mfma_f32_16x16x32_bf16 under `bf16_ih`, so the mode
+    means the same arithmetic there as on the one-tile-per-CU kernel.  Same re-stated tolerance (2.5e-3 on the recurrent model alone);
+    4112 = 4096 on half tiles + 16 on a column-split kernel (those stay fp32: reported per launch)."""
+    sd = make_state_dict(10, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd)
+    steps = 24
+    rng = np.random.Generator(np.random.PCG64(555 + n))
+    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
+    want = fsnp_torch.lstm2_fc(x, sd).numpy()
+    got32 = m.lstm2_fc(x.cuda()).cpu().numpy()
+    assert rel_err(got32, want) < 2e-5
+    m.set_precision("bf16_ih")
+    got = m.lstm2_fc(x.cuda()).cpu().numpy()
+    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
+    err = rel_err(got, want)
+    per_row = np.abs(got - want).max(axis=(1, 2)) / np.abs(want).max()
+    _record(f"bf16_ih_half_tile_{n}", rel_bf16=err, rows_that_differ_from_fp32=int((np.abs(got - got32).max(axis=(1, 2)) > 0).sum()))
+    assert 1e-6 < err < 2.5e-3, err
+    # every row of the half-tile chunk really ran in bf16 (it differs from the fp32 run), inside the bound row by row
+    assert (np.abs(got - got32).max(axis=(1, 2))[:min(n, 4096)] > 0).all() and per_row.max() < 2.5e-3
+    m.set_precision("fp32")
+    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got32)
+
+
+def test_bf16_ih_forward_parity_mode_b32_and_b16():
+    """... and through the whole forward: the reference's literal batched call at B = 32 (drop_band: 4096 sequences = 256 half tiles) and
+    B = 16 in full mode (4112 = 4096 + 16) against the fp32 ORACLE on every utterance, bound 6e-3 as at the chip-filling batch;
+    describe_plan reports the half-tile chunk as bf16 and the 16-sequence column-split chunk as fp32."""
+    sd = make_state_dict(0, "default")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for B, mode in ((32, "parity"), (16, "full")):
+        mag, real, imag = make_inputs(B, 2.0, 100 + B)
+        m = _model(DEFAULT_MODEL_ARGS, sd, mode)
+        ins = _cuda((mag, real, imag))
+        ref = m(*ins).cpu().numpy()
+        m.set_precision("bf16_ih")
+        plan = m.describe_plan(B, parity=(mode == "parity"))
+        assert plan[0]["kernel"].startswith("lstm2_fc16_kernel") and plan[0]["precision"] == "f32 + bf16 layer-1 ih-GEMM", plan
+        assert all(c["precision"] == "f32" for c in plan[1:]), plan
+        got = m(*ins).cpu().numpy()
+        want = (fsnp_torch.forward(sd, mag, real, imag) if mode == "parity" else fsnp_torch.forward_full(sd, mag, real, imag)).numpy()
+        e_ref, e_bf = rel_err(ref, want), rel_err(got, want)
+        _record(f"bf16_ih_forward_{mode}_b{B}", rel_fp32=e_ref, rel_bf16=e_bf, plan=[c["kernel"] + f" x{c['sequences']} [{c['precision']}]" for c in plan])
+        assert e_ref < TOL and 1e-6 < rel_err(got, ref) and e_bf < 6e-3, (e_ref, e_bf)
+
+
 @pytest.mark.parametrize("n,steps", [(70, 24), (700, 40), (8192, 24)])
 def test_bf16x3_variant(n, steps):
     """Optional precision mode 2 (csrc/lstm_bf3.hip, fsnp.h: fsnp_set_precision): every fp32 product of the one-tile-per-CU
