@@ -1,0 +1,101 @@
+#!/bin/bash
+# round 4 evidence run.  Usage (from the build container): gpurun -- "FSNP_HEAD=<commit> bash tools/gpu_r04_final.sh [ref]"
+#   1. the whole GPU suite (run A), smoke, the headline exactly as the driver runs it
+#   2. rocprofv3 kernel stats of that command (serving loop) and of the back-to-back loop, PMC passes of the dominant kernel
+#      (each counter set in its own run) -> profiles/lstm_pmc.json
+#   3. the configuration table, RCCL at N = 1, the B = 1 phase profile
+#   4. [ref] the unmodified reference CLI end to end (reference staged under the git-ignored _refstage/ for this one call)
+#   5. the whole GPU suite again (run B): two green runs on one HEAD
+# The pytest logs carry the commit and a digest of the kernel sources at start and end of each run.  Everything -> gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+digest() { cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h | sha256sum | cut -c1-16; }
+suite() {   # $1 = log name
+  {
+    echo "commit: ${FSNP_HEAD:-unknown}   csrc sha256[:16] at start: $(digest)   library stamp: $(cut -c1-16 fullsubnet_plus_amd/libfsnp_hip.so.stamp)   $(date -u +%FT%TZ)"
+    timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=8 2>&1 | tail -30
+    echo "csrc sha256[:16] at end: $(digest)"
+  } | tee gpurun_out/$1
+}
+suite pytest_gpu_runA.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/bench.log
+cd /tmp
+rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc?
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $R/gpurun_out/prof_bench.log 2>&1
+f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats.csv
+rm -rf $R/gpurun_out/prof
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt --pipeline 0 > $R/gpurun_out/prof_bench_serial.log 2>&1
+f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats_serial_loop.csv
+rm -rf $R/gpurun_out/prof
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-alt --pipeline 0 > $R/gpurun_out/prof_bench_b1.log 2>&1
+f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats_b1.csv
+rm -rf $R/gpurun_out/prof
+i=0
+for ctr in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $ctr -f csv -d $R/gpurun_out/pmc$i -o pmc -- python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 > $R/gpurun_out/pmc$i.log 2>&1
+done
+cd $R
+python - <<'PY' | tee gpurun_out/pmc_summary.txt
+import csv, glob, collections, json
+vals = {}
+for i in (1, 2, 3, 4):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(f"gpurun_out/pmc{i}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = (r["Kernel_Name"][:70], r["Counter_Name"])
+            agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+    for (k, c), (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
+        print(f"pmc{i} {k:70s} {c:30s} sum={v:.6g} n={n} per_launch={v/n:.6g}")
+        if "lstm2_fc_kernel<384, 40, 2, 0, false, 4, false>" in k:
+            vals[c] = v / n
+if {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <= set(vals):
+    out = {"kernel": "lstm2_fc_kernel<384,40,2,EX=0,NW=4> (the first chunk of the B=32 plan: 8192 of the 8224 sequences)",
+           "workload": "B=32 x 2 s, full mode: 8192 sequences x 128 steps on the one-tile-per-CU kernel (+ 32 on a K-split kernel)",
+           "source": "rocprofv3 --pmc, separate passes (tools/gpu_r04_final.sh, final run of round 4 at HEAD); profiles/r04_pmc_summary.txt",
+           "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
+           "TCC_HIT_per_launch": vals.get("TCC_HIT_sum"), "TCC_MISS_per_launch": vals.get("TCC_MISS_sum"),
+           "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": vals["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE_per_launch": vals["GRBM_GUI_ACTIVE"],
+           "mfma_busy_frac": vals["SQ_VALU_MFMA_BUSY_CYCLES"] * 8 / (1024 * vals["GRBM_GUI_ACTIVE"]),
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (wide coalesced reads are tallied at half); counts fabric requests, i.e. L2 misses served by the 256 MiB Infinity Cache are included - an upper bound on HBM bytes.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES * 8 / (1024 SIMDs * GRBM_GUI_ACTIVE)",
+           "traffic_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+           "SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch": vals.get("SQ_INSTS_VALU_MFMA_MOPS_F32")}
+    json.dump(out, open("gpurun_out/lstm_pmc.json", "w"), indent=1)
+PY
+rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
+: > gpurun_out/b_final.log
+for args in "--batch 31" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--mode parity --precision bf16_ih" "--precision bf16_ih" "--precision bf16x3" "--batch 1" "--batch 2" "--batch 5" "--batch 8" "--batch 16" "--batch 16 --precision bf16_ih" "--batch 21" "--batch 40" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
+  timeout 400 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 >> gpurun_out/b_final.log
+done
+python tools/make_config_table.py r04 > /dev/null
+python tools/dump_costs.py > gpurun_out/dump_costs.log 2>&1
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_rccl_n1.log
+timeout 120 python tools/pp_phase_profile.py 257 64 0 2>&1 | grep -v amdgpu > gpurun_out/hp_phase_profile.txt
+python - <<'PY' | tee gpurun_out/b_final.txt
+import json
+r = json.loads(open("gpurun_out/bench.log").read())
+print("HEADLINE %.0f frames/s %.3f ms (alt %.3f) frac %.4f lstm %.3f ms stage %.3f ms fullband %.3f (alt %.3f) cpu %.0f err %.2e checked %d utterances" % (r["value"], r["ms_per_step"], r["alt_ms_per_step"], r["roofline"]["frac"], r["roofline"]["avg_launch_ms"], r["roofline"]["subband_stage_ms"], r["roofline"]["fullband_ms"], r["roofline"]["alt_fullband_ms"], r["cpu_baseline"]["value"], r["cirm_rel_err"], len(r["cirm_checked_utterances"])))
+for l in open("gpurun_out/b_final.log"):
+    try:
+        r = json.loads(l)
+    except Exception:
+        print("??", l[:200]); continue
+    plan = " + ".join("%s x%d" % (c["kernel"].split(" ")[0].replace("lstm2_", ""), c["sequences"]) for c in r["roofline"]["subband_plan"])
+    alt = r["alt_ms_per_step"]
+    print("%-62s | %8.0f frames/s %8.3f ms (alt %s) sub-band %7.3f fullband %6.3f (alt %s) | %s | %s" % (r["config"]["workload"][:62], r["value"], r["ms_per_step"],
+          "%.3f" % alt if alt else "-", r["roofline"]["subband_stage_ms"], r["roofline"]["fullband_ms"], "%.3f" % r["roofline"]["alt_fullband_ms"] if r["roofline"].get("alt_fullband_ms") else "-", r["dtype"][:8], plan))
+try:
+    r = json.loads(open("gpurun_out/bench_rccl_n1.log").read())
+    print("bench_rccl_n1 %.3f ms/step" % r["ms_per_step"], r.get("dist"), r.get("gather_ms"))
+except Exception as e:
+    print("bench_rccl_n1 ??", e)
+PY
+if [ $# -ge 1 ] && [ -d "$1" ]; then
+  timeout 900 python tools/cli_e2e.py "$1" 2>&1 | tail -15 | tee gpurun_out/cli_e2e_stdout.log
+fi
+suite pytest_gpu_runB.log
+head -16 gpurun_out/kernel_stats.csv | cut -c1-170
+echo "== done"

@@ -29,7 +29,7 @@ out = [f"# {TAG} - bench.py on one MI355X: every configuration measured at the e
 for m, a, v, ms, alt, dt, plan in rows:
     a = a.replace(" clips per GPU", "").replace(", random-init weights (seed 0)", "").replace(", num_neighbors=15", "")
     out.append("| %s: %s%s | %.0f | %.3f | %s | %s |" % (m, a, "" if dt == "f32" else " **[" + dt + "]**", v, ms, "%.3f" % alt if alt else "-", plan))
-out += ["", "Earlier rounds for comparison: `profiles/r01_bench_configs.md` (headline 29.03 ms), `profiles/r02_bench_configs.md` (27.62 ms; B = 1 2.22 / 2.65 ms;",
+out += ["", "Earlier rounds for comparison: `profiles/r01_bench_configs.md` (headline 29.03 ms), `profiles/r02_bench_configs.md` (27.62 ms; B = 1 2.22 / 2.65 ms;", "`profiles/r03_bench_configs.md` (27.59 ms; B = 1 1.80 / 1.97 ms; B = 8 9.79; B = 16 14.67; parity-mode B = 32 14.33; bf16-ih 21.20; 10 s clips 134.97 ms);",
         "B = 8 9.73 ms; B = 16 15.4 ms; parity-mode B = 32 14.8 ms; GRU B = 32 21.1 ms; bf16-ih 21.2 ms; 10 s clips 133 ms)."]
 open(os.path.join(ROOT, "profiles", f"{TAG}_bench_configs.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
