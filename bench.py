@@ -285,8 +285,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of round 3 by "
-                                       "tools/gpu_r03_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
+                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of round 4 by "
+                                       "tools/gpu_r04_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
@@ -303,12 +303,12 @@ def main():
                           "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref_outs = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
-        ref_path = os.path.join(ROOT, "profiles", "r02_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
+        ref_path = os.path.join(ROOT, "profiles", "r04_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
         if os.path.exists(ref_path) and not fsn:                        # (tools/cli_e2e.py; the reference is not on this box)
             with open(ref_path) as f:
                 rm = json.load(f)["reference_cpu_forward"]
             base["reference_measured"] = {"value": rm["value"], "unit": "frames/s", "cores": rm["best_threads"], "kind": "reference",
-                                          "source": "profiles/r02_cli_e2e.json (committed measurement, not re-run here)"}
+                                          "source": "profiles/r04_cli_e2e.json (the unmodified reference class on a GPU box's host cores, tools/cli_e2e.py; committed measurement, not re-run here)"}
         result["cpu_baseline"] = base
         if args.mode == "full" and not args.wave:
             # every utterance of the timed batch the CPU leg computed (B = 32 x 2 s: all 32 - the 15 s budget cycles through
