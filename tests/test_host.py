@@ -335,6 +335,63 @@ def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
         assert l["epi_load16"] == (8 if "ILi1E" in key else 0), (key, l)             # EPI_RESIDUAL: the eight residual rows
 
 
+def test_dma64_gemm_image_column_ownership_and_asm():
+    """csrc/tcn.hip tcn_gemm_dma64_kernel (round 4: the sconv GEMM on 64 x 64 tiles, column 256 on the VALU), restated:
+    * the LDS image [row][8 k-quads] XOR-swizzled by (row >> 1) & 7: the lane-linear DMA pieces (4 per wave and k-tile) cover every
+      (row, k-quad) of the 64 x 32 A tile and the 64 x 32 B tile exactly once, readers find the k-quad they ask for, the 16 lanes of
+      each quarter of a ds_read_b128 touch 64 distinct banks, and the k permutation is shared by A and B and covers the 32 k of a tile;
+    * the VALU column: thread -> slots tid and tid + 256 = rows tid >> 3 and 32 + (tid >> 3); the eight threads of a row hold its eight
+      k-quads (each once), so three __shfl_xor steps over lanes 8 i ... 8 i + 7 complete the dot product;
+    * the launcher's round count: the kernel runs exactly where it needs no more rounds of workgroups than the 128-row kernel;
+    * static: 32 MFMAs and 12 DMA pieces in the unrolled pair of k-tiles (+ the first tile's 4), no scratch, no accumulator moves or LDS
+      stores in the loop, 16-byte global traffic only behind it."""
+    swz = lambda row: (row >> 1) & 7
+    for tile in ("A", "B"):
+        image = {}
+        for wave in range(4):
+            for piece in range(2):
+                for lane in range(64):
+                    sl = (wave * 2 + piece) * 64 + lane
+                    row, kq = sl >> 3, (sl & 7) ^ swz(sl >> 3)
+                    assert sl not in image
+                    image[sl] = (row, kq)
+        assert sorted(image.values()) == [(r, q) for r in range(64) for q in range(8)]
+        for base in (0, 32):                                  # wave row half (A: wr) / column half (B: wc)
+            for kg in range(4):
+                for quarter in range(4):
+                    banks = []
+                    for lane in range(quarter * 16, quarter * 16 + 16):
+                        r, kh = lane & 31, lane >> 5
+                        row, kq = base + r, kg * 2 + kh
+                        slot = row * 8 + (kq ^ swz(row))
+                        assert image[slot] == (row, kq)
+                        banks += [(slot * 4 + w) % 64 for w in range(4)]
+                    assert len(set(banks)) == 64, (tile, base, kg, quarter)
+    assert sorted(8 * kg + 4 * kh + j for kg in range(4) for kh in range(2) for j in range(4)) == list(range(32))
+    # the VALU column's ownership
+    per_row = {}
+    for tid in range(256):
+        xrow = tid >> 3
+        for row, slot in ((xrow, tid), (xrow + 32, tid + 256)):
+            assert slot >> 3 == row
+            per_row.setdefault(row, []).append((slot & 7) ^ swz(row))
+        assert (tid >> 3) == ((tid ^ 1) >> 3) == ((tid ^ 2) >> 3) == ((tid ^ 4) >> 3)      # the shuffle partners share the row
+    assert sorted(per_row) == list(range(64)) and all(sorted(q) == list(range(8)) for q in per_row.values())
+    # round counts (launch_gemm_dma64): B = 32 x 2 s takes it (768 workgroups = 3 rounds of half-size tiles vs 2 x 2), B = 24 ties (taken)
+    for B, Tp, want in ((32, 128, True), (24, 128, True), (40, 128, True), (32, 628, True)):
+        wg64, wg128 = 4 * (-(-Tp // 64)) * B * 3, 5 * (-(-Tp // 128)) * B * 3
+        assert (-(-wg64 // 256) <= 2 * (-(-wg128 // 256))) == want, (B, Tp)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_dma64_gemm()
+    assert len(res) == 1                                      # EPI_RESIDUAL only
+    for key, l in res.items():
+        assert l["mfma"] == 32 and l["dma"] == 12 and l["scratch"] == 0 and l["acc_moves_in_loop"] == 0 and l["ds_write_in_loop"] == 0, (key, l)
+        assert l["epi_store4"] == 0 and l["epi_store16"] == 6 and l["epi_load16"] == 4 and l["epi_drains"] <= 3, (key, l)
+
+
 def test_half_tile_ping_pong_index_arithmetic():
     """csrc/lstm_hp.hip, index arithmetic restated: (1) hp_a16 puts element (row, k) of a half-tile image where lane (k & 3) * 16 + row
     of k-group k >> 4 reads component (k >> 2) & 3 - the A operand of v_mfma_f32_16x16x4_f32 number j = (k >> 2) & 3 of that group;

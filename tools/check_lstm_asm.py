@@ -182,8 +182,33 @@ def analyse_dma_gemm(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_dma64_gemm(flags=("-fno-slp-vectorize",)):
+    """tcn_gemm_dma64_kernel (tcn.hip, round 4): whole-kernel counts.  The k-loop body exists twice (two k-tiles per trip), each with 16
+    MFMAs, 4 LDS-DMA pieces and 8 fragment reads (+ 4 reads of the VALU column's operands); no scratch, no AGPR<->VGPR moves; the epilogue
+    moves 16-byte rows (4 residual loads + 4 stores per lane for the 64 x 64 tile, one float4 store per row of the VALU column)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "tcn.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp21tcn_gemm_dma64_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), [l for l in m.group(2).split("\n") if l.strip() and not l.strip().startswith(";")]
+        idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+        loop, epi = body[idx[0]:idx[-1] + 1], body[idx[-1] + 1:]
+        cnt = lambda seg, pat: sum(1 for x in seg if re.search(pat, x))
+        res[name] = dict(mfma=cnt(body, r"v_mfma_f32_32x32x2"), dma=cnt(body, r"buffer_load_dwordx4 .* lds"), scratch=cnt(body, r"scratch_"),
+                         acc_moves_in_loop=cnt(loop, r"v_accvgpr"), ds_write_in_loop=cnt(loop, r"ds_write"),
+                         epi_store16=cnt(epi, r"global_store_dwordx4"), epi_store4=cnt(epi, r"global_store_dword\s"),
+                         epi_load16=cnt(epi, r"global_load_dwordx4"), epi_drains=cnt(epi, r"vmcnt\(0\)"))
+    return res
+
+
 if __name__ == "__main__":
     for k, v in analyse_dma_gemm().items():
+        print(k, v)
+    for k, v in analyse_dma64_gemm().items():
         print(k, v)
     for k, loops in analyse_half_tile().items():
         for l in loops:
