@@ -44,7 +44,7 @@ static PlannerCtx pctx(const fsnp_handle* h) {
     c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
     for (int i = 0; i < 4; ++i) c.occ_ksplit[i] = h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) c.occ_coopn[i] = h->occ_coopn[i];
-    c.coop_split = h->coop_split; c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
+    c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
     c.cost = h->cost;
     return c;
 }
@@ -211,7 +211,6 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_bar2 = nullptr;
         ca.coop_skew = h->coop_skew;
         ca.coop_chaos = h->coop_chaos;
-        ca.coop_split = c.kind == 1 && c.rpg ? 1 : 0;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
         // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)
@@ -224,7 +223,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
         static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
         {
-            const int S = c.kind == 8 ? h->H / 16 : c.kind == 1 ? (h->H / c.units) * (c.rpg ? 2 : 1) : h->H / 128;
+            const int S = c.kind == 8 ? h->H / 16 : c.kind == 1 ? h->H / c.units : h->H / 128;
             const int T = c.kind == 1 || c.kind == 8 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
             ca.coop_xcd = c.kind != 6 && xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
@@ -652,9 +651,6 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
-    const char* csp = getenv("FSNP_COOP_SPLIT");
-    if (csp && csp[0] >= '0' && csp[0] <= '3') h->coop_split = csp[0] - '0';
-    h->coop_split_cfg = h->coop_split;
     {
         // (The round-3 ping-pong K-split kernel lstm_pp.hip - opt-in, ahead of the other kernels at exactly 10 row tiles - was removed in
         // round 4; its measurements stay in profiles/r03_column_split.md and profiles/r03_pp_*.txt.)
@@ -1131,7 +1127,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
         if (n >= max_chunks) break;
         // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel,
         // 12 = half-tile ping-pong (lstm_hp.hip)
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 1 && c.rpg ? 5 : c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
@@ -1315,7 +1311,6 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
     add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
     add("  FSNP_COOP_SKEW=%s -> K-split schedule %s (FSNP_SKEW_MIN_UNITS=%s: smallest units per workgroup that run it, default 8)\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial", env("FSNP_SKEW_MIN_UNITS"));
-    add("  FSNP_COOP_SPLIT=%s -> role-split K split mode %d (0 never, 1 auto outside the pipelined loop, 2 wherever it fits, 3 auto also pipelined)\n", env("FSNP_COOP_SPLIT"), h->coop_split);
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
     add("  FSNP_COOP_XCD=%s (0 = no XCD-local workgroup placement)  FSNP_OWN_CU=%s (0 = deferred chunks do not claim their CUs' LDS)\n", env("FSNP_COOP_XCD"), env("FSNP_OWN_CU"));
     add("  FSNP_LSTM16=%s -> half-tile kernel %s\n", env("FSNP_LSTM16"), h->lstm16_ok ? "planned" : "not used");
@@ -1367,7 +1362,6 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule), 3 (= 1; selected the ping-pong K split lstm_pp.hip until round 4 removed it) or 4 (auto + the half-tile ping-pong kernel even where FSNP_COOP_HP=0)"); return 1; }
     h->lstm_coop = mode != 0;
     h->coop_skew = mode == 1 || mode >= 3;
-    h->coop_split = mode == 1 || mode >= 3 ? h->coop_split_cfg : 0;
     h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);

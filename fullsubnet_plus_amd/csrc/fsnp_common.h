@@ -200,7 +200,6 @@ struct LstmArgs {
     unsigned* coop_bar;        // per row tile arrival counter, zeroed per launch
     unsigned* coop_bar2;       // second counter per row tile (layer-skewed K-split kernel: finished layer-1 phases)
     int coop_skew;             // lstm_coop.hip: 1 = layer-skewed schedule (lstm2_coop_skew_kernel)
-    int coop_split;            // lstm_coop.hip: 1 = role-split schedule (lstm2_coop_split_kernel: 2 S workgroups per row tile)
     unsigned* coop_err;        // host-mapped: set to 1 if a barrier wait timed out
     unsigned* coop_abort;      // device word (zeroed per forward): raised by the first waiter that gives up, polled by all
     int coop_units;            // hidden units per workgroup: 8, 16, 32 or 64

@@ -103,14 +103,11 @@ struct fsnp_handle {
     int lstm_coop = 1;           // 0 = never, 1 = automatic (small batches)
     int coop_chaos = 0;          // fsnp_debug_set_chaos: drift injection seed for the column-split kernels (0 = off)
     int coop_skew = 1;           // K-split kernel: 1 = layer-skewed schedule (lstm2_coop_skew_kernel), 0 = the serial one (FSNP_COOP_SKEW=0)
-    int coop_split_cfg = 1;      // (coop_split as configured at fsnp_create: fsnp_debug_set_lstm_coop(h, 2) turns it off, 1 restores it)
     bool generic_sb = false;     // the sub-band recurrent model runs on the runtime-sized kernel (lstm_generic.hip): a hidden size or an
                                  // input width no tuned kernel is instantiated for
     bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
     int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0 / 1; fsnp_debug_set_lstm_coop(h, 4) = only it)   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
-    int coop_split = 1;          // K-split kernel: 1 = the planner may use the role-split schedule (lstm2_coop_split_kernel: 2 S workgroups
-                                 // per row tile), 0 = never, 2 = wherever it fits (FSNP_COOP_SPLIT, tuning)
     unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
                                  // so the NEXT call on the handle can fail loudly without a device synchronisation
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4

@@ -760,268 +760,6 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
 }
 
 // ------------------------------------------------------------------------------------------------
-// Role-split schedule (sub-band LSTM only): 2 S workgroups per row tile - S of them run ONLY layer 0 of every step, the other
-// S ONLY layer 1, one step behind.  In lstm2_coop_kernel a step is two dependent hand-offs (h0_t, then h1_t) through the same
-// workgroups; here each set has ONE hand-off per step and the two chains run side by side:
-//     layer-0 set, step t: wait b0 >= S t (h0_{t-1})  [and b1 >= S (t-2): image t % 3 is free]  -> MFMAs -> cell -> publish h0_t -> arrive b0
-//     layer-1 set, step t: wait b0 >= S (t+1) (h0_t) and b1 >= S t (h1_{t-1}, Linear partials of t-1) -> MFMAs -> cell -> publish h1_t -> arrive b1
-// so a step costs max(chain 0, chain 1) instead of their sum (1 tile at 8 units: 8.7 -> ~4.5 us; profiles/r02_column_split.md).
-// Same exchange region as the layer-skewed kernel (three h0 images, two h1 images, two Linear-partial buffers, two counters),
-// same weight stream (a workgroup reads only its layer's groups - which also makes a wave's share register-resident at 16
-// units), same k-split, LDS reduction, cell and Linear code: results are bit-identical to lstm2_coop_kernel.  All 2 S x tiles
-// workgroups must be co-resident.
-template <int HID, int KX, int UNITS>
-__global__ __launch_bounds__(256) void lstm2_coop_split_kernel(LstmWeights w, LstmArgs a) {
-    constexpr int NT = UNITS / 8, NP = UNITS / 8;
-    constexpr int KGX = KX / 8, KGH = HID / 8;
-    constexpr int KGXP = (KGX + 3) / 4 * 4;
-    constexpr int G0W = (KGXP + KGH) / 4, G1W = KGH / 2;
-    constexpr int S = HID / UNITS;
-    constexpr int HIMG = KGH * 64;
-    constexpr int FCP4 = 2 * (HID / 8) * 16;
-    constexpr bool WREG0 = NT * G0W * 4 <= 192, WREG1 = NT * G1W * 4 <= 192;      // the layer's weights stay in VGPRs (8 and 16 units)
-    static_assert(KX <= 64, "gathered sub-band input");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4* Xs = reinterpret_cast<float4*>(smem_raw);                     // [KGXP][64] A image of x_t (layer-0 set)
-    float* red = reinterpret_cast<float*>(Xs + KGXP * 64);                // [4 waves][NT][16][64]
-    RowDesc* rows_s = reinterpret_cast<RowDesc*>(red + 4 * NT * 16 * 64); // [32]
-    __shared__ int abort_s;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rt = blockIdx.x / (2 * S), cs2 = blockIdx.x % (2 * S);
-    if (a.coop_xcd && !xcd_local_decode(blockIdx.x, 2 * S, a.num_tiles, a.coop_xcd, rt, cs2)) return;
-    const int role = __builtin_amdgcn_readfirstlane(cs2 >= S ? 1 : 0);
-    const int cs = role ? cs2 - S : cs2;
-    const int slot0 = rt * 32;
-    const int Tp = a.Tp;
-
-    float4* hx = reinterpret_cast<float4*>(a.coop_hx) + (size_t)rt * coop_tile_f4(HID);
-    auto h0off = [](int m3) -> int { return m3 < 2 ? m3 * HIMG : 4 * HIMG + FCP4; };
-    auto h1off = [](int par) -> int { return (2 + par) * HIMG; };
-    float* fcp = reinterpret_cast<float*>(hx + 4 * HIMG);                  // [2][S][64]
-    unsigned* bar0 = FSNP_COOP_BAR(a, rt, 0);
-    unsigned* bar1 = FSNP_COOP_BAR(a, rt, 1);
-
-    if (tid == 0) abort_s = 0;
-    for (int i = tid; i < KGXP * 64; i += 256) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 32) rows_s[tid] = a.rows[slot0 + tid];
-    __syncthreads();
-
-    CoopStream ws;
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(w.wpack) + (size_t)(cs * 4 + wave) * (G0W + G1W) * NT * 256, 0, (G0W + G1W) * NT * 1024, 0x00020000);
-    ws.voff = lane * 16;
-    CoopStream hs;
-    hs.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(hx), 0, coop_tile_f4(HID) * 16, 0x00020000);
-    hs.voff = (wave * 64 + lane) * 16;
-    auto hload = [&](int off_f4, int i) -> float4 {
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hs.rsrc, hs.voff, off_f4 * 16 + i * 4096, kSc1));
-    };
-
-    // cell ownership: as lstm2_coop_kernel (pair p = tid + 256 i -> unit p % UNITS, row p / UNITS); one layer's state only
-    int prow[NP], pk[NP], pred[NP][4];
-    float c[NP], bias[NP][4];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int p = tid + 256 * i;
-        const int u = p % UNITS, row = p / UNITS;
-        prow[i] = row;
-        pk[i] = cs * UNITS + u;
-        c[i] = 0.f;
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) {
-            const int j = gate * UNITS + u;
-            pred[i][gate] = (((j >> 5) * 16) + (row & 3) + 4 * (row >> 3)) * 64 + (j & 31) + 32 * ((row >> 2) & 1);
-            bias[i][gate] = w.bias[role * 4 * HID + gate * HID + pk[i]];
-        }
-    }
-    auto publish_tiles = [&](f32x16 (&acc)[NT]) {
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * NT + n) * 16 + r) * 64 + lane] = acc[n][r];
-        __syncthreads();
-    };
-    auto red_sum = [&](int idx) -> float { return red[idx] + red[idx + NT * 1024] + red[idx + 2 * NT * 1024] + red[idx + 3 * NT * 1024]; };
-    auto cell = [&](auto emit) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const float ig = fast_sigmoid(red_sum(pred[i][0]) + bias[i][0]);
-            const float fg = fast_sigmoid(red_sum(pred[i][1]) + bias[i][1]);
-            const float gg = fast_tanh(red_sum(pred[i][2]) + bias[i][2]);
-            const float og = fast_sigmoid(red_sum(pred[i][3]) + bias[i][3]);
-            const float cn = fg * c[i] + ig * gg;
-            c[i] = cn;
-            emit(i, og * fast_tanh(cn));
-        }
-    };
-    auto arrive = [&](unsigned* bar) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // thread 0 waits for both counters (target 0 = nothing to wait for); false once the launch is aborted
-    auto wait_both = [&](unsigned t0, unsigned t1) -> bool {
-        if (tid == 0) {
-            if (t0 && !xchg_wait(bar0, t0, a.coop_abort, a.coop_err)) abort_s = 1;
-            if (t1 && !abort_s && !xchg_wait(bar1, t1, a.coop_abort, a.coop_err)) abort_s = 1;
-        }
-        __syncthreads();
-        return abort_s == 0;
-    };
-    auto zero_acc = [&](f32x16 (&acc)[NT]) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    };
-
-    if (role == 0) {
-        // ================= layer-0 set: [x_t | h0_{t-1}] =================
-        const bool dense = a.dense != nullptr;
-        const float* __restrict__ gbase = dense ? a.dense : a.att_mag;
-        const int gstep = dense ? a.dense_stride : a.FP;
-        constexpr int NG = KGX;
-        const int grow = tid & 31, jrow = tid >> 5;
-        int goff[NG];
-        NormMD md = {0.0f, 1.0f};
-        const NormMD* md_t = nullptr;
-        {
-            const RowDesc rd = rows_s[grow];
-#pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const int j = jrow + 8 * i;
-                int off = -1;
-                if (rd.valid && j < w.NIN) {
-                    if (dense) off = rd.b * Tp * gstep + j;
-                    else off = sb_feature_offset(j, rd.f, rd.b * Tp * a.FP, a.F, a.NSBN, a.NFBN, a.fb_rel, a.fb_branch_stride);
-                }
-                goff[i] = off;
-            }
-            if (rd.valid) {
-                if (a.md_seq != nullptr) md_t = a.md_seq + (size_t)rd.b * Tp;
-                else if (!dense && a.md_row != nullptr) md_t = a.md_row + (size_t)(slot0 + grow) * Tp;
-                else if (!dense) md = a.md_utt[rd.b];
-            }
-        }
-        auto x_load = [&](int i, int t) -> float { return goff[i] >= 0 ? gbase[goff[i] + t * gstep] : 0.0f; };
-        const int xdst0 = a_frag_index(grow, jrow);
-        float* Xf = reinterpret_cast<float*>(Xs);
-        {
-            const NormMD m0 = md_t ? md_t[0] : md;
-#pragma unroll
-            for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (x_load(i, 0) - m0.m) / m0.d : 0.0f;
-        }
-        float4 bw[WREG0 ? G0W : 1][NT];
-        if constexpr (WREG0) {
-#pragma unroll
-            for (int i = 0; i < G0W; ++i)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bw[i][n] = coop_wload<NT>(ws, i, n);
-        }
-        const float4* Xw = Xs + wave * 64 + lane;
-        __syncthreads();
-        int m3 = 0, pm3 = 2;                               // t % 3, (t - 1) % 3; h0_{-1} = the (zeroed) third image
-        for (int t = 0; t < Tp; ++t) {
-            chaos_delay(a.coop_chaos, t, 0);
-            float xr[NG];
-            NormMD mdn = md;
-            const bool have_next = t + 1 < Tp;
-            if (have_next) {
-                if (md_t) mdn = md_t[t + 1];
-#pragma unroll
-                for (int i = 0; i < NG; ++i) xr[i] = x_load(i, t + 1);
-            }
-            // h0_{t-1} published by every layer-0 slice; image m3 (last read by layer 1 of step t - 3) free again
-            if (t > 0 && !wait_both((unsigned)S * (unsigned)t, t >= 3 ? (unsigned)S * (unsigned)(t - 2) : 0u)) return;
-            f32x16 acc[NT];
-            zero_acc(acc);
-            const int hprev = h0off(pm3);
-            if constexpr (WREG0)
-                coop_layer_resident<NT, G0W, KGXP / 4>(acc, bw, [&](int i) -> float4 { return Xw[i * 256]; },
-                                                       [&](int i) -> float4 { return hload(hprev, i); });
-            else
-                coop_layer<NT, G0W, KGXP / 4, 0>(acc, ws, [&](int i) -> float4 { return Xw[i * 256]; },
-                                                 [&](int i) -> float4 { return hload(hprev, i); });
-            publish_tiles(acc);
-            float* img = reinterpret_cast<float*>(hx + h0off(m3));
-            cell([&](int i, float hval) { xchg_store(img + a_frag_index(prow[i], pk[i]), hval); });
-            if (have_next) {
-#pragma unroll
-                for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
-            }
-            chaos_delay(a.coop_chaos, t, 1);
-            arrive(bar0);
-            pm3 = m3;
-            m3 = m3 == 2 ? 0 : m3 + 1;
-        }
-        return;
-    }
-
-    // ================= layer-1 set: [h1_{t-1} | h0_t], Linear(H, 2) =================
-    float wfc0[NP], wfc1[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) { wfc0[i] = w.wfc[pk[i]]; wfc1[i] = w.wfc[HID + pk[i]]; }
-    float4 bw[WREG1 ? G1W : 1][NT];
-    if constexpr (WREG1) {
-#pragma unroll
-        for (int i = 0; i < G1W; ++i)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bw[i][n] = coop_wload<NT>(ws, G0W + i, n);
-    }
-    auto fc_epilogue = [&](int t_done) {     // slice 0 of the layer-1 set sums the S partials of step t_done in a fixed order
-        if (cs == 0 && tid < 64) {
-            const int row = tid & 31, o = tid >> 5;
-            const RowDesc rd = rows_s[row];
-            const float* part = fcp + (size_t)(t_done & 1) * S * 64;
-            float sum = w.bfc[o];
-            for (int p = 0; p < S; ++p) sum += xchg_load(part + p * 64 + o * 32 + row);
-            if (rd.valid && t_done >= a.LA)
-                a.out[(size_t)rd.out_off + (size_t)o * a.out_stride_o + (t_done - a.LA)] = apply_act(sum, a.act);
-        }
-    };
-    __syncthreads();
-    int m3 = 0;
-    for (int t = 0; t < Tp; ++t) {
-        const int cur = t & 1, prv = cur ^ 1;
-        chaos_delay(a.coop_chaos, t, 2);
-        if (!wait_both((unsigned)S * (unsigned)(t + 1), (unsigned)S * (unsigned)t)) return;     // h0_t; h1_{t-1} + partials of t-1
-        if (t > 0) fc_epilogue(t - 1);
-        f32x16 acc[NT];
-        zero_acc(acc);
-        const int h1p = h1off(prv), h0c = h0off(m3);
-        if constexpr (WREG1)
-            coop_layer_resident<NT, G1W, KGH / 4>(acc, bw, [&](int i) -> float4 { return hload(h1p, i); },
-                                                  [&](int i) -> float4 { return hload(h0c, i); });
-        else
-            coop_layer<NT, G1W, KGH / 4, G0W>(acc, ws, [&](int i) -> float4 { return hload(h1p, i); },
-                                              [&](int i) -> float4 { return hload(h0c, i); });
-        publish_tiles(acc);
-        float* img = reinterpret_cast<float*>(hx + h1off(cur));
-        cell([&](int i, float h) {
-            xchg_store(img + a_frag_index(prow[i], pk[i]), h);
-            float p0 = h * wfc0[i], p1 = h * wfc1[i];                 // partial Linear over this workgroup's units
-#pragma unroll
-            for (int m = UNITS / 2; m > 0; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); }
-            if ((tid & (UNITS - 1)) == 0) {
-                float* part = fcp + ((size_t)cur * S + cs) * 64;
-                xchg_store(part + prow[i], p0);
-                xchg_store(part + 32 + prow[i], p1);
-            }
-        });
-        chaos_delay(a.coop_chaos, t, 3);
-        arrive(bar1);
-        m3 = m3 == 2 ? 0 : m3 + 1;
-    }
-    if (!wait_both(0u, (unsigned)S * (unsigned)Tp)) return;
-    fc_epilogue(Tp - 1);
-}
-
-// ------------------------------------------------------------------------------------------------
 static int coop_kgxp(int KX) { return (KX / 8 + 3) / 4 * 4; }
 
 size_t lstm_coop_pack_floats(int H, int KX, int units) {
@@ -1090,16 +828,6 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
     const size_t smem = a.coop_own_cu > 0 && (size_t)a.coop_own_cu > smem_need ? (size_t)a.coop_own_cu : smem_need;
     LstmWeights wv = w;
     wv.wpack = w.wpack_coop[coop_units_index(UNITS)];
-    if constexpr (!SEQ && !GRU) {
-        if (a.coop_split) {          // role-split schedule: 2 S workgroups per row tile (lstm2_coop_split_kernel)
-            auto split = lstm2_coop_split_kernel<HID, KX, UNITS>;
-            static PerDeviceOnce split_once;
-            split_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds); });
-            const int sgrid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(2 * S, a.num_tiles, a.coop_xcd) : a.num_tiles * 2 * S;
-            hipLaunchKernelGGL(split, dim3(sgrid), dim3(256), smem, s, wv, a);
-            return;
-        }
-    }
     const int grid = a.coop_xcd ? 8 * xcd_local_blocks_per_xcd(S, a.num_tiles, a.coop_xcd) : a.num_tiles * S;
     if constexpr (!SEQ) {
         // layer-skewed schedule (lstm2_coop_skew_kernel), same launch shape.  Measured (profiles/r02_column_split.md): 16 units per

@@ -43,13 +43,8 @@ CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
     return t;
 }
 static int units_index(int units) { return units <= 8 ? 0 : units <= 16 ? 1 : units <= 32 ? 2 : 3; }
-// per-step cost of the role-split K-split schedule relative to the one-set kernel of the same units and tile count
-// (lstm_coop.hip: lstm2_coop_split_kernel; measured, profiles/r02_column_split.md section 8: 1 tile at 8 units 11.06 -> 9.47 us,
-// 2 tiles 14.40 -> 11.32; from 16 units up it does not pay - a step is ONE hand-off on either schedule, the split only takes
-// the other layer's MFMA + cell time out of the chain)
-static const double kSplitRatio[4] = {0.85, 1.0, 1.1, 1.25};
 int chunk_workgroups(const PlannerCtx& h, const SbChunk& c) {
-    if (c.kind == 1) return c.num_tiles * (h.H / c.units) * (c.rpg ? 2 : 1);     // (rpg = 1 on a K-split chunk: role-split schedule)
+    if (c.kind == 1) return c.num_tiles * (h.H / c.units);
     if (c.kind == 2) return c.groups * (h.H / 128);
     if (c.kind == 8) return c.num_tiles * (h.H / 16);
     return c.num_tiles;
@@ -58,15 +53,6 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
     const int dbl = chunk_workgroups(h, c) > h.num_cus_real ? 1 : 0;
     if (c.kind == 1) {
         const int ui = units_index(c.units);
-        if (c.rpg) {             // role-split schedule: priced relative to the same shape on the one-set kernels (kSplitRatio)
-            const int cap = h.num_cus_real / (2 * (h.H / c.units));
-            const double r = h.coop_split == 2 ? 0.01 : kSplitRatio[ui];
-            // 8 units: measured directly against the one-set (layer-skewed) kernel, scaled with the table
-            if (ui == 0 && c.num_tiles <= 2 && h.coop_split != 2) return (c.num_tiles == 1 ? 0.93 : 1.13) * h.cost.ksplit1[0];     // (8.2 / 10.0 us against 8.8 / 8.85 layer-skewed)
-            if (cap <= 1) return r * h.cost.ksplit1[ui];
-            const double f = (double)(c.num_tiles - 1) / (cap - 1);
-            return r * (h.cost.ksplit1[ui] + (h.cost.ksplit[ui][0] - h.cost.ksplit1[ui]) * (f < 1.0 ? f : 1.0));
-        }
         const int cap = h.num_cus_real / (h.H / c.units);
         if (dbl || cap <= 1) return h.cost.ksplit[ui][dbl];
         const double f = (double)(c.num_tiles - 1) / (cap - 1);              // 1 tile .. a full launch
@@ -106,11 +92,6 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
                 shapes.push_back({1, u, 0, slots / (h.H / u), occ - 1});
         for (int rpg = 1; rpg <= 2; ++rpg)
             if (h.occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
-        // role-split K split: 2 S workgroups per row tile, LSTM only; not in the pipelined loop, where the chunk runs beside the
-        // next forward's full-band stages and twice the CUs for 15 % less time is a bad trade (auto mode)
-        if (occ == 1 && !h.gru && (h.coop_split >= 2 || (h.coop_split == 1 && !h.pipeline)))      // (3 = auto, also when pipelined: tuning)
-            for (int u = 8; u <= 64; u *= 2)
-                if (h.H % u == 0 && slots / (2 * (h.H / u)) > 0) shapes.push_back({1, u, 1, slots / (2 * (h.H / u)), 0});
         // half-tile ping-pong (lstm_hp.hip): H / 16 workgroups per row tile
         if (occ == 1 && h.hp_ok && h.coop_hp && slots / (h.H / 16) > 0) shapes.push_back({8, 16, 0, slots / (h.H / 16), 0});
     }

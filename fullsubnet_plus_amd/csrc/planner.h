@@ -46,7 +46,7 @@ struct PlannerCtx {
     bool gru = false, sb_tcn = false, generic_sb = false, rowtile_ok = true, lstm16_ok = false, hp_ok = false;
     int ih_bf16 = 0, lstm_coop = 1, coop_occ = 1;
     int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};
-    int coop_split = 1, coop_hp = 0, pipeline = 0;
+    int coop_hp = 0, pipeline = 0;
     double composite_gain = 0.97;
     CostTable cost{};
 };

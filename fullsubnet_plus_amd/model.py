@@ -521,7 +521,6 @@ class _HipModel(nn.Module):
                  1: "lstm2_coop_kernel (K split)",
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
-                 5: "lstm2_coop_split_kernel (K split, one workgroup set per layer)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
                  12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)"}
         prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}

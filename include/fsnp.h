@@ -206,9 +206,8 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
 int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
- *  half-tile: 16-row tiles, csrc/lstm16.hip, 5 = lstm2_coop_split K-split with one workgroup set per layer: planned for 1-2 row
- *  tiles outside the pipelined loop; FSNP_COOP_SPLIT=0 at fsnp_create time = never; (7..10 were the round-3 ping-pong
- *  K split csrc/lstm_pp.hip, removed in round 4;) 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
+ *  half-tile: 16-row tiles, csrc/lstm16.hip, (5 was the role-split K split lstm2_coop_split_kernel, 7..10 the round-3 ping-pong
+ *  K split csrc/lstm_pp.hip: both removed in round 4;) 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
  *  gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row tiles;
  *  FSNP_COOP_HP=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */

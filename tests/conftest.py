@@ -18,7 +18,8 @@ def pytest_configure(config):
 _FIRST = ("test_forward_from_plain_c", "test_c_abi_argument_errors_are_loud", "test_forward_vs_reference_golden",
           "test_fullsubnet_forward_vs_reference_golden", "test_stages_vs_reference",
           "test_b32_full_vs_oracle", "test_b32_parity_vs_oracle_and_subselection", "test_b32_10s_full_vs_oracle",
-          "test_b32_10s_cumulative_norms_vs_oracle", "test_bf16_ih_forward_b32", "test_b32_batch_independence",
+          "test_b32_10s_cumulative_norms_vs_oracle", "test_bf16_ih_forward_b32", "test_bf16_ih_forward_parity_mode_b32_and_b16",
+          "test_b32_batch_independence",
           "test_forward_complex_equals_three_plane_forward", "test_stft_istft_vs_torch", "test_enhance_wave_vs_oracle",
           "test_enhance_epilogue_vs_oracle", "test_fullsubnet_batch_vs_oracle", "test_fullsubnet_enhance_wave_vs_oracle",
           "test_forward_sharded_two_ranks_equals_single_process", "test_forward_sharded_over_rccl_world_size_1",

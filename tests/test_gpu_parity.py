@@ -150,32 +150,6 @@ def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
         assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), skew)
 
 
-@pytest.mark.parametrize("n,steps", [(16, 1), (32, 2), (32, 3), (33, 40), (64, 25), (32, 300)])
-def test_role_split_k_split_equals_serial_schedule(n, steps):
-    """csrc/lstm_coop.hip: lstm2_coop_split_kernel gives every row tile TWO workgroup sets - one runs only layer 0 of every step,
-    the other only layer 1, one step behind (two arrival counters, three h0 images); the planner uses it for 1-2 row tiles at 8
-    units per workgroup outside the pipelined loop.  Same arithmetic and summation order as the serial schedule: bit-identical,
-    for 1, 2, 3 and many steps (300: the counters run far past the image rotation), ragged tiles, and against the oracle."""
-    sd = make_state_dict(9, "harsh")
-    m = _model(DEFAULT_MODEL_ARGS, sd)
-    rng = np.random.Generator(np.random.PCG64(777 + n + steps))
-    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
-    m.lstm2_fc(x[:1])
-    m.debug_set_lstm_coop(2)                  # serial schedule, no role split
-    serial = m.lstm2_fc(x).cpu().numpy()
-    m.check_errors()
-    m.debug_set_lstm_coop(1)
-    plan = m.describe_plan(1)                 # (describes a B = 1 forward; the dense call below plans its own n sequences)
-    del plan
-    split = m.lstm2_fc(x).cpu().numpy()
-    m.check_errors()
-    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
-    assert rel_err(split, want) < 2e-5
-    assert np.array_equal(split, serial)
-    for _ in range(3):
-        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), split)
-
-
 # K split at 8 units cheap (a full launch and one tile), everything else priced out
 _SERIAL_8_UNITS_COSTS = [5.0, 900.0] + [900.0] * 6 + [900.0] * 4 + [900.0, 0.11] + [5.0, 900.0, 900.0, 900.0] + [900.0, 0.0] + [1e9] * 4
 
@@ -236,18 +210,6 @@ def test_generic_recurrent_kernel_dense_vs_oracle(seq, hidden, fbn):
         _record(f"generic_{seq}_h{hidden}_fbn{fbn}_{n}x{steps}", rel=err)
         assert err < 2e-5, (n, steps, err)
         assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
-
-
-def test_b32_remainder_runs_role_split_outside_the_pipelined_loop(b32):
-    sd, (mag, real, imag), m, full = b32
-    plan = m.describe_plan(32)
-    assert plan[-1]["kernel"].startswith("lstm2_coop_split_kernel") and plan[-1]["sequences"] == 32, plan
-    m.set_pipeline(True)
-    try:
-        plan_p = m.describe_plan(32)
-        assert plan_p[-1]["kernel"].startswith("lstm2_coop_kernel") and plan_p[-1]["sequences"] == 32, plan_p
-    finally:
-        m.set_pipeline(False)
 
 
 @pytest.mark.parametrize("seq", ["LSTM", "GRU"])

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 # sequences -> launches of the default plan on 256 CUs (tests/test_host.py::_plan):
-#   20 role-split K split @ 8 units | 131 layer-skewed K split @ 8 | 257 half-tile ping-pong | 514 layer-skewed @ 32 (17 tiles)
+#   20 one row tile, layer-skewed K split @ 8 units | 131 five tiles @ 8 | 257 half-tile ping-pong | 514 layer-skewed @ 32 (17 tiles)
 #   771 = 640 @ 32 + 131 @ 8 (the B = 3 plan of the round-3 failure) | 1028 = @ 32 + half-tile ping-pong + @ 8
 #   1285 layer-skewed @ 64 | 2056 three-way column split, one row tile per group | 2700 two row tiles per group
 FAMILIES = [20, 131, 257, 514, 771, 1028, 1285, 2056, 2700]

@@ -671,8 +671,7 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(5397) == [(4, 4096), (1, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles K split
     assert kinds(5397, gru=1) == [(2, 5397)] and _plan(5397, gru=1)[0]["rpg"] == 2  # (108 + 48.5 us against 157 for two per group); GRU: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
-    assert _plan(8224)[1]["rpg"] == 1 and _plan(16448)[1]["rpg"] == 0 and _plan(16448)[1]["tiles"] == 2   # ONE tile at 8 units: role-split schedule
-    assert _plan(96)[0]["rpg"] == 0 and _plan(257)[0]["rpg"] == 0                   # (3 tiles and up: it does not pay)
+    assert _plan(8224)[1]["rpg"] == 0 and _plan(16448)[1]["rpg"] == 0 and _plan(16448)[1]["tiles"] == 2   # (the role-split schedule was removed in round 4)
     assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
     assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
