@@ -392,6 +392,130 @@ def test_dma64_gemm_image_column_ownership_and_asm():
         assert l["epi_store4"] == 0 and l["epi_store16"] == 6 and l["epi_load16"] == 4 and l["epi_drains"] <= 3, (key, l)
 
 
+def _run_exchange_model(program, S, steps, seed, slow=None):
+    """Event-level model of one row tile's S workgroups running `program(w)` (a generator of events) under a random scheduler.
+    Events: ("wait", counter, target) blocks until the counter reaches the target; ("arrive", counter); ("read_begin", image, version)
+    / ("read_end", image): between them the image must hold `version` in EVERY slice and nobody may write it; ("write", image, version):
+    this workgroup's slice.  Returns None, or a description of the first hazard."""
+    import random
+    rng = random.Random(seed)
+    gens = [program(w) for w in range(S)]
+    pending = [next(g) for g in gens]
+    counters, images, readers = {}, {}, {}
+    done = [False] * S
+    while not all(done):
+        runnable = [w for w in range(S) if not done[w] and not (pending[w][0] == "wait" and counters.get(pending[w][1], 0) < pending[w][2])]
+        if not runnable:
+            return "deadlock"
+        if slow is not None and slow in runnable and len(runnable) > 1 and rng.random() < 0.9:
+            runnable.remove(slow)                                   # one workgroup that almost never gets a turn
+        w = rng.choice(runnable)
+        ev = pending[w]
+        if ev[0] == "arrive":
+            counters[ev[1]] = counters.get(ev[1], 0) + 1
+        elif ev[0] == "read_begin":
+            img = images.setdefault(ev[1], [-1] * S)                # -1 = the zeroed initial state
+            if any(v != ev[2] for v in img):
+                return f"workgroup {w} reads {ev[1]} expecting version {ev[2]}, slices hold {img}"
+            readers.setdefault(ev[1], set()).add(w)
+        elif ev[0] == "read_end":
+            readers[ev[1]].discard(w)
+        elif ev[0] == "write":
+            if readers.get(ev[1]):
+                return f"workgroup {w} writes {ev[1]} (version {ev[2]}) while {sorted(readers[ev[1]])} still read it"
+            images.setdefault(ev[1], [-1] * S)[w] = ev[2]
+        try:
+            pending[w] = next(gens[w])
+        except StopIteration:
+            done[w] = True
+    return None
+
+
+def test_exchange_schedules_are_race_free_under_any_interleaving():
+    """The inter-workgroup hand-off SCHEDULES of csrc/lstm_coop.hip restated as event programs - which image / counter every phase
+    waits for, reads and overwrites, in the kernels' program order - and run under random and adversarial (one starved workgroup)
+    interleavings: no image is read before all its slices carry the expected step, none is overwritten while a peer still reads it,
+    nobody deadlocks.  (The device-side counterpart is the drift injection of tests/test_gpu_soak.py.)  Negative controls: the
+    layer-skewed schedule with TWO h0 images and the serial schedule without its barrier both fail here at once."""
+    def serial(S, T, barrier=True):                                  # lstm2_coop_kernel / lstm2_coopn_kernel: ONE barrier per step
+        def prog(w):
+            for t in range(T):
+                cur, prv = t & 1, (t & 1) ^ 1
+                yield ("read_begin", f"h0[{prv}]", t - 1); yield ("read_end", f"h0[{prv}]")            # layer 0 over h0_{t-1}
+                yield ("write", f"h0[{cur}]", t)
+                yield ("arrive", "b")
+                if barrier:
+                    yield ("wait", "b", S * (t + 1))
+                if w == 0 and t > 0:                                                                    # Linear partials of step t - 1
+                    yield ("read_begin", f"fc[{prv}]", t - 1); yield ("read_end", f"fc[{prv}]")
+                yield ("read_begin", f"h1[{prv}]", t - 1); yield ("read_begin", f"h0[{cur}]", t)       # layer 1 over [h1_{t-1} | h0_t]
+                yield ("read_end", f"h1[{prv}]"); yield ("read_end", f"h0[{cur}]")
+                yield ("write", f"h1[{cur}]", t); yield ("write", f"fc[{cur}]", t)
+            yield ("arrive", "b"); yield ("wait", "b", S * (T + 1))
+            if w == 0:
+                yield ("read_begin", f"fc[{(T - 1) & 1}]", T - 1); yield ("read_end", f"fc[{(T - 1) & 1}]")
+        return prog
+
+    def skewed(S, T, images=3):                                      # lstm2_coop_skew_kernel: A_t = layer 0 of step t, C_t = layer 1
+        def phase_a(t, with_c):
+            yield ("read_begin", f"h0[{(t - 1) % images}]", t - 1); yield ("read_end", f"h0[{(t - 1) % images}]")
+            yield ("write", f"h0[{t % images}]", t)
+            if with_c:
+                yield ("wait", "b1", S * (t - 1))                    # h1_{t-2}, Linear partials of step t - 2
+            yield ("arrive", "b0")
+        def phase_c(t):
+            cur, prv = t & 1, (t & 1) ^ 1
+            yield ("read_begin", f"h1[{prv}]", t - 1); yield ("read_begin", f"h0[{t % images}]", t)
+            yield ("read_end", f"h1[{prv}]"); yield ("read_end", f"h0[{t % images}]")
+            yield ("write", f"h1[{cur}]", t); yield ("write", f"fc[{cur}]", t)
+            yield ("arrive", "b1")
+        def fc(w, t):
+            if w == 0:
+                yield ("read_begin", f"fc[{t & 1}]", t); yield ("read_end", f"fc[{t & 1}]")
+        def prog(w):
+            yield from phase_a(0, False)
+            for t in range(1, T):
+                yield ("wait", "b0", S * t)
+                yield from phase_a(t, True)
+                if t >= 2:
+                    yield from fc(w, t - 2)
+                yield from phase_c(t - 1)
+            yield ("wait", "b0", S * T); yield ("wait", "b1", S * (T - 1))
+            if T >= 2:
+                yield from fc(w, T - 2)
+            yield from phase_c(T - 1)
+            yield ("wait", "b1", S * T)
+            yield from fc(w, T - 1)
+        return prog
+
+    def half_tile_ping_pong(S, T, h0_images=2):                      # lstm2_coop_hp_kernel, one half tile (the halves are independent:
+        def prog(w):                                                 # own images, own counter); fused phase t = [layer 1 of t, layer 0 of t + 1]
+            yield ("write", "h0[0]", 0); yield ("arrive", "c")       # phase -1: h0_0
+            for t in range(T):
+                yield ("wait", "c", S * (t + 1))
+                yield ("read_begin", f"h1[{(t - 1) & 1}]", t - 1); yield ("read_begin", f"h0[{t % h0_images}]", t)
+                if w == 0 and t >= 1:
+                    yield ("read_begin", f"fc[{(t - 1) & 1}]", t - 1); yield ("read_end", f"fc[{(t - 1) & 1}]")
+                yield ("read_end", f"h1[{(t - 1) & 1}]"); yield ("read_end", f"h0[{t % h0_images}]")
+                yield ("write", f"h1[{t & 1}]", t); yield ("write", f"fc[{t & 1}]", t); yield ("write", f"h0[{(t + 1) % h0_images}]", t + 1)
+                yield ("arrive", "c")
+            yield ("wait", "c", S * (T + 1))
+            if w == 0:
+                yield ("read_begin", f"fc[{(T - 1) & 1}]", T - 1); yield ("read_end", f"fc[{(T - 1) & 1}]")
+        return prog
+
+    for S, T in ((3, 9), (6, 14)):
+        for seed in range(40):
+            for slow in (None, 0, S - 1):
+                assert _run_exchange_model(serial(S, T), S, T, seed, slow) is None
+                assert _run_exchange_model(skewed(S, T), S, T, seed, slow) is None
+                assert _run_exchange_model(half_tile_ping_pong(S, T), S, T, seed, slow) is None
+    assert any(_run_exchange_model(half_tile_ping_pong(4, 12, h0_images=1), 4, 12, seed, slow=1) for seed in range(20))
+    # negative controls: the model does catch what it is there to catch
+    assert any(_run_exchange_model(skewed(4, 12, images=2), 4, 12, seed, slow=1) for seed in range(20))
+    assert any(_run_exchange_model(serial(4, 12, barrier=False), 4, 12, seed, slow=1) for seed in range(20))
+
+
 def test_half_tile_ping_pong_index_arithmetic():
     """csrc/lstm_hp.hip, index arithmetic restated: (1) hp_a16 puts element (row, k) of a half-tile image where lane (k & 3) * 16 + row
     of k-group k >> 4 reads component (k >> 2) & 3 - the A operand of v_mfma_f32_16x16x4_f32 number j = (k >> 2) & 3 of that group;
