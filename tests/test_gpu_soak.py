@@ -2,7 +2,7 @@
 
 Round 3 ended with one wrong answer on the driver's box: B = 3 x 126-second clips (T' = 7,878 steps - by accident: a
 parametrisation written in frames was passed as seconds), default kernels, 0.35 rel on the 4th forward of a handle whose
-first three forwards were right.  It never reproduced (round 4: 450 forwards of that exact shape on nine boxes, back to back
+first three forwards were right.  It never reproduced (round 4: 550 forwards of that exact shape on ten boxes, back to back
 and behind 17 s of host-busy / GPU-idle time, all bit-identical - DESIGN.md section 5), so what this file pins is what CAN be
 pinned: every column-split family at >= 8,000 steps, bit-repeatable and against the oracle, and every family with its
 workgroups forced to drift apart by whole steps (fsnp_debug_set_chaos): the hand-off protocols may not depend on lockstep."""
