@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 4: the write-through exchange alone, every word checked (tools/ubench/exchange_litmus.hip)
+# round 4: the write-through exchange alone, every word checked (tools/ubench/exchange_litmus.hip; built in the container:
+#   hipcc --offload-arch=gfx950 -O3 -o exchange_litmus exchange_litmus.hip ; ... -DLITMUS_S=12 -o exchange_litmus_s12 ...)
 set -u
 mkdir -p gpurun_out
 cd tools/ubench
 {
-  timeout 200 ./exchange_litmus 1500000 2 0 0
-  timeout 200 ./exchange_litmus 1500000 2 1 0
-  timeout 200 ./exchange_litmus 600000 2 0 6
-  timeout 200 ./exchange_litmus 600000 2 1 6
-} 2>&1 | tee ../../gpurun_out/exchange_litmus.txt
+  timeout 300 ./exchange_litmus_s12 2500000 2 0 0 20
+  timeout 300 ./exchange_litmus_s12 1200000 2 0 6 20
+  timeout 300 ./exchange_litmus 2000000 2 0 0
+} 2>&1 | tee ../../gpurun_out/exchange_litmus2.txt

@@ -17,7 +17,10 @@
 #include <cstdlib>
 #include <vector>
 
-constexpr int kS = 48, kWordsPerSlice = 256, kImgWords = kS * kWordsPerSlice;     // one image = 48 KiB
+#ifndef LITMUS_S
+#define LITMUS_S 48                    // workgroups per row tile: 48 (8 hidden units per workgroup) or 12 (32 units: -DLITMUS_S=12)
+#endif
+constexpr int kS = LITMUS_S, kWordsPerSlice = 12288 / kS, kImgWords = kS * kWordsPerSlice;     // one image = 32 rows x 384 units = 48 KiB
 constexpr int kCounterStride = 64;                                                 // words: one 256-byte slot per tile
 
 __device__ __forceinline__ unsigned tag(int tile, int t, int word) {
@@ -52,12 +55,15 @@ __global__ __launch_bounds__(256) void litmus_kernel(Args a) {
         }
         // ---- publish this workgroup's slice of image `cur`
         if (a.mode == 0) {
-            __hip_atomic_store(img + (size_t)cur * kImgWords + cs * kWordsPerSlice + tid, tag(tile, t, cs * kWordsPerSlice + tid), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);             // global_store_dword ... sc1
-        } else if (wave == 0) {                                        // 64 lanes x 16 bytes = the slice, by ONE wave (lstm_hp.hip)
-            const int w0 = cs * kWordsPerSlice + lane * 4;
-            const __attribute__((ext_vector_type(4))) unsigned v = {tag(tile, t, w0), tag(tile, t, w0 + 1), tag(tile, t, w0 + 2), tag(tile, t, w0 + 3)};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (cur * kImgWords + w0) * 4, 0, 16);
+            for (int i = tid; i < kWordsPerSlice; i += 256)
+                __hip_atomic_store(img + (size_t)cur * kImgWords + cs * kWordsPerSlice + i, tag(tile, t, cs * kWordsPerSlice + i), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);         // global_store_dword ... sc1
+        } else if (wave == 0) {                                        // 16 bytes per lane, by ONE wave (lstm_hp.hip)
+            for (int i = lane; i < kWordsPerSlice / 4; i += 64) {
+                const int w0 = cs * kWordsPerSlice + i * 4;
+                const __attribute__((ext_vector_type(4))) unsigned v = {tag(tile, t, w0), tag(tile, t, w0 + 1), tag(tile, t, w0 + 2), tag(tile, t, w0 + 3)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (cur * kImgWords + w0) * 4, 0, 16);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains its stores
         __syncthreads();
