@@ -335,6 +335,35 @@ def test_dma_gemm_k_loop_is_stripped_to_the_matrix_pipe():
         assert l["epi_load16"] == (8 if "ILi1E" in key else 0), (key, l)             # EPI_RESIDUAL: the eight residual rows
 
 
+def test_float4_epilogue_covers_every_element_once():
+    """csrc/tcn.hip EpiF4 / the staging loops of the three DMA GEMM kernels, restated: the accumulator layout of
+    v_mfma_f32_32x32x2_f32 (lane -> column lane & 31, register q -> row (q & 3) + 8 (q >> 2) + 4 (lane >> 5)) written into a row-major
+    [rows][64] LDS slice covers every (row, column) exactly once with conflict-free ds_write_b32 (the 32 lanes of a half wave hit 32
+    consecutive banks), and the float4 phase (lane -> column quad lane & 15, rows (lane >> 4) + 4 i) reads every float4 exactly once
+    with each 16-lane quarter of a ds_read_b128 covering one whole 256-byte row."""
+    # 128-row kernel: a wave's 32 x 64 slice from two accumulators; split-K kernel: 8 x 64 from sum[2][4]; 64-row kernel: 2 x 2 waves on a 64 x 64 tile
+    def staged_128(lane, j, q):
+        return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j * 32 + (lane & 31)
+    cells = [staged_128(lane, j, q) for lane in range(64) for j in range(2) for q in range(16)]
+    assert sorted(cells) == [(r, c) for r in range(32) for c in range(64)]
+    for j in range(2):
+        for q in range(16):
+            for half in range(2):
+                banks = [(r * 64 + c) % 32 for r, c in (staged_128(lane, j, q) for lane in range(32 * half, 32 * half + 32))]
+                assert len(set(banks)) == 32
+    cells = [(qq + 4 * (lane >> 5), j * 32 + (lane & 31)) for lane in range(64) for j in range(2) for qq in range(4)]
+    assert sorted(cells) == [(r, c) for r in range(8) for c in range(64)]
+    cells = [(wr * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), wc * 32 + (lane & 31)) for wr in range(2) for wc in range(2) for lane in range(64) for q in range(16)]
+    assert sorted(cells) == [(r, c) for r in range(64) for c in range(64)]
+    for rows in (32, 8, 16):                                  # float4 phase: EpiF4<EPI, ROWS>
+        quads = [((lane >> 4) + 4 * i, lane & 15) for lane in range(64) for i in range(rows // 4)]
+        assert sorted(quads) == [(r, c) for r in range(rows) for c in range(16)]
+        for i in range(rows // 4):
+            for quarter in range(4):
+                lanes = range(16 * quarter, 16 * quarter + 16)
+                assert len({(lane >> 4) + 4 * i for lane in lanes}) == 1 and sorted(lane & 15 for lane in lanes) == list(range(16))
+
+
 def test_dma64_gemm_image_column_ownership_and_asm():
     """csrc/tcn.hip tcn_gemm_dma64_kernel (round 4: the sconv GEMM on 64 x 64 tiles, column 256 on the VALU), restated:
     * the LDS image [row][8 k-quads] XOR-swizzled by (row >> 1) & 7: the lane-linear DMA pieces (4 per wave and k-tile) cover every
