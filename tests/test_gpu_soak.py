@@ -6,6 +6,8 @@ first three forwards were right.  It never reproduced (round 4: 550 forwards of 
 and behind 17 s of host-busy / GPU-idle time, all bit-identical - DESIGN.md section 5), so what this file pins is what CAN be
 pinned: every column-split family at >= 8,000 steps, bit-repeatable and against the oracle, and every family with its
 workgroups forced to drift apart by whole steps (fsnp_debug_set_chaos): the hand-off protocols may not depend on lockstep."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +20,8 @@ from tests._util import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+torch.set_num_threads(min(16, os.cpu_count() or 1))   # the CPU oracle collapses when oversubscribed (256 hardware threads on the GPU boxes:
+                                                      # run alone, without test_gpu_parity.py's identical line, this file took 395 s instead of 30)
 
 # sequences -> launches of the default plan on 256 CUs (tests/test_host.py::_plan):
 #   20 one row tile, layer-skewed K split @ 8 units | 131 five tiles @ 8 | 257 half-tile ping-pong | 514 layer-skewed @ 32 (17 tiles)
