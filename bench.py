@@ -140,6 +140,10 @@ def main():
         # two processes must not each plan launches that fill every CU twice, nor calibrate against each other
         os.environ.setdefault("FSNP_COOP_OCC", "1")
         os.environ.setdefault("FSNP_CALIBRATE", "0")
+        if world > 2:
+            # more than two processes interleaving co-resident launches on one GPU can each hold part of the chip and wait for the
+            # rest (the kernels' 2 s time-out would end it, loudly): the plumbing test of many ranks runs the exchange-free kernel
+            os.environ.setdefault("FSNP_LSTM_COOP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -222,15 +226,28 @@ def main():
 
         pipelined = bool(args.pipeline) and not args.wave
         alt_elapsed, alt_timing, _ = timed_loop(not pipelined) if not (args.wave or args.no_alt) else (None, None, None)
+        # the drop-in default: what a maintainer who edits the one TOML line gets - error_check="sync" (every forward waits for its
+        # own launches and polls the error word before it returns), no pipelined loop
+        dropin_elapsed = None
+        if not (args.wave or args.no_alt) and world == 1:
+            model.error_check = "sync"
+            dropin_elapsed, _, _ = timed_loop(False)
+            model.error_check = "deferred"
         elapsed, timing, out = timed_loop(pipelined)
 
     rank_ms = None
     if dist is not None:
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cnt = max(timing["count"], 1)
+        mine = torch.tensor([elapsed, timing["lstm_ms"] / cnt, timing["lstm_first_chunk_ms"] / cnt, timing["fullband_ms"] / cnt,
+                             timing["forward_ms"] / cnt], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
-        elapsed = max(float(t.item()) for t in every)          # the job is as slow as its slowest rank
+        rank_ms = [float(t[0].item()) / args.steps * 1e3 for t in every]
+        slow = max(range(world), key=lambda r: float(every[r][0].item()))
+        elapsed = float(every[slow][0].item())                 # the job is as slow as its slowest rank ...
+        # ... and the roofline block below describes THAT rank's kernels (the N > 1 line carries the slowest rank's roofline)
+        timing = {"count": 1, "lstm_ms": float(every[slow][1]), "lstm_first_chunk_ms": float(every[slow][2]),
+                  "fullband_ms": float(every[slow][3]), "forward_ms": float(every[slow][4])}
         # batch-split plumbing: gather every rank's masks once (outside the timed region)
         g0 = time.perf_counter()
         gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=dev)
@@ -268,6 +285,8 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "alt_ms_per_step": None if alt_elapsed is None else alt_elapsed / args.steps * 1e3,
+        # the drop-in default (error_check="sync", no pipelined loop): one TOML line edited, nothing else
+        "dropin_ms_per_step": None if dropin_elapsed is None else dropin_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak",
         # the arithmetic type per launch of the sub-band plan (the bf16 variants exist for the one-tile-per-CU LSTM kernel only)
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else
@@ -279,14 +298,15 @@ def main():
                                ("" if args.sequence_model == "LSTM" else f", sequence_model={args.sequence_model}"),
                    "global_batch": world * B, "frames_per_clip": T, "parallelism": f"dp{world} (batch split, no data-path collective)",
                    "loop": ("pipelined serving loop: the column-split remainder chunk of forward i overlaps the full-band stages "
-                            "of forward i+1 (fsnp_set_pipeline); every forward is complete inside the timed region; "
-                            "alt_ms_per_step = the same K forwards strictly back to back") if pipelined else
+                            "of forward i+1 where the planner says that pays (fsnp_set_pipeline; roofline.subband_plan[].deferred_when_pipelined); "
+                            "every forward is complete inside the timed region; alt_ms_per_step = the same K forwards strictly back to back; "
+                            "dropin_ms_per_step = the same with the module's default error_check='sync' (each forward waits for its launches)") if pipelined else
                            "forwards strictly back to back (alt_ms_per_step = the pipelined serving loop)"},
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of round 4 by "
-                                       "tools/gpu_r04_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
+                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of every round by "
+                                       "tools/gpu_r05_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
@@ -300,15 +320,17 @@ def main():
         result["dist"] = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""),
                           "world_size_seen": dist.get_world_size(), "same_device": bool(args.same_device),
                           "gathered_shape": list(gathered.shape),
-                          "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}}
+                          "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}, "roofline_of_rank": slow}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref_outs = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
-        ref_path = os.path.join(ROOT, "profiles", "r04_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
+        ref_path = os.path.join(ROOT, "profiles", "r05_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
+        if not os.path.exists(ref_path):
+            ref_path = os.path.join(ROOT, "profiles", "r04_cli_e2e.json")
         if os.path.exists(ref_path) and not fsn:                        # (tools/cli_e2e.py; the reference is not on this box)
             with open(ref_path) as f:
                 rm = json.load(f)["reference_cpu_forward"]
             base["reference_measured"] = {"value": rm["value"], "unit": "frames/s", "cores": rm["best_threads"], "kind": "reference",
-                                          "source": "profiles/r04_cli_e2e.json (the unmodified reference class on a GPU box's host cores, tools/cli_e2e.py; committed measurement, not re-run here)"}
+                                          "source": os.path.relpath(ref_path, ROOT) + " (the unmodified reference class on a GPU box's host cores, tools/cli_e2e.py; committed measurement, not re-run here)"}
         result["cpu_baseline"] = base
         if args.mode == "full" and not args.wave:
             # every utterance of the timed batch the CPU leg computed (B = 32 x 2 s: all 32 - the 15 s budget cycles through

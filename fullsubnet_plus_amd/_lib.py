@@ -24,6 +24,7 @@ ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
 ATTENTION = {"TSSE": 0, "SE": 1, "ECA": 2, "CBAM": 3}
 SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1, "TCN": 2}
 MODE_FULL, MODE_PARITY = 0, 1
+NUM_COSTS = 25           # FSNP_NUM_COSTS: values of the planner's flat cost table (fsnp_get_costs)
 MODEL_FULLSUBNET_PLUS, MODEL_FULLSUBNET = 0, 1
 
 # every symbol include/fsnp.h declares: name -> (restype, argtypes)
@@ -51,9 +52,9 @@ SYMBOLS = {
     "fsnp_describe_plan_ex": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fsnp_reserve": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_dump_config": (ctypes.c_int64, [c_vp, ctypes.c_char_p, ctypes.c_int64]),
-    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 26), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "fsnp_get_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * NUM_COSTS), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fsnp_debug_plan_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_i32), c_i32]),
-    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 26)]),
+    "fsnp_measure_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * NUM_COSTS)]),
     "fsnp_debug_set_costs": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), c_i32]),
     "fsnp_debug_plan_rows2": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(c_i32), c_i32]),
@@ -66,6 +67,10 @@ SYMBOLS = {
     "fsnp_poll_errors": (c_i32, [c_vp]),
     "fsnp_set_pipeline": (c_i32, [c_vp, c_i32]),
     "fsnp_flush": (c_i32, [c_vp, c_vp]),
+    "fsnp_watch_weights": (c_i32, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), c_i32, c_i32, c_vp]),
+    "fsnp_set_verify": (c_i32, [c_vp, c_i32]),
+    "fsnp_verify_count": (c_i64, [c_vp]),
+    "fsnp_debug_corrupt_exchange": (c_i32, [c_vp, c_i32]),
     "fsnp_abi_version": (c_i32, []),
     "fsnp_config_size": (c_i32, []),
     "fsnp_debug_set_lstm_coop": (c_i32, [c_vp, c_i32]),
@@ -77,11 +82,12 @@ SYMBOLS = {
     "fsnp_debug_set_num_cus": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coop_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_debug_lstm_coopw_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_last_error": (ctypes.c_char_p, []),
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 8          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 9          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 
@@ -117,6 +123,17 @@ def last_error():
     return load().fsnp_last_error().decode(errors="replace")
 
 
+ERR_TIMEOUT, ERR_STALE_WEIGHTS, ERR_VERIFY = 5, 6, 7      # device-side conditions noticed by a later call (include/fsnp.h)
+
+
+class FsnpError(RuntimeError):
+    """RuntimeError that carries the C ABI's return code."""
+
+    def __init__(self, msg, code):
+        super().__init__(msg)
+        self.code = code
+
+
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+        raise FsnpError(f"{what} failed (code {rc}): {last_error()}", rc)

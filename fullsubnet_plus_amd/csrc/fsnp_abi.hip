@@ -36,12 +36,36 @@ using namespace fsnp;
 
 namespace fsnp {
 
+// Decodes and clears the host-mapped error word that finished launches set (fsnp_handle.h: kErr*).  0 = clean.
+int take_device_errors(fsnp_handle* h, const char* where) {
+    volatile unsigned* e = reinterpret_cast<volatile unsigned*>(h->d_err);
+    const unsigned bits = e[0];
+    if (bits == 0) return 0;
+    const unsigned key = e[4];
+    e[0] = 0; e[4] = 0xFFFFFFFFu;
+    if (bits & kErrTimeout) {
+        set_error("%s: an inter-workgroup wait timed out in a column-split LSTM kernel (its workgroups were not co-resident - is the GPU "
+                  "shared with another process?); the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids these kernels", where);
+        return 5;
+    }
+    if (bits & kErrVerify) {
+        set_error("%s: exchange verification failed (fsnp_set_verify): the column-split kernels and the one-tile-per-CU kernel disagree, "
+                  "first at utterance %u, bin %u, frame %u; the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids the "
+                  "column-split kernels", where, key >> 24, (key >> 14) & 1023u, key & 16383u);
+        return 7;
+    }
+    set_error("%s: the watched source tensors no longer match the packed weights (a parameter was modified in place through .data "
+              "after packing): forwards since that edit ran on the OLD weights - re-pack (fsnp_set_weight / fsnp_commit_weights / "
+              "fsnp_watch_weights; Python: model.refresh_weights())", where);
+    return 6;
+}
+
 // what the planner needs to know of a handle
 static PlannerCtx pctx(const fsnp_handle* h) {
     PlannerCtx c;
     c.H = h->H; c.NIN = h->NIN; c.num_cus = h->num_cus; c.num_cus_real = h->num_cus_real;
     c.gru = h->gru != 0; c.sb_tcn = h->sb_tcn != 0; c.generic_sb = h->generic_sb; c.rowtile_ok = h->rowtile_ok; c.lstm16_ok = h->lstm16_ok;
-    c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
+    c.hp_ok = h->hp_ok; c.coop_hp = h->coop_hp; c.coopw_ok = h->coopw_ok; c.coop_w = h->coop_w; c.ih_bf16 = h->ih_bf16; c.lstm_coop = h->lstm_coop; c.coop_occ = h->coop_occ;
     for (int i = 0; i < 4; ++i) c.occ_ksplit[i] = h->occ_ksplit[i];
     for (int i = 0; i < 2; ++i) c.occ_coopn[i] = h->occ_coopn[i];
     c.pipeline = h->pipeline; c.composite_gain = h->composite_gain;
@@ -223,12 +247,13 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
         static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
         {
-            const int S = c.kind == 8 ? h->H / 16 : c.kind == 1 ? h->H / c.units : h->H / 128;
-            const int T = c.kind == 1 || c.kind == 8 ? c.num_tiles : c.groups, cpx = h->num_cus_real / 8;
-            ca.coop_xcd = c.kind != 6 && xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
+            const int S = c.kind == 8 ? h->H / 16 : (c.kind == 1 || c.kind == 9) ? h->H / c.units : h->H / 128;
+            const int T = c.kind == 2 ? c.groups : c.num_tiles, cpx = h->num_cus_real / 8;
+            ca.coop_xcd = xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
             if (c.kind == 8) launch_lstm_hp(h->lw, ca, s);
+            else if (c.kind == 9) launch_lstm_coopw(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
         });
@@ -248,6 +273,28 @@ static int fb_row_tiles(int B) { return cdiv(B, 32); }
 static int fb_coop_units(const fsnp_handle* h, int B) {
     const int u = lstm_coop_pick_units(h->CH, fb_row_tiles(B), h->num_cus_real, 8);
     return u > 32 ? 0 : u;
+}
+
+// Pipelined serving loop (fsnp_set_pipeline): which chunks of a plan go to the side stream, where they overlap the NEXT forward's
+// full-band stages.  Deferred column-split launches own their CUs (LstmArgs::coop_own_cu), so the overlapped stages run on what is
+// left: that pays while the deferred launches leave at least 32 CUs free (B = 32: 48 workgroups, 28.2 -> 27.5 ms; B = 1: 216, 1.97 ->
+// 1.77) and LOSES when they fill the chip (B = 40: a 66-tile remainder, 36.9 -> 37.5 ms; B = 21: the overlapped stage took 5.4 ms
+// instead of 0.66 - profiles/r04_bench_configs.md): the planner defers only in the first case.
+//   returns: first deferred chunk (== chunks.size(): nothing is deferred; 0: the whole plan)
+static int plan_first_deferred(const fsnp_handle* h, const SbPlan& plan) {
+    const int n = (int)plan.chunks.size();
+    auto fills_chip = [](const SbChunk& c) { return c.kind == 0 || c.kind == 4; };       // one (half) tile per CU, no exchange
+    if (n == 0 || h->sb_tcn) return n;
+    int first = n;
+    if (n > 1 && fills_chip(plan.chunks[0])) {
+        first = 1;
+        while (first < n && fills_chip(plan.chunks[first])) ++first;
+    } else if (h->defer_small && !fills_chip(plan.chunks[0])) {
+        first = 0;
+    }
+    int busiest = 0;
+    for (int i = first; i < n; ++i) busiest = std::max(busiest, chunk_workgroups(h, plan.chunks[i]));
+    return (first < n && busiest <= h->num_cus_real - 32) ? first : n;
 }
 
 static int rows_per_utt(const fsnp_handle* h, int mode) {
@@ -472,7 +519,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     auto time_shape = [&](SbChunk c) -> double {
         c.row0 = 0; c.nrows = c.num_tiles * c.rps; c.slot0 = 0; c.coop_tile0 = 0;
         SbPlan plan;
-        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 8) ? c.num_tiles : 0;
+        plan.chunks = {c}; plan.total_slots = c.num_tiles * c.rps; plan.coop_tiles = (c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9) ? c.num_tiles : 0;
         double ms[2] = {0, 0};
         for (int k = 0; k < 2; ++k) {
             const int steps = k == 0 ? steps_a : steps_b;
@@ -521,6 +568,12 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         const double u1 = time_shape(SbChunk{8, 0, 0, 1, 0, 32, 16, 0, 0, 0, 0}), uf = time_shape(SbChunk{8, 0, 0, cap, 0, 32, 16, 0, 0, 0, 0});
         if (u1 < 0 || uf < 0) rc = 4; else { t.hp[0] = u1; t.hp[1] = uf; }
     }
+    for (int nt = 1; nt <= 2 && rc == 0 && h->coopw_ok; ++nt) {
+        const int u = 32 * nt, cap = h->num_cus_real / (h->H / u);
+        if (cap <= 0) continue;
+        const double u1 = time_shape(SbChunk{9, 0, 0, 1, 0, 32, u, 0, 0, 0, 0}), uf = cap > 1 ? time_shape(SbChunk{9, 0, 0, cap, 0, 32, u, 0, 0, 0, 0}) : u1;
+        if (u1 < 0 || uf < 0) rc = 4; else { t.coopw[nt - 1][0] = u1; t.coopw[nt - 1][1] = uf; }
+    }
     if (rc == 0 && h->lstm16_ok) {
         const double us16 = time_shape(SbChunk{4, 0, 0, h->num_cus_real, 0, 16, 0, 0, 0, 0, 0});
         if (us16 < 0) rc = 4; else t.rowtile16 = us16;
@@ -528,9 +581,9 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     cleanup();
 #undef FSNP_CAL_CHECK
     if (rc) { if (g_last_error.empty()) set_error("calibration of the sub-band planner failed"); return rc; }
-    if (*reinterpret_cast<volatile unsigned*>(h->d_err) != 0) {
+    if ((*reinterpret_cast<volatile unsigned*>(h->d_err) & kErrTimeout) != 0) {
         // a calibration launch gave up (its workgroups were not all resident): never plan two workgroups per CU
-        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
+        *reinterpret_cast<volatile unsigned*>(h->d_err) &= ~kErrTimeout;
         t = default_costs();
         h->coop_occ = 1;
     }
@@ -539,6 +592,76 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     if (adopt) { h->cost = t; drop_graphs(h); }
     std::lock_guard<std::mutex> lk(g_cal_mu);
     g_cal_cache[key] = t;
+    return 0;
+}
+
+// ---- fsnp_set_verify: the sequences a plan hands to column-split kernels, run again on the one-tile-per-CU kernel (no inter-workgroup
+// exchange at all) into a scratch mask and compared on the device.  The kernels sum K in different orders, so "equal" is a tolerance:
+// |a - b| <= 1e-4 + 1e-3 |b| (kernel-to-kernel differences are ~1e-6; one corrupted exchange element moves the mask by 1e-2 and more).
+__global__ __launch_bounds__(256) void verify_compare_kernel(const float* __restrict__ out, const float* __restrict__ ref, const RowDesc* __restrict__ rows,
+                                                             int num_slots, int T, int OC, long stride_o, unsigned* err_host) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)num_slots * OC * T) return;
+    const int t = (int)(i % T), o = (int)((i / T) % OC), slot = (int)(i / ((long)OC * T));
+    const RowDesc rd = rows[slot];
+    if (!rd.valid) return;
+    const size_t at = (size_t)rd.out_off + (size_t)o * stride_o + t;
+    const float a = out[at], b = ref[at];
+    if (!(fabsf(a - b) <= 1e-4f + 1e-3f * fabsf(b))) {
+        const unsigned key = ((unsigned)(rd.b & 255) << 24) | ((unsigned)(rd.f & 1023) << 14) | (unsigned)(t & 16383);
+        __hip_atomic_fetch_min(err_host + 4, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or(err_host, kErrVerify, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+static bool plan_has_exchange(const SbPlan& plan) {
+    for (const SbChunk& c : plan.chunks) if (c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9) return true;
+    return false;
+}
+// `a` = the arguments of the forward's own sub-band launches (its rows / md_row belong to `plan`); out_elems = floats of the mask tensor
+static int verify_pass(fsnp_handle* h, const SbPlan& plan, const Dims& d, int mode, int batch_offset, int global_batch, const LstmArgs& a,
+                       const SubbandBuffers& sbuf, size_t out_elems, hipStream_t s) {
+    const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
+    // the exchange-free plan of exactly the column-split chunks' sequences
+    SbPlan vp;
+    for (const SbChunk& c : plan.chunks) {
+        if (!(c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9)) continue;
+        PlannerCtx pc = pctx(h);
+        pc.lstm_coop = 0;
+        const SbPlan one = plan_sb(pc, c.nrows);
+        for (SbChunk k : one.chunks) {
+            if (k.kind != 0 && k.kind != 4) { set_error("fsnp_set_verify: no exchange-free kernel for this model"); return 2; }
+            k.row0 += c.row0; k.slot0 = vp.total_slots; k.coop_tile0 = 0;
+            vp.total_slots += k.num_tiles * k.rps;
+            vp.chunks.push_back(k);
+        }
+    }
+    if (vp.chunks.empty()) return 0;
+    const size_t out_b = align_up(out_elems * 4, 256), rows_b = align_up((size_t)vp.total_slots * sizeof(RowDesc), 256);
+    const size_t md_b = cumulative ? align_up((size_t)vp.total_slots * d.Tp * sizeof(NormMD), 256) : 0;
+    const size_t need = out_b + rows_b + md_b;
+    if (need > h->verify_bytes) {
+        if (h->verify_out) FSNP_HIP_CHECK(hipFreeAsync(h->verify_out, s));
+        h->verify_out = nullptr; h->verify_bytes = 0;
+        FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&h->verify_out), need, s));
+        h->verify_bytes = need;
+    }
+    unsigned char* vb = reinterpret_cast<unsigned char*>(h->verify_out);
+    RowDesc* vrows = reinterpret_cast<RowDesc*>(vb + out_b);
+    NormMD* vmd = cumulative ? reinterpret_cast<NormMD*>(vb + out_b + rows_b) : nullptr;
+    launch_build_rows(vp, vrows, h->F, d.T, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, h->cfg.output_size, s);
+    if (cumulative) {
+        SubbandBuffers vs = sbuf;
+        vs.md_row = vmd;
+        launch_subband_stats(d, h->cfg.norm_type, vs, vrows, vp.total_slots, s);      // (cumulative norms: per-slot tables only)
+    }
+    LstmArgs va = a;
+    va.rows = vrows; va.md_row = vmd; va.out = reinterpret_cast<float*>(vb);
+    launch_sb_lstm(h, vp, va, nullptr, nullptr, nullptr, s);
+    const long n = (long)vp.total_slots * h->cfg.output_size * d.T;
+    hipLaunchKernelGGL(verify_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.out, reinterpret_cast<const float*>(vb), vrows,
+                       vp.total_slots, d.T, h->cfg.output_size, a.out_stride_o, h->d_err);
+    FSNP_HIP_CHECK(hipGetLastError());
+    h->verify_runs += 1;
     return 0;
 }
 
@@ -661,6 +784,11 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         h->coop_hp_cfg = h->coop_hp;
         h->hp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
     }
+    {
+        const char* we = getenv("FSNP_COOP_W");           // 0 = never plan the wave-owned column split (lstm_coopw.hip)
+        h->coop_w = we && we[0] == '0' ? 0 : 1;
+        h->coopw_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384;
+    }
     const char* dsm = getenv("FSNP_DEFER_SMALL");
     if (dsm && dsm[0] == '0') h->defer_small = 0;
     const char* sk = getenv("FSNP_COOP_SKEW");
@@ -671,6 +799,7 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         return 4;
     }
     memset(h->d_err, 0, 256);
+    h->d_err[4] = 0xFFFFFFFFu;                     // smallest (utterance, bin, frame) key of a failed verification (atomic min)
     const char* cg = getenv("FSNP_COMPOSITE_GAIN");      // tuning: 0 = never split a batch into row-tile rounds + remainder
     if (cg) h->composite_gain = atof(cg);
     const char* gp = getenv("FSNP_GRAPH");
@@ -697,6 +826,8 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->d_stft) (void)hipFree(h->d_stft);
     if (h->d_weights) (void)hipFree(h->d_weights);
+    drop_weight_watch(h);
+    if (h->verify_out) (void)hipFree(h->verify_out);
     if (h->d_err) (void)hipHostFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
@@ -720,12 +851,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     const bool fsn = h->model == FSNP_MODEL_FULLSUBNET;
     if (!fsn && !is_complex && (!real || !imag)) { set_error("fsnp_forward: null argument (FullSubNet+ takes mag, real and imag)"); return 1; }
     if (!h->committed) { set_error("fsnp_forward: weights not committed (call fsnp_commit_weights)"); return 2; }
-    if (*reinterpret_cast<volatile unsigned*>(h->d_err) != 0) {     // set by an earlier launch that has finished since
-        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
-        set_error("an earlier forward on this handle failed: an inter-workgroup wait timed out in a column-split LSTM kernel "
-                  "(its workgroups were not co-resident - is the GPU shared?); that result was invalid - set FSNP_LSTM_COOP=0");
-        return 5;
-    }
+    if (const int ec = take_device_errors(h, "an earlier forward on this handle failed")) return ec;     // set by a launch that has finished since
     if (mode != FSNP_MODE_FULL && mode != FSNP_MODE_PARITY) { set_error("unknown mode %d", mode); return 2; }
     if (mode == FSNP_MODE_PARITY && (h->cfg.num_groups_in_drop_band < 2 || global_batch <= h->cfg.num_groups_in_drop_band)) {
         set_error("PARITY mode needs num_groups_in_drop_band >= 2 and a global batch larger than it (feature.py:263)");
@@ -765,6 +891,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     unsigned char* base = h->ws + (size_t)slot * h->ws_bytes;
     auto fptr = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
 
+    // fsnp_watch_weights: fingerprint the caller's source tensors in front of this forward (a .data edit since the pack flags the handle)
+    if (h->watch_nseg > 0 && (h->watch_calls++ % h->watch_every) == 0 && launch_weight_watch(h, s, false)) return 4;
     TimingRec rec{};
     if (h->timing) {
         if (take_timing_rec(h, rec)) return 4;
@@ -885,19 +1013,22 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     // idle too (B = 1: 216 of 256 busy, latency-bound), and the next forward's full-band stages fit beside them.
     int ndefer = 0;
     bool defer_all = false;
-    auto fills_chip = [](const SbChunk& c) { return c.kind == 0 || c.kind == 4; };       // one (half) tile per CU, no exchange
-    if (h->pipeline && plan.chunks.size() > 1 && fills_chip(plan.chunks[0])) {
-        ndefer = 1;
-        while (ndefer < (int)plan.chunks.size() && fills_chip(plan.chunks[ndefer])) ++ndefer;
-        if (ndefer == (int)plan.chunks.size()) ndefer = 0;
-    } else if (h->pipeline && h->defer_small && !fills_chip(plan.chunks[0])) {
-        // ... if its launches leave room: they own their CUs, and the overlapped stages crawl on what is left (B = 5: 246 of 256
-        // CUs taken, full-band stage 0.5 -> 5.4 ms: no gain)
-        int busiest = 0;
-        for (const SbChunk& c : plan.chunks) busiest = std::max(busiest, chunk_workgroups(h, c));
-        defer_all = busiest <= h->num_cus_real - 32;
+    // fsnp_set_verify: every Nth forward with a column-split launch is checked against the exchange-free kernel (nothing deferred then)
+    const bool verify_now = h->verify_every > 0 && plan_has_exchange(plan) && (h->verify_calls++ % h->verify_every) == 0;
+    a.coop_corrupt = h->corrupt_exchange; h->corrupt_exchange = 0;
+    if (verify_now) {
+        launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, s, h->timing ? rec.e[3] : nullptr);
+        if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], s));
+        const size_t out_elems = (size_t)(mode == FSNP_MODE_PARITY ? global_batch : batch) * h->cfg.output_size * rows_per_utt(h, mode) * frames;
+        if (const int vr = verify_pass(h, plan, d, mode, batch_offset, global_batch, a, sbuf, out_elems, s)) return vr;
+    } else if (h->pipeline) {
+        const int first = plan_first_deferred(h, plan);
+        if (first == 0) defer_all = true;
+        else if (first < (int)plan.chunks.size()) ndefer = first;
     }
-    if (defer_all) {
+    if (verify_now) {
+        // (launched above)
+    } else if (defer_all) {
         FSNP_HIP_CHECK(hipEventRecord(h->ev_main, s));
         FSNP_HIP_CHECK(hipStreamWaitEvent(h->side_stream, h->ev_main, 0));
         launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, h->side_stream, h->timing ? rec.e[3] : nullptr);
@@ -954,6 +1085,7 @@ int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t 
     }
     if (ensure_workspace(h, need, s)) return 4;
     if (max_samples > 0) {
+        if (h->cfg.output_size != 2) { set_error("fsnp_reserve: max_samples > 0 sizes the waveform path, which needs output_size = 2 (this handle: %d)", h->cfg.output_size); return 2; }
         if (ensure_stft(h)) return 2;
         const StftPlan p = stft_plan(h);
         const int T = 1 + max_samples / p.hop;
@@ -1044,17 +1176,11 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     h.cost = default_costs(); h.coop_occ = workgroups_per_cu >= 2 ? 2 : 1;
     for (int i = 0; i < 4; ++i) h.occ_ksplit[i] = h.coop_occ;
     for (int i = 0; i < 2; ++i) h.occ_coopn[i] = h.coop_occ;
-    if (costs) {
-        for (int i = 0; i < 4; ++i) { h.cost.ksplit[i][0] = costs[2 * i]; h.cost.ksplit[i][1] = costs[2 * i + 1]; }
-        for (int i = 0; i < 2; ++i) { h.cost.coopn[i][0] = costs[8 + 2 * i]; h.cost.coopn[i][1] = costs[9 + 2 * i]; }
-        h.cost.rowtile = costs[12]; h.cost.rowtile_ex = costs[13];
-        for (int i = 0; i < 4; ++i) h.cost.ksplit1[i] = costs[14 + i];
-        h.cost.rowtile16 = costs[18];
-        for (int i = 0; i < 4; ++i) h.cost.pp[i] = costs[20 + i];
-        h.cost.hp[0] = costs[24]; h.cost.hp[1] = costs[25];
-    }
+    if (costs) costs_from_array(h.cost, costs);
     h.hp_ok = gru == 0 && (hidden == 384 || hidden == 256);
     h.coop_hp = 1;
+    h.coopw_ok = gru == 0 && hidden == 384;
+    h.coop_w = 1;
     h.lstm16_ok = gru == 0 && hidden == 384;
     h.rowtile_ok = gru == 0 || gru == 2;      // gru = 1: plan as if there were no one-tile-per-CU GRU kernel (round-1 shape)
     h.gru = gru != 0;
@@ -1064,39 +1190,30 @@ int fsnp_debug_plan_rows2(int32_t num_rows, int32_t num_cus, int32_t hidden, int
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
         int32_t* o = out + 8 * n;
-        o[0] = c.kind; o[1] = c.row0; o[2] = c.nrows; o[3] = c.num_tiles; o[4] = c.ex; o[5] = c.kind == 1 ? c.units : c.groups;      // (kind 6: groups)
+        o[0] = c.kind; o[1] = c.row0; o[2] = c.nrows; o[3] = c.num_tiles; o[4] = c.ex; o[5] = (c.kind == 1 || c.kind == 9) ? c.units : c.groups;
         o[6] = c.rpg; o[7] = c.slot0;
         ++n;
     }
     return n;
 }
 
-int fsnp_get_costs(const fsnp_handle* h, double out[26], int32_t* calibrated, int32_t* occ) {
+int fsnp_get_costs(const fsnp_handle* h, double out[FSNP_NUM_COSTS], int32_t* calibrated, int32_t* occ) {
     if (!h || !out) { set_error("fsnp_get_costs: null argument"); return 1; }
-    for (int i = 0; i < 4; ++i) { out[2 * i] = h->cost.ksplit[i][0]; out[2 * i + 1] = h->cost.ksplit[i][1]; }
-    for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = h->cost.coopn[i][0]; out[9 + 2 * i] = h->cost.coopn[i][1]; }
-    out[12] = h->cost.rowtile; out[13] = h->cost.rowtile_ex;
-    for (int i = 0; i < 4; ++i) out[14 + i] = h->cost.ksplit1[i];
-    out[18] = h->cost.rowtile16; out[19] = 0.0;
-    for (int i = 0; i < 4; ++i) out[20 + i] = h->cost.pp[i];
-    out[24] = h->cost.hp[0]; out[25] = h->cost.hp[1];
+    static_assert(kNumCosts == FSNP_NUM_COSTS, "planner.h and fsnp.h agree on the flat table");
+    costs_to_array(h->cost, out);
     if (calibrated) *calibrated = h->cost.calibrated;
     if (occ) *occ = h->coop_occ;
     return 0;
 }
 
-int fsnp_measure_costs(fsnp_handle* h, double out[26]) {
+int fsnp_measure_costs(fsnp_handle* h, double out[FSNP_NUM_COSTS]) {
     if (!h || !out) { set_error("fsnp_measure_costs: null argument"); return 1; }
     if (!h->committed) { set_error("fsnp_measure_costs: weights not committed"); return 2; }
     if (h->sb_tcn) { set_error("fsnp_measure_costs: the sub-band model of this handle is a TCN (no recurrent kernels)"); return 2; }
     FSNP_ON_DEVICE(h);
     CostTable t = h->cost;
     if (calibrate_costs(h, false, &t)) return 4;
-    for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
-    for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
-    out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16; out[19] = 0.0;
-    for (int i = 0; i < 4; ++i) out[20 + i] = t.pp[i];
-    out[24] = t.hp[0]; out[25] = t.hp[1];
+    costs_to_array(t, out);
     return 0;
 }
 
@@ -1104,15 +1221,7 @@ int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups
     if (!h || (workgroups_per_cu != 1 && workgroups_per_cu != 2)) { set_error("fsnp_debug_set_costs: bad argument"); return 1; }
     if (!h->committed) { set_error("fsnp_debug_set_costs: commit the weights first (the kernels' occupancy is checked then)"); return 2; }
     h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
-    if (costs) {
-        for (int i = 0; i < 4; ++i) { h->cost.ksplit[i][0] = costs[2 * i]; h->cost.ksplit[i][1] = costs[2 * i + 1]; }
-        for (int i = 0; i < 2; ++i) { h->cost.coopn[i][0] = costs[8 + 2 * i]; h->cost.coopn[i][1] = costs[9 + 2 * i]; }
-        h->cost.rowtile = costs[12]; h->cost.rowtile_ex = costs[13];
-        for (int i = 0; i < 4; ++i) h->cost.ksplit1[i] = costs[14 + i];
-        h->cost.rowtile16 = costs[18];
-        for (int i = 0; i < 4; ++i) h->cost.pp[i] = costs[20 + i];
-        h->cost.hp[0] = costs[24]; h->cost.hp[1] = costs[25];
-    }
+    if (costs) costs_from_array(h->cost, costs);
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
     drop_graphs(h);
@@ -1125,9 +1234,8 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        // kind 4 = half-tile kernel, 5 = role-split K split, 7..10 = ping-pong K split with 1..4 row tiles per group, 11 = runtime-sized kernel,
-        // 12 = half-tile ping-pong (lstm_hp.hip)
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind);
+        // kind 4 = half-tile kernel, 11 = runtime-sized kernel, 12 = half-tile ping-pong (lstm_hp.hip), 13 = wave-owned column split (lstm_coopw.hip)
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind == 9 ? 13 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }
@@ -1140,16 +1248,18 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
     const int n = fsnp_describe_plan(h, batch, mode, base, max_chunks < 64 ? max_chunks : 64);
     if (n < 0) return n;
     const SbPlan plan = plan_sb(h, batch * rows_per_utt(h, mode));
+    const int first_deferred = plan_first_deferred(h, plan);
     for (int i = 0; i < n; ++i) {
         const SbChunk& c = plan.chunks[i];
-        for (int k = 0; k < 4; ++k) out[6 * i + k] = base[4 * i + k];
+        for (int k = 0; k < 4; ++k) out[7 * i + k] = base[4 * i + k];
         // arithmetic of THIS chunk: the bf16 variants exist for the one-tile-per-CU LSTM kernel only (lstm.hip / lstm_bf3.hip);
         // sequences that the plan hands to any other kernel run in fp32 whatever fsnp_set_precision says
         int prec = 0;
         if (!h->sb_tcn && !h->gru && c.kind == 0) prec = h->ih_bf16 == 1 ? 1 : (h->ih_bf16 == 2 && c.ex == 0) ? 2 : 0;
         if (!h->sb_tcn && !h->gru && c.kind == 4 && h->ih_bf16 == 1 && h->lw.wpack16_bf) prec = 1;       // half-tile kernel: bf16 ih-GEMM too (round 4)
-        out[6 * i + 4] = prec;
-        out[6 * i + 5] = h->sb_tcn ? 0 : chunk_workgroups(h, c);
+        out[7 * i + 4] = prec;
+        out[7 * i + 5] = h->sb_tcn ? 0 : chunk_workgroups(h, c);
+        out[7 * i + 6] = i >= first_deferred ? 1 : 0;        // the pipelined loop runs this launch on the side stream
     }
     return n;
 }
@@ -1184,17 +1294,17 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
 int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps, int32_t tiles_per_group,
                           uint64_t* host_stamps, int64_t num_stamps) {
     if (!h || !x || !out || !host_stamps) { set_error("fsnp_debug_pp_profile: null argument"); return 1; }
-    if (!h->committed || !h->hp_ok) { set_error("fsnp_debug_pp_profile: no half-tile ping-pong kernel for this handle"); return 2; }
-    // tiles_per_group: 0 = the half-tile ping-pong kernel (lstm_hp.hip: 2 halves x 16 stamps per step) - the only kernel left that stamps
-    // (1..4 used to select the round-3 ping-pong K-split kernel lstm_pp.hip, removed in round 4)
-    if (tiles_per_group != 0 || num_stamps != (int64_t)steps * 32) { set_error("fsnp_debug_pp_profile: tiles_per_group must be 0 (half-tile ping-pong kernel) with steps * 32 stamps"); return 2; }
-    const bool hp = true;
-    const int tiles = cdiv(num_seq, 32), groups = tiles;
-    if (num_seq <= 0 || groups * (h->H / 16) > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
+    if (!h->committed || (!h->hp_ok && tiles_per_group == 0)) { set_error("fsnp_debug_pp_profile: no half-tile ping-pong kernel for this handle"); return 2; }
+    // tiles_per_group: 0 = the half-tile ping-pong kernel (lstm_hp.hip: 2 halves x 16 stamps per step); 32 / 64 = the wave-owned column
+    // split (lstm_coopw.hip) at that many units per workgroup (16 stamps per step: 8 per layer phase)
+    const bool hp = tiles_per_group == 0, cw = tiles_per_group == 32 || tiles_per_group == 64;
+    if ((!hp && !cw) || num_stamps != (int64_t)steps * (hp ? 32 : 16)) { set_error("fsnp_debug_pp_profile: tiles_per_group must be 0 (half-tile ping-pong kernel, steps * 32 stamps) or 32 / 64 (wave-owned column split, steps * 16 stamps)"); return 2; }
+    if (cw && !h->coopw_ok) { set_error("fsnp_debug_pp_profile: no wave-owned column split for this handle"); return 2; }
+    const int tiles = cdiv(num_seq, 32), groups = tiles, S = hp ? h->H / 16 : h->H / tiles_per_group;
+    if (num_seq <= 0 || groups * S > h->num_cus_real) { set_error("fsnp_debug_pp_profile: the launch must fit the chip"); return 2; }
     FSNP_ON_DEVICE(h);
     SbPlan plan;
-    (void)hp; (void)groups;
-    plan.chunks = {SbChunk{8, 0, num_seq, tiles, 0, 32, 16, 0, 0, 0, 0}};
+    plan.chunks = {hp ? SbChunk{8, 0, num_seq, tiles, 0, 32, 16, 0, 0, 0, 0} : SbChunk{9, 0, num_seq, tiles, 0, 32, tiles_per_group, 0, 0, 0, 0}};
     plan.total_slots = tiles * 32; plan.coop_tiles = tiles;
     const size_t rows_b = align_up((size_t)plan.total_slots * sizeof(RowDesc), 256), hx_b = align_up(lstm_coop_exchange_bytes(h->H, tiles), 256);
     const size_t bar_b = align_up(coop_counter_bytes(tiles), 256), st_b = (size_t)num_stamps * 8;
@@ -1228,13 +1338,24 @@ int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
 
 int fsnp_poll_errors(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
-    const unsigned e = *reinterpret_cast<volatile unsigned*>(h->d_err);
-    if (e != 0) {
-        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
-        set_error("column-split LSTM kernel: an inter-workgroup wait timed out (its workgroups were not co-resident - is the "
-                  "GPU shared with another process?); the result of that call is invalid.  FSNP_LSTM_COOP=0 avoids these kernels");
-        return 5;
+    return take_device_errors(h, "fsnp_poll_errors");
+}
+
+int fsnp_set_verify(fsnp_handle* h, int32_t every) {
+    if (!h || every < 0) { set_error("fsnp_set_verify: every must be >= 0 (0 = off)"); return 1; }
+    if (every > 0 && (!h->rowtile_ok || h->sb_tcn || h->generic_sb)) {
+        set_error("fsnp_set_verify: this model has no exchange-free (one-tile-per-CU) kernel to verify against");
+        return 2;
     }
+    h->verify_every = every; h->verify_calls = 0;
+    return 0;
+}
+
+int64_t fsnp_verify_count(const fsnp_handle* h) { return h ? (int64_t)h->verify_runs : -1; }
+
+int fsnp_debug_corrupt_exchange(fsnp_handle* h, int32_t step) {
+    if (!h || step < 0) { set_error("fsnp_debug_corrupt_exchange: step must be >= 0 (0 = off)"); return 1; }
+    h->corrupt_exchange = step;
     return 0;
 }
 
@@ -1279,14 +1400,7 @@ int fsnp_check_errors(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
     FSNP_ON_DEVICE(h);
     FSNP_HIP_CHECK(hipDeviceSynchronize());
-    const unsigned e = *reinterpret_cast<volatile unsigned*>(h->d_err);
-    if (e != 0) {
-        *reinterpret_cast<volatile unsigned*>(h->d_err) = 0;
-        set_error("cooperative LSTM kernel: an inter-workgroup wait timed out (a workgroup was not resident); the "
-                  "results of that forward are invalid - set FSNP_LSTM_COOP=0");
-        return 5;
-    }
-    return 0;
+    return take_device_errors(h, "fsnp_check_errors");
 }
 
 int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
@@ -1310,6 +1424,7 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("effective settings (environment variable as read at fsnp_create = value in force):\n");
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
     add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
+    add("  FSNP_COOP_W=%s -> wave-owned column split (lstm_coopw.hip) %s\n", env("FSNP_COOP_W"), !h->coopw_ok ? "not built for this model" : h->coop_w ? "planned" : "never");
     add("  FSNP_COOP_SKEW=%s -> K-split schedule %s (FSNP_SKEW_MIN_UNITS=%s: smallest units per workgroup that run it, default 8)\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial", env("FSNP_SKEW_MIN_UNITS"));
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
     add("  FSNP_COOP_XCD=%s (0 = no XCD-local workgroup placement)  FSNP_OWN_CU=%s (0 = deferred chunks do not claim their CUs' LDS)\n", env("FSNP_COOP_XCD"), env("FSNP_OWN_CU"));
@@ -1321,10 +1436,10 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_GRAPH=%s -> %d (0 plain launches, 1 / 2 hipGraph replay of the full-band stages)\n", env("FSNP_GRAPH"), h->use_graph);
     add("  FSNP_GEMM_DMA=%s -> %d  FSNP_GEMM_BN=%s FSNP_GEMM_PF=%s (tuning of the general GEMM kernel)  FSNP_GEMM_SPLITK=%s (small-batch split-K GEMM up to this many workgroups per CU, default 6, 0 = never)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma, env("FSNP_GEMM_BN"), env("FSNP_GEMM_PF"), env("FSNP_GEMM_SPLITK"));
     add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
-    add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, ping-pong %.1f / %.1f / %.1f / %.1f\n",
+    add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, half-tile ping-pong %.1f / %.1f, wave-owned split full %.1f / %.1f, one tile %.1f / %.1f\n",
         h->cost.ksplit[0][0], h->cost.ksplit[1][0], h->cost.ksplit[2][0], h->cost.ksplit[3][0], h->cost.ksplit1[0], h->cost.ksplit1[1],
         h->cost.ksplit1[2], h->cost.ksplit1[3], h->cost.coopn[0][0], h->cost.coopn[1][0], h->cost.rowtile, h->cost.rowtile_ex, h->cost.rowtile16,
-        h->cost.pp[0], h->cost.pp[1], h->cost.pp[2], h->cost.pp[3]);
+        h->cost.hp[0], h->cost.hp[1], h->cost.coopw[0][1], h->cost.coopw[1][1], h->cost.coopw[0][0], h->cost.coopw[1][0]);
     if (buf && cap > 0) {
         const size_t n = o.size() < (size_t)cap - 1 ? o.size() : (size_t)cap - 1;
         memcpy(buf, o.data(), n);
@@ -1335,7 +1450,7 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
 
 int fsnp_debug_inject_error(fsnp_handle* h) {
     if (!h) { set_error("null handle"); return 1; }
-    *reinterpret_cast<volatile unsigned*>(h->d_err) = 1u;
+    *reinterpret_cast<volatile unsigned*>(h->d_err) |= kErrTimeout;
     return 0;
 }
 
@@ -1359,9 +1474,9 @@ int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
 }
 
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule), 3 (= 1; selected the ping-pong K split lstm_pp.hip until round 4 removed it) or 4 (auto + the half-tile ping-pong kernel even where FSNP_COOP_HP=0)"); return 1; }
+    if (!h || mode < 0 || mode > 4 || mode == 3) { set_error("fsnp_debug_set_lstm_coop: mode must be 0 (off), 1 (auto), 2 (auto, serial K-split schedule, no half-tile ping-pong kernel) or 4 (auto + the half-tile ping-pong kernel even where FSNP_COOP_HP=0)"); return 1; }
     h->lstm_coop = mode != 0;
-    h->coop_skew = mode == 1 || mode >= 3;
+    h->coop_skew = mode != 2;
     h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
@@ -1407,6 +1522,18 @@ int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, in
         return 2;
     }
     lstm_coop_pack_weights(hidden, input_size, kx, units, wih0, whh0, wih1, whh1, out);
+    return 0;
+}
+
+int fsnp_debug_lstm_coopw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
+                               const float* whh1, float* out, int64_t out_floats) {
+    if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_coopw_pack: null argument"); return 1; }
+    if (hidden % 32 != 0 || kx % 8 != 0 || input_size > kx) { set_error("fsnp_debug_lstm_coopw_pack: bad sizes"); return 2; }
+    if ((int64_t)lstm_coopw_pack_floats(hidden, kx) != out_floats) {
+        set_error("fsnp_debug_lstm_coopw_pack: need %lld floats", (long long)lstm_coopw_pack_floats(hidden, kx));
+        return 2;
+    }
+    lstm_coopw_pack_weights(hidden, input_size, kx, wih0, whh0, wih1, whh1, out);
     return 0;
 }
 

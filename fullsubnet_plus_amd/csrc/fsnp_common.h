@@ -163,6 +163,7 @@ struct LstmWeights {
     const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     const float* wpack_hp;      // half-tile ping-pong kernel (lstm_hp.hip): [column slice of 16 units][gate][k-group of 16][lane][4]
+    const float* wpack_coopw;   // wave-owned column split (lstm_coopw.hip): [k-group][8-unit block, gate-interleaved columns][lane][4]; nullptr = not packed
     const float* wgen;          // runtime-sized kernel (lstm_generic.hip): transposed [layer][k][4H], layer 0 k = [x | h0], layer 1 = [h0 | h1]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
     int waves;           // 4 or 12 waves per workgroup
@@ -209,6 +210,8 @@ struct LstmArgs {
                                // concurrent kernel that needs LDS shares the CU (deferred remainder chunk in the pipelined loop)
     int coop_groups;           // lstm_coopn.hip: groups of 3 workgroups; group g owns row tiles g, g + groups
     int coop_rows_per_group;   // lstm_coopn.hip: 1 or 2 row tiles per group; lstm_generic.hip: sequences per workgroup
+    int coop_corrupt;          // test hook (fsnp_debug_corrupt_exchange): > 0 = the workgroup / wave that owns hidden unit 0 of row tile 0 publishes
+                               // h0 of row 0 at step coop_corrupt - 1 with 1.0 added (its own state stays right): a corrupted exchange image
     int coop_chaos;            // test hook (fsnp_debug_set_chaos): != 0 = seed of pseudo-random, workgroup-uniform delays at the phase boundaries
                                // of the column-split kernels, so that the workgroups of a launch drift apart instead of running in lockstep
 };
@@ -245,6 +248,13 @@ void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 bool lstm_hp_available(const LstmWeights& w);
 size_t lstm_hp_pack_floats(int H, int KX);
 void lstm_hp_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
+// lstm_coopw.hip: a wave owns 8 NT hidden units over the full K, S = H / (32 NT) workgroups per row tile (a.coop_units = 32 NT in
+// {32, 64}), layer-skewed schedule without workgroup barriers: 11 ... 42 row tiles per launch (B = 2 ... 8)
+void launch_lstm_coopw(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+bool lstm_coopw_available(const LstmWeights& w, int units);
+int lstm_coopw_occupancy(const LstmWeights& w, int units);
+size_t lstm_coopw_pack_floats(int H, int KX);
+void lstm_coopw_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 // lstm_generic.hip: runtime-sized fp32-FMA kernel for the sizes no tuned kernel is instantiated for (any hidden size / input width);
 // a.num_tiles workgroups of a.coop_rows_per_group (1, 2, 4, 8) sequences; seq = the full-band model of the original FullSubNet
 void launch_lstm_generic(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s);

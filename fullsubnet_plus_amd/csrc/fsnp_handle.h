@@ -107,9 +107,24 @@ struct fsnp_handle {
                                  // input width no tuned kernel is instantiated for
     bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
-    int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0 / 1; fsnp_debug_set_lstm_coop(h, 4) = only it)   // ... and the planner may use it (opt-in: FSNP_COOP_PP=1 / fsnp_debug_set_lstm_coop(h, 3))
-    unsigned* d_err = nullptr;   // [0] = an inter-workgroup wait timed out in a column-split LSTM kernel.  Host-mapped,
-                                 // so the NEXT call on the handle can fail loudly without a device synchronisation
+    int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0: never; fsnp_debug_set_lstm_coop(h, 4): even then)
+    bool coopw_ok = false;       // the wave-owned column split (lstm_coopw.hip) exists for this handle's sub-band model (LSTM, H = 384) ...
+    int coop_w = 1;              // ... and the planner may use it (FSNP_COOP_W=0: never)
+    unsigned* d_err = nullptr;   // [0] = error bits of finished launches (kErr*): an inter-workgroup wait timed out in a column-split LSTM
+                                 // kernel / the watched source tensors no longer match the packed weights / a verification pass
+                                 // disagreed; [4..7] = where the verification pass first disagreed.  Host-mapped, so the NEXT call on
+                                 // the handle can fail loudly without a device synchronisation
+    // fsnp_watch_weights: the caller's SOURCE tensors of the packed weights, fingerprinted on the device in front of every forward
+    void* watch_segs = nullptr;              // device: WatchSeg[watch_nseg]
+    unsigned long long* watch_acc = nullptr; // device: {running sum, finished blocks, baseline}
+    int watch_nseg = 0, watch_every = 1;
+    long long watch_calls = 0;
+    // fsnp_set_verify: every Nth forward whose plan holds a column-split launch is re-run on the one-tile-per-CU kernel and compared
+    int verify_every = 0;
+    long long verify_calls = 0, verify_runs = 0;
+    float* verify_out = nullptr;             // scratch mask of the verification pass (stream-ordered allocation)
+    size_t verify_bytes = 0;
+    int corrupt_exchange = 0;                // fsnp_debug_corrupt_exchange: flip one word of the next column-split launch's exchange (test hook)
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 
     // STFT / iSTFT around the model (stft.hip): DFT GEMM operands, built on first use, and an I/O workspace
@@ -149,6 +164,13 @@ struct fsnp_handle {
 namespace fsnp {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// bits of the host-mapped error word (fsnp_handle::d_err[0])
+constexpr unsigned kErrTimeout = 1u, kErrStaleWeights = 2u, kErrVerify = 4u;
+// fsnp_weights.hip: fingerprint of the watched source tensors on stream s (no-op without a watch)
+int launch_weight_watch(fsnp_handle* h, hipStream_t s, bool baseline);
+void drop_weight_watch(fsnp_handle* h);
+// decodes and clears the error word: 0 = clean, else the return code of the call that notices (5 time-out, 6 stale weights, 7 verify) + message
+int take_device_errors(fsnp_handle* h, const char* where);
 void drop_graphs(fsnp_handle* h);
 // fsnp_weights.hip
 void build_specs(fsnp_handle* h);

@@ -108,6 +108,9 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
     if (!h || !wav || !out) { set_error("fsnp_enhance_wave: null argument"); return 1; }
     if (batch <= 0) { set_error("fsnp_enhance_wave: empty input"); return 2; }
     if (!h->committed) { set_error("fsnp_enhance_wave: weights not committed (call fsnp_commit_weights)"); return 2; }
+    // the cIRM epilogue multiplies by exactly two mask planes (decompress_cIRM, audio_zen/acoustics/mask.py:60-63) and the io area is
+    // sized for them: a model built with another output_size has no waveform path
+    if (h->cfg.output_size != 2) { set_error("fsnp_enhance_wave: the cIRM epilogue needs output_size = 2 (this handle: %d)", h->cfg.output_size); return 2; }
     if (ensure_stft(h)) return 2;
     const StftPlan p = stft_plan(h);
     if (samples <= p.hop) { set_error("fsnp_enhance_wave: need more than n_fft/2 = %d samples (reflect padding)", p.hop); return 2; }

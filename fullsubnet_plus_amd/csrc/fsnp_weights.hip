@@ -107,9 +107,81 @@ void build_specs(fsnp_handle* h) {
     add("sb_model.fc_output_layer.bias", h->cfg.output_size);
 }
 
+// ---- fsnp_watch_weights: a 64-bit fingerprint of the caller's source tensors, taken on the device in front of every forward.
+// sum over all elements of bits(x_i) * (2 i + 1) mod 2^64 (i = position in the concatenation): any single changed element changes
+// it, the sum is order-independent (integer adds), so blocks accumulate with one atomic each and the LAST block to finish compares.
+struct WatchSeg { const unsigned* p; unsigned n; unsigned long long first; };
+__global__ __launch_bounds__(256) void weight_watch_kernel(const WatchSeg* __restrict__ segs, int nseg, unsigned long long* acc,
+                                                           int baseline, unsigned* err_host) {
+    unsigned long long sum = 0;
+    for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const WatchSeg g = segs[sg];
+        for (unsigned i = threadIdx.x; i < g.n; i += 256) sum += (unsigned long long)g.p[i] * (2ull * (g.first + i) + 1ull);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+    __shared__ unsigned long long part[4];
+    __shared__ int last;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(acc, part[0] + part[1] + part[2] + part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = __hip_atomic_fetch_add(acc + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1;
+        if (last) {
+            const unsigned long long total = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (baseline) acc[2] = total;
+            else if (total != acc[2]) __hip_atomic_fetch_or(err_host, kErrStaleWeights, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+int launch_weight_watch(fsnp_handle* h, hipStream_t s, bool baseline) {
+    if (h->watch_nseg <= 0) return 0;
+    const int grid = h->watch_nseg < 1024 ? h->watch_nseg : 1024;
+    hipLaunchKernelGGL(weight_watch_kernel, dim3(grid), dim3(256), 0, s, static_cast<const WatchSeg*>(h->watch_segs), h->watch_nseg,
+                       h->watch_acc, baseline ? 1 : 0, h->d_err);
+    FSNP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+void drop_weight_watch(fsnp_handle* h) {
+    if (h->watch_segs) (void)hipFree(h->watch_segs);
+    if (h->watch_acc) (void)hipFree(h->watch_acc);
+    h->watch_segs = nullptr; h->watch_acc = nullptr; h->watch_nseg = 0;
+}
+
 }  // namespace fsnp
 
 extern "C" {
+
+int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_t* numels, int32_t n, int32_t every, void* hip_stream) {
+    if (!h || n < 0 || (n > 0 && (!dev_ptrs || !numels)) || every < 1) { set_error("fsnp_watch_weights: bad argument"); return 1; }
+    if (!h->committed) { set_error("fsnp_watch_weights: commit the weights first (the baseline fingerprint belongs to the packed set)"); return 2; }
+    FSNP_ON_DEVICE(h);
+    FSNP_HIP_CHECK(hipDeviceSynchronize());           // (an earlier watch kernel may still read the old table)
+    drop_weight_watch(h);
+    h->watch_every = every; h->watch_calls = 0;
+    if (n == 0) return 0;
+    std::vector<WatchSeg> segs;
+    unsigned long long first = 0;
+    constexpr int64_t kSeg = 32768;                   // elements per segment: ~270 segments of work for the default model
+    for (int i = 0; i < n; ++i) {
+        if (!dev_ptrs[i] || numels[i] < 0) { set_error("fsnp_watch_weights: tensor %d is null / negative", i); return 1; }
+        for (int64_t o = 0; o < numels[i]; o += kSeg) {
+            const int64_t c = numels[i] - o < kSeg ? numels[i] - o : kSeg;
+            segs.push_back(WatchSeg{static_cast<const unsigned*>(dev_ptrs[i]) + o, (unsigned)c, first + (unsigned long long)o});
+        }
+        first += (unsigned long long)numels[i];
+    }
+    if (segs.empty()) return 0;
+    FSNP_HIP_CHECK(hipMalloc(&h->watch_segs, segs.size() * sizeof(WatchSeg)));
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->watch_acc), 256));
+    FSNP_HIP_CHECK(hipMemcpy(h->watch_segs, segs.data(), segs.size() * sizeof(WatchSeg), hipMemcpyHostToDevice));
+    FSNP_HIP_CHECK(hipMemset(h->watch_acc, 0, 256));
+    h->watch_nseg = (int)segs.size();
+    return launch_weight_watch(h, static_cast<hipStream_t>(hip_stream), true);
+}
 
 int fsnp_num_weights(const fsnp_handle* h) { return h ? (int)h->specs.size() : 0; }
 
@@ -130,6 +202,7 @@ int fsnp_set_weight(fsnp_handle* h, const char* name, const float* host_data, in
             }
             h->host_w[s.name].assign(host_data, host_data + numel);
             h->committed = false;
+            h->watch_nseg = 0;            // the watched tensors belonged to the previous weight set (fsnp_watch_weights again after the commit)
             return 0;
         }
     }
@@ -345,6 +418,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
         o_wpack_hp = alloc(lstm_hp_pack_floats(H, h->KX));
         lstm_hp_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_hp);
     }
+    size_t o_wpack_coopw = 0;
+    if (h->coopw_ok) {
+        o_wpack_coopw = alloc(lstm_coopw_pack_floats(H, h->KX));
+        lstm_coopw_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_coopw);
+    }
     const size_t o_wpack_coopn = alloc(tuned ? lstm_coopn_pack_floats(H, h->KX) : 0);
     if (tuned)
         lstm_coopn_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
@@ -405,6 +483,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_hp = d + o_wpack_hp;
+    h->lw.wpack_coopw = h->coopw_ok ? d + o_wpack_coopw : nullptr;
     h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack_bf3 = d + o_wpack_bf3;
     h->lw.wpack16 = d + o_wpack16;

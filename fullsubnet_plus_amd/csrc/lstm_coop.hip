@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void lstm2_coop_kernel(LstmWeights w, LstmArgs
                     c0[i] = cn;
                     hval = og * fast_tanh(cn);
                 }
+                if (a.coop_corrupt != 0 && rt == 0 && pk[i] == 0 && prow[i] == 0 && t + 1 == a.coop_corrupt) hval += 1.0f;     // test hook: published value only
                 xchg_store(img + a_frag_index(prow[i], pk[i]), hval);
             }
         }
@@ -685,7 +686,10 @@ __global__ __launch_bounds__(256) void lstm2_coop_skew_kernel(LstmWeights w, Lst
         if (with_c) early1 = poll_early(bar1);           // for the wait in front of the C phase that follows
         publish_tiles(acc);
         float* img = reinterpret_cast<float*>(hx + h0off(m3));
-        cell(c0, bias0, 0, [&](int i, float hval) { xchg_store(img + a_frag_index(prow[i], pk[i]), hval); });
+        cell(c0, bias0, 0, [&](int i, float hval) {
+            if (a.coop_corrupt != 0 && rt == 0 && pk[i] == 0 && prow[i] == 0 && t + 1 == a.coop_corrupt) hval += 1.0f;     // test hook: published value only
+            xchg_store(img + a_frag_index(prow[i], pk[i]), hval);
+        });
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst0 + i * 256] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;

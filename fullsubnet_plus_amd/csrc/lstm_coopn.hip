@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void lstm2_coopn_kernel(LstmWeights w, LstmArg
             for (int q = 0; q < 16; q += 2) {                  // two cells per pass: packed fp32 math (lstm_common.h)
                 const f32x2 h2 = cell_pair(acc, q, b0, c0[r]);
                 const int row = (q & 3) + 8 * (q >> 2) + rowbase;
-                xchg_store(img + a_frag_index(row, unit), h2.x);
+                const bool corrupt = a.coop_corrupt != 0 && rt[r] == 0 && unit == 0 && row == 0 && t + 1 == a.coop_corrupt;     // test hook: published value only
+                xchg_store(img + a_frag_index(row, unit), corrupt ? h2.x + 1.0f : h2.x);
                 xchg_store(img + a_frag_index(row + 1, unit), h2.y);
             }
             if (have_next) {      // the other parity: last read in step t-1, before that step's barrier

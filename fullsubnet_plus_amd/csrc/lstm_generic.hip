@@ -209,9 +209,12 @@ template <int RG, bool SEQ>
 static hipError_t generic_prepare(size_t smem) {
     auto k = lstm2_generic_kernel<RG, SEQ>;
     static PerDeviceOnce once;
-    static hipError_t attr_err = hipSuccess;
-    once.run([&] { attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
-    if (attr_err != hipSuccess) return attr_err;
+    static hipError_t attr_err[64] = {};                       // per device: a failure on one GPU is that GPU's alone
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int di = dev >= 0 && dev < 64 ? dev : 0;
+    once.run([&] { attr_err[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
+    if (attr_err[di] != hipSuccess) return attr_err[di];
     if (smem == 0) return hipSuccess;
     int blocks = 0;
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(k), kGenThreads, smem);
@@ -222,11 +225,12 @@ static hipError_t generic_prepare(size_t smem) {
 template <int RG>
 static void launch_generic_rg(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s) {
     const size_t smem = gen_smem_floats(RG, w.H, w.NIN) * 4;
+    // (a failed LDS opt-in makes the launch itself fail: forward_impl's hipGetLastError reports it - never a silent no-op)
     if (seq) {
-        (void)generic_prepare<RG, true>(0);
+        if (generic_prepare<RG, true>(0) != hipSuccess) set_error("lstm_generic: LDS opt-in of the runtime-sized kernel failed on this device");
         hipLaunchKernelGGL((lstm2_generic_kernel<RG, true>), dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     } else {
-        (void)generic_prepare<RG, false>(0);
+        if (generic_prepare<RG, false>(0) != hipSuccess) set_error("lstm_generic: LDS opt-in of the runtime-sized kernel failed on this device");
         hipLaunchKernelGGL((lstm2_generic_kernel<RG, false>), dim3(a.num_tiles), dim3(kGenThreads), smem, s, w, a);
     }
 }

@@ -396,7 +396,8 @@ void lstm2_coop_hp_kernel(LstmWeights w, LstmArgs a) {
             {
                 const f32x2 hh = lstm_cell_pair(f32x2{gf[4 * 256 + gidx], gf[0 * 256 + gidx]}, f32x2{gf[5 * 256 + gidx], gf[1 * 256 + gidx]},
                                                 f32x2{gf[6 * 256 + gidx], gf[2 * 256 + gidx]}, f32x2{gf[7 * 256 + gidx], gf[3 * 256 + gidx]}, cst[hf]);
-                sf[sdst] = hh.y;
+                // (test hook, LstmArgs::coop_corrupt: h0 of step t + 1, row 0, unit 0 of row tile 0 is published with 1.0 added)
+                sf[sdst] = (a.coop_corrupt != 0 && rt == 0 && cs == 0 && hf == 0 && cu == 0 && crow == 0 && t + 2 == a.coop_corrupt) ? hh.y + 1.0f : hh.y;
                 sf[256 + sdst] = hh.x;
                 float p0 = hh.x * wfc0, p1 = hh.x * wfc1;               // partial Linear over this workgroup's 16 units
                 p0 = row_sum16(p0); p1 = row_sum16(p1);

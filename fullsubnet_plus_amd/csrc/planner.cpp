@@ -23,11 +23,31 @@ CostTable default_costs() {
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
     t.rowtile = 206.0; t.rowtile_ex = 0.11; t.rowtile16 = 103.0;
-    // round 3 (profiles/r03_column_split.md): ping-pong K split, a full launch of 5 groups with 1 / 2 / 3 / 4 row tiles each (measured)
-    const double pp[4] = {9.9, 14.6, 22.3, 29.7};
-    for (int i = 0; i < 4; ++i) t.pp[i] = pp[i];
     t.hp[0] = 12.3; t.hp[1] = 12.9;      // half-tile ping-pong (lstm_hp.hip): one row tile / a full launch of 10
+    // round 5: wave-owned column split (lstm_coopw.hip) at 32 / 64 units per workgroup: one row tile / a full launch of 21 / 42
+    // (profiles/r05_column_split.md; a 96-unit instantiation - 64 tiles x 4 workgroups - measured 63.3 us: no better than a 42-tile
+    // launch at 64 units + a 21-tile launch at 32, and it spilled registers: not built)
+    const double cw1[2] = {21.5, 37.5}, cwf[2] = {22.8, 39.0};
+    for (int i = 0; i < 2; ++i) { t.coopw[i][0] = cw1[i]; t.coopw[i][1] = cwf[i]; }
     return t;
+}
+// flat layout (include/fsnp.h, fsnp_get_costs): [0..7] K split full launch x {one, two per CU} at 8 / 16 / 32 / 64 units, [8..11] three-way
+// split 1 / 2 row tiles per group x {one, two per CU}, [12] one tile per CU, [13] relative extra per VALU row, [14..17] K split with ONE row
+// tile, [18] half tile per CU, [19..20] half-tile ping-pong one tile / full launch, [21..23] wave-owned split full launch at 32 / 64 / 96
+// units, [24..26] the same with ONE row tile
+void costs_to_array(const CostTable& t, double* out) {
+    for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
+    for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
+    out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16;
+    out[19] = t.hp[0]; out[20] = t.hp[1];
+    for (int i = 0; i < 2; ++i) { out[21 + i] = t.coopw[i][1]; out[23 + i] = t.coopw[i][0]; }
+}
+void costs_from_array(CostTable& t, const double* in) {
+    for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = in[2 * i]; t.ksplit[i][1] = in[2 * i + 1]; t.ksplit1[i] = in[14 + i]; }
+    for (int i = 0; i < 2; ++i) { t.coopn[i][0] = in[8 + 2 * i]; t.coopn[i][1] = in[9 + 2 * i]; }
+    t.rowtile = in[12]; t.rowtile_ex = in[13]; t.rowtile16 = in[18];
+    t.hp[0] = in[19]; t.hp[1] = in[20];
+    for (int i = 0; i < 2; ++i) { t.coopw[i][1] = in[21 + i]; t.coopw[i][0] = in[23 + i]; }
 }
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
 CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
@@ -35,8 +55,9 @@ CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
     if (gru) t.rowtile *= 0.75;   // three of the four gate tiles per k-group
     if (sb_hidden != 384 && !sb_tcn) {     // scale by the work per step
         const double f = sb_hidden / 384.0;
-        for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; t.pp[i] *= f; }
+        for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; }
         t.hp[0] *= f; t.hp[1] *= f;
+        for (int i = 0; i < 2; ++i) { t.coopw[i][0] *= f; t.coopw[i][1] *= f; }
         for (int i = 0; i < 2; ++i) { t.coopn[i][0] *= f; t.coopn[i][1] *= f; }
         t.rowtile *= f * f;
     }
@@ -47,6 +68,7 @@ int chunk_workgroups(const PlannerCtx& h, const SbChunk& c) {
     if (c.kind == 1) return c.num_tiles * (h.H / c.units);
     if (c.kind == 2) return c.groups * (h.H / 128);
     if (c.kind == 8) return c.num_tiles * (h.H / 16);
+    if (c.kind == 9) return c.num_tiles * (h.H / c.units);
     return c.num_tiles;
 }
 double est_step_us(const PlannerCtx& h, const SbChunk& c) {
@@ -65,7 +87,15 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
         const double f = (double)(c.num_tiles - 1) / (cap - 1);
         return h.cost.hp[0] + (h.cost.hp[1] - h.cost.hp[0]) * (f < 1.0 ? f : 1.0);
     }
-    if (c.kind == 4) return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile16;
+    if (c.kind == 9) {
+        const int wi = c.units / 32 - 1, cap = h.num_cus_real / (h.H / c.units);
+        if (cap <= 1) return h.cost.coopw[wi][0];
+        const double f = (double)(c.num_tiles - 1) / (cap - 1);
+        return h.cost.coopw[wi][0] + (h.cost.coopw[wi][1] - h.cost.coopw[wi][0]) * (f < 1.0 ? f : 1.0);
+    }
+    // (bf16 ih-GEMM mode: the half-tile kernel streams 12 bf16 k-steps instead of 48 fp32 k-groups for layer 1's ih product - measured
+    //  11.42 vs 14.16 ms at 4096 sequences, profiles/r04_bf16_half_tile_bench.jsonl: the fp32 entry scaled by that ratio)
+    if (c.kind == 4) return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile16 * (h.ih_bf16 == 1 ? 0.81 : 1.0);
     return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile * (1.0 + h.cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const PlannerCtx& h, int row0, int nrows) {
@@ -94,6 +124,9 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
             if (h.occ_coopn[rpg - 1] >= occ) shapes.push_back({2, 0, rpg, (slots / S3) * rpg, occ - 1});
         // half-tile ping-pong (lstm_hp.hip): H / 16 workgroups per row tile
         if (occ == 1 && h.hp_ok && h.coop_hp && slots / (h.H / 16) > 0) shapes.push_back({8, 16, 0, slots / (h.H / 16), 0});
+        // wave-owned column split (lstm_coopw.hip): H / (32 NT) workgroups per row tile, one per CU
+        for (int nt = 1; nt <= 2 && occ == 1 && h.coopw_ok && h.coop_w; ++nt)
+            if (h.H % (32 * nt) == 0 && slots / (h.H / (32 * nt)) > 0) shapes.push_back({9, 32 * nt, 0, slots / (h.H / (32 * nt)), 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
         SbChunk c{sh.kind, 0, n * 32, n, 0, 32, sh.units, sh.kind == 2 ? cdiv(n, sh.rpg) : 0, sh.rpg, 0, 0};
@@ -134,7 +167,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     SbPlan p;
     auto push = [&](SbChunk c) {
         c.slot0 = p.total_slots; p.total_slots += c.num_tiles * c.rps;
-        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 8) p.coop_tiles += c.num_tiles;
+        c.coop_tile0 = p.coop_tiles; if (c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9) p.coop_tiles += c.num_tiles;
         p.chunks.push_back(c);
     };
     if (h.sb_tcn) { push(SbChunk{0, 0, num_rows, cdiv(num_rows, 32), 0, 32, 0, 0, 0, 0, 0}); return p; }   // no recurrent kernel

@@ -5,16 +5,15 @@
 
 namespace fsnp {
 
-// per-step cost table of the sub-band planner (see default_costs / calibrate_costs)
+// per-step cost table of the sub-band planner (see default_costs / calibrate_costs); flat layout: costs_to_array (fsnp.h: FSNP_NUM_COSTS)
 struct CostTable {
     double ksplit[4][2];       // K-split kernel at 8 / 16 / 32 / 64 units per workgroup x {<= 1, 2} workgroups per CU, launch FULL
     double ksplit1[4];         // the same with ONE row tile (the exchange traffic, hence a step, grows with the tiles in flight)
     double coopn[2][2];        // three-way split, 1 / 2 row tiles per group x {<= 1, 2} workgroups per CU
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
     double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
-    double pp[4];                 // (values 20..23 of the 26-value table: the round-3 ping-pong K split lstm_pp.hip, removed in round 4; the
-                                  //  slots stay so that the table layout of fsnp_get_costs / fsnp_debug_set_costs does not move)
     double hp[2];                 // half-tile ping-pong (lstm_hp.hip, 16 units): ONE row tile, a FULL launch (num_cus / (H / 16) tiles)
+    double coopw[2][2];           // wave-owned column split (lstm_coopw.hip) at 32 / 64 units per workgroup: ONE row tile, a FULL launch
     int calibrated;
 };
 
@@ -29,7 +28,8 @@ struct CostTable {
 // column-split, of the exchange images and barrier counters (coop_tile0).
 struct SbChunk {
     int kind;                  // 0 = row tile, 1 = coop (K split), 2 = coopn, 4 = half tile (lstm16.hip: 16-row tiles, rps = 16),
-                               // (6 = the removed ping-pong K split), 7 = runtime-sized (lstm_generic.hip), 8 = half-tile ping-pong (lstm_hp.hip)
+                               // 7 = runtime-sized (lstm_generic.hip), 8 = half-tile ping-pong (lstm_hp.hip), 9 = wave-owned column split
+                               // (lstm_coopw.hip: units = 32 or 64 per workgroup)
     int row0, nrows;           // sequences [row0, row0 + nrows)
     int num_tiles, ex, rps;    // tiles, VALU rows per tile, slots per tile (32 + ex)
     int units, groups, rpg;    // column-split parameters
@@ -43,15 +43,19 @@ struct SbPlan {
 // what the planner needs to know of a handle (fsnp_abi.hip: pctx)
 struct PlannerCtx {
     int H = 0, NIN = 0, num_cus = 256, num_cus_real = 256;
-    bool gru = false, sb_tcn = false, generic_sb = false, rowtile_ok = true, lstm16_ok = false, hp_ok = false;
+    bool gru = false, sb_tcn = false, generic_sb = false, rowtile_ok = true, lstm16_ok = false, hp_ok = false, coopw_ok = false;
     int ih_bf16 = 0, lstm_coop = 1, coop_occ = 1;
     int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};
-    int coop_hp = 0, pipeline = 0;
+    int coop_hp = 0, coop_w = 0, pipeline = 0;
     double composite_gain = 0.97;
     CostTable cost{};
 };
 
 CostTable default_costs();
+// the flat table of fsnp_get_costs / fsnp_debug_set_costs (include/fsnp.h: FSNP_NUM_COSTS values)
+constexpr int kNumCosts = 25;
+void costs_to_array(const CostTable& t, double* out);
+void costs_from_array(CostTable& t, const double* in);
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
 CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn);
 int chunk_workgroups(const PlannerCtx& h, const SbChunk& c);

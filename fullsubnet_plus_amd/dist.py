@@ -52,17 +52,27 @@ def forward_sharded(model, noisy_mag, noisy_real=None, noisy_imag=None, gather=T
     if not gather or not dist.is_initialized():
         return out                              # (a process group of ONE rank still runs the collective: the RCCL path is
                                                 #  the same call at every world size, tests/test_gpu_multirank.py exercises it)
-    if parity:
-        # every rank holds a zero-initialised global tensor with only its rows written: a sum is the gather
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-        return out
     sizes = [shard_bounds(B, r, world) for r in range(world)]
     rows = max(h - l for l, h in sizes)
-    if out.shape[0] < rows:                     # ragged split: pad to the largest shard, trim after the gather
-        pad = torch.zeros((rows - out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-        out = torch.cat([out, pad], dim=0)
-    full = torch.empty((world * rows,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-    dist.all_gather_into_tensor(full, out.contiguous(), group=group)
+    if parity:
+        # every rank holds the global [B, OC, F // G, T] tensor with only its own rows written (rows of the reference's drop_band
+        # order, parity_output_row).  Gather the row BLOCKS and scatter them by index: world x fewer bytes on the wire than summing
+        # the zero-filled global tensors, and exact (no 0 + x arithmetic).
+        mine = [parity_output_row(sm, B, groups) for sm in range(lo, hi)]
+        block = out[mine] if mine else out[:0]
+    else:
+        block = out
+    if block.shape[0] < rows:                   # ragged / empty shards: pad to the largest, trim after the gather
+        pad = torch.zeros((rows - block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        block = torch.cat([block, pad], dim=0)
+    full = torch.empty((world * rows,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(full, block.contiguous(), group=group)
+    if parity:
+        res = torch.empty_like(out)
+        for r, (l, h) in enumerate(sizes):
+            if h > l:
+                res[[parity_output_row(sm, B, groups) for sm in range(l, h)]] = full[r * rows: r * rows + (h - l)]
+        return res
     if all(h - l == rows for l, h in sizes):
         return full
     return torch.cat([full[r * rows: r * rows + (h - l)] for r, (l, h) in enumerate(sizes)], dim=0)

@@ -135,17 +135,17 @@ class _HipState:
 
 
 def _reference_style_init(m):
-    """Behaviour of BaseModel.weight_init (base_model.py:332-397) for the module kinds on this path."""
+    """Behaviour of BaseModel.weight_init (base_model.py:332-397) for the module kinds on this path (through `.data`, as there)."""
     if isinstance(m, nn.Conv1d):
-        nn.init.normal_(m.weight)
+        nn.init.normal_(m.weight.data)
         if m.bias is not None:
-            nn.init.normal_(m.bias)
+            nn.init.normal_(m.bias.data)
     elif isinstance(m, nn.Linear):
-        nn.init.xavier_normal_(m.weight)
-        nn.init.normal_(m.bias)
+        nn.init.xavier_normal_(m.weight.data)
+        nn.init.normal_(m.bias.data)
     elif isinstance(m, (nn.LSTM, nn.GRU)):
         for p in m.parameters():
-            (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p)
+            (nn.init.orthogonal_ if p.dim() >= 2 else nn.init.normal_)(p.data)
 
 
 def _resolve_device(device):
@@ -174,6 +174,8 @@ class _HipModel(nn.Module):
         #   "deferred" nothing is waited for (throughput loops, bench.py): call check_errors() / poll_errors() before
         #              trusting results; the next call on the handle also fails loudly.
         self.error_check = "sync"
+        # fsnp_watch_weights: every Nth forward starts with one fingerprint kernel over the parameters' storage (1 = every forward)
+        self.weight_watch_every = 1
         self._pipeline = False
         self._hip = _HipState()
 
@@ -184,13 +186,53 @@ class _HipModel(nn.Module):
         # submodule registration anywhere in the process since the list was cached (_TREE_GENERATION: assigning a new
         # nn.Parameter to a submodule attribute, load_state_dict(assign=True), replacing a submodule, parametrize).  Deleting
         # a parameter fires no hook: every 256th call re-walks the tree regardless.
+        # What NEITHER pointer nor version sees is an edit through `.data` (p.data.add_(), init.normal_(m.weight.data) - the idiom of
+        # the reference's own BaseModel.weight_init, base_model.py:339-355 - EMA / weight averaging): `.data` is a fresh tensor
+        # with its own version counter on the same storage.  Three nets catch it: (1) on a GPU the handle WATCHES the parameters'
+        # storage (fsnp_watch_weights: one fingerprint kernel in front of every forward; forward() re-packs and re-runs under
+        # error_check="sync", poll_errors() / check_errors() / the next call say so under "deferred"); (2) the periodic walk folds
+        # a content fingerprint into the key (this also covers parameters that cannot be watched: on another device, not fp32);
+        # (3) refresh_weights() - what weight_init() calls - forces the re-pack at once.
         cached = self.__dict__.get("_fsnp_plist")
         calls = self.__dict__.get("_fsnp_plist_calls", 0) + 1
         self.__dict__["_fsnp_plist_calls"] = calls
         if cached is None or cached[0] != _TREE_GENERATION[0] or calls % 256 == 0:
-            cached = (_TREE_GENERATION[0], list(self.parameters()))
+            plist = list(self.parameters())
+            # (while the handle watches the parameters' storage on the device the fingerprint slot stays None: any change of the
+            #  parameter set shows in the pointer tuple, re-packs, and registers the watch again)
+            cached = (_TREE_GENERATION[0], plist, None if self.__dict__.get("_fsnp_watched", False) else self._content_fingerprint(plist))
             self.__dict__["_fsnp_plist"] = cached
-        return tuple([(p.data_ptr(), p._version) for p in cached[1]])
+        return (tuple([(p.data_ptr(), p._version) for p in cached[1]]), cached[2])
+
+    @staticmethod
+    def _content_fingerprint(plist):
+        """(sum, sum of squares) over all parameter values in fp64: moves with any realistic in-place edit."""
+        if not plist:
+            return None
+        with torch.no_grad():
+            by_dev = {}
+            for p in plist:
+                by_dev.setdefault(p.device, []).append(p.detach().reshape(-1).double())
+            s1 = s2 = 0.0
+            for ts in by_dev.values():
+                flat = torch.cat(ts)
+                s1 += float(flat.sum())
+                s2 += float((flat * flat).sum())
+        return (s1, s2)
+
+    def refresh_weights(self):
+        """Force the next forward to re-pack the device weights from the module's parameters.  Call it after editing parameters
+        through `.data` (which changes neither a storage pointer nor a version counter): `p.data.add_()`, `init.*_(m.weight.data)`,
+        EMA / weight averaging.  On a GPU the handle's weight watch notices such edits by itself (see _weights_key); this is the
+        explicit, immediate form - and what weight_init() uses."""
+        self._hip.packed_key = None
+
+    def weight_init(self, m):
+        """BaseModel.weight_init of the reference (audio_zen/model/base_model.py:332-397), usage `model.apply(model.weight_init)`:
+        Conv1d normal / normal, Linear xavier-normal / normal, LSTM / GRU orthogonal matrices and normal biases - through `.data`
+        like the reference's, followed by refresh_weights()."""
+        _reference_style_init(m)
+        self.refresh_weights()
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_fsnp_plist", None)
@@ -207,6 +249,8 @@ class _HipModel(nn.Module):
                 cfg = self._config()
                 _lib.check(lib.fsnp_create(ctypes.byref(cfg), ctypes.byref(hp)), "fsnp_create")
             st.handle, st.device, st.packed_key = hp, device, None
+            if self.__dict__.get("_verify_every"):
+                _lib.check(lib.fsnp_set_verify(hp, int(self.__dict__["_verify_every"])), "fsnp_set_verify")
         key = self._weights_key()
         if key != st.packed_key:
             for name, tensor in self.state_dict().items():
@@ -215,8 +259,27 @@ class _HipModel(nn.Module):
                            f"fsnp_set_weight({name})")
             with torch.cuda.device(device):
                 _lib.check(lib.fsnp_commit_weights(st.handle), "fsnp_commit_weights")
-            st.packed_key = key
+            self._watch_parameters(lib, device)
+            st.packed_key = self._weights_key()
         return lib
+
+    def _watch_parameters(self, lib, device):
+        """fsnp_watch_weights over the parameters' own storage - possible when every parameter is contiguous fp32 on the handle's
+        device (what `.to(device)` leaves); otherwise the periodic content fingerprint of _weights_key is the net."""
+        plist = self.__dict__["_fsnp_plist"][1]
+        ok = bool(plist) and all(p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in plist)
+        n = len(plist) if ok else 0
+        ptrs = (ctypes.c_void_p * max(n, 1))(*([p.data_ptr() for p in plist] if ok else [None]))
+        nums = (ctypes.c_int64 * max(n, 1))(*([p.numel() for p in plist] if ok else [0]))
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            _lib.check(lib.fsnp_watch_weights(self._hip.handle, ptrs, nums, n, max(1, int(self.weight_watch_every)), ctypes.c_void_p(stream)),
+                       "fsnp_watch_weights")
+        was = self.__dict__.get("_fsnp_watched", False)
+        self.__dict__["_fsnp_watched"] = ok
+        if ok != was:                       # the key's fingerprint slot follows (None while the device watches)
+            self.__dict__.pop("_fsnp_plist", None)
+            self._weights_key()
 
     @property
     def _handle(self):
@@ -263,10 +326,14 @@ class _HipModel(nn.Module):
         mode = _lib.MODE_PARITY if parity else _lib.MODE_FULL
         if complex_in:
             cst = (ctypes.c_int64 * 3)(*noisy_mag.stride())
-            with torch.cuda.device(device):
-                rc = lib.fsnp_forward_complex(self._handle, torch.view_as_real(noisy_mag).data_ptr(), ctypes.byref(cst),
-                                              out.data_ptr(), batch_size, num_frames, mode, int(batch_offset), gb,
-                                              ctypes.c_void_p(stream))
+            for attempt in (0, 1):
+                with torch.cuda.device(device):
+                    rc = lib.fsnp_forward_complex(self._handle, torch.view_as_real(noisy_mag).data_ptr(), ctypes.byref(cst),
+                                                  out.data_ptr(), batch_size, num_frames, mode, int(batch_offset), gb,
+                                                  ctypes.c_void_p(stream))
+                if rc != _lib.ERR_STALE_WEIGHTS or attempt:
+                    break
+                self._stale_weights_noticed(device)
             _lib.check(rc, "fsnp_forward_complex")
             return out
         strides = (ctypes.c_int64 * 3 * 3)()
@@ -274,12 +341,24 @@ class _HipModel(nn.Module):
             sb, _, sf, st = t.stride()
             strides[i][0], strides[i][1], strides[i][2] = sb, sf, st
         ptrs = [t.data_ptr() for t in ins] + [None] * (3 - len(ins))
-        with torch.cuda.device(device):
-            rc = lib.fsnp_forward(self._handle, ptrs[0], ptrs[1], ptrs[2],
-                                  ctypes.byref(strides), out.data_ptr(), batch_size, num_frames,
-                                  mode, int(batch_offset), gb, ctypes.c_void_p(stream))
+        for attempt in (0, 1):
+            with torch.cuda.device(device):
+                rc = lib.fsnp_forward(self._handle, ptrs[0], ptrs[1], ptrs[2],
+                                      ctypes.byref(strides), out.data_ptr(), batch_size, num_frames,
+                                      mode, int(batch_offset), gb, ctypes.c_void_p(stream))
+            if rc != _lib.ERR_STALE_WEIGHTS or attempt:
+                break
+            self._stale_weights_noticed(device)       # the watch flagged an EARLIER forward: re-pack, say so, run this one
         _lib.check(rc, "fsnp_forward")
         return out
+
+    def _stale_weights_noticed(self, device):
+        import warnings
+        warnings.warn("fullsubnet_plus_amd: parameters were modified in place through .data after they were packed; forwards since "
+                      "that edit ran on the OLD weights (error_check='deferred' does not wait for the watch).  Re-packing now; call "
+                      "model.refresh_weights() after such edits", RuntimeWarning)
+        self._hip.packed_key = None
+        self._ensure_handle(device)
 
     def _checked(self, run, device):
         """Runs `run()` (one forward) under the handle's error policy (see error_check in _init_hip)."""
@@ -290,7 +369,18 @@ class _HipModel(nn.Module):
             self.flush()
         torch.cuda.current_stream(device).synchronize()
         lib = _lib.load()
-        if lib.fsnp_poll_errors(self._handle) == 0:
+        rc = lib.fsnp_poll_errors(self._handle)
+        if rc == 0:
+            return out
+        if rc == _lib.ERR_STALE_WEIGHTS:
+            # the weight watch: a parameter was edited through .data since the pack - this forward ran on the old weights.
+            # Re-pack and run it again; the caller never sees the stale result (same contract as a timed-out launch).
+            self._hip.packed_key = None
+            out = run()
+            if self._pipeline:
+                self.flush()
+            torch.cuda.current_stream(device).synchronize()
+            _lib.check(lib.fsnp_poll_errors(self._handle), "fsnp_forward (after re-packing the weights)")
             return out
         msg = _lib.last_error()
         import warnings
@@ -306,6 +396,34 @@ class _HipModel(nn.Module):
         finally:
             lib.fsnp_debug_set_lstm_coop(self._handle, prev)      # the mode the caller had set (debug_set_lstm_coop), not always 1
         return out
+
+    def set_verify(self, every, device="cuda"):
+        """Exchange verification (fsnp_set_verify): every `every`-th forward whose plan holds a column-split launch runs those
+        sequences again on the one-tile-per-CU kernel (no inter-workgroup exchange) and compares on the device; a mismatch flags
+        the handle (code 7: error_check="sync" then re-runs the batch on the one-tile-per-CU kernel with a RuntimeWarning,
+        "deferred" reports through poll_errors() / check_errors() / the next call).  0 = off.  Also `model.verify_every = N`
+        before the first forward, or FSNP_VERIFY_EVERY=N in the environment."""
+        self.__dict__["_verify_every"] = int(every)
+        lib = self._ensure_handle(_resolve_device(device))
+        _lib.check(lib.fsnp_set_verify(self._handle, int(every)), "fsnp_set_verify")
+
+    @property
+    def verify_every(self):
+        return self.__dict__.get("_verify_every", 0)
+
+    @verify_every.setter
+    def verify_every(self, every):
+        self.__dict__["_verify_every"] = int(every)
+        if self._hip.handle is not None:
+            _lib.check(_lib.load().fsnp_set_verify(self._handle, int(every)), "fsnp_set_verify")
+
+    def verify_count(self):
+        """-> verification passes run so far (fsnp_verify_count)."""
+        return int(_lib.load().fsnp_verify_count(self._handle))
+
+    def debug_corrupt_exchange(self, step):
+        """Test hook (fsnp_debug_corrupt_exchange): the next forward's column-split launches publish one wrong h0 value at `step` - 1."""
+        _lib.check(_lib.load().fsnp_debug_corrupt_exchange(self._handle, int(step)), "fsnp_debug_corrupt_exchange")
 
     def poll_errors(self):
         """Raise if a finished launch flagged the handle; no synchronisation (fsnp_poll_errors)."""
@@ -460,8 +578,8 @@ class _HipModel(nn.Module):
 
     def debug_set_lstm_coop(self, mode, device="cuda"):
         """Tuning hook: 1 = use the column-split LSTM kernels for small batches (default), 0 = never, 2 = as 1 with the
-        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one, 4 = as 1 + the half-tile ping-pong
-        kernel even where FSNP_COOP_HP=0 (3 = 1: it selected the ping-pong K split removed in round 4)."""
+        K-split kernel's serial (round-1) step schedule instead of the layer-skewed one and without the half-tile ping-pong
+        kernel, 4 = as 1 + the half-tile ping-pong kernel even where FSNP_COOP_HP=0."""
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_lstm_coop(self._handle, int(mode)), "fsnp_debug_set_lstm_coop")
         self.__dict__["_lstm_coop_mode"] = int(mode)
@@ -510,10 +628,10 @@ class _HipModel(nn.Module):
         return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "lstm_first_chunk_ms": ms[3], "count": int(cnt[0])}
 
     def describe_plan(self, batch, parity=False):
-        """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups"}, ...]: how the sub-band sequences of a
-        `batch`-utterance forward are cut into kernel launches, and the arithmetic each launch runs in under the current
-        set_precision mode (fsnp_describe_plan_ex)."""
-        buf = (ctypes.c_int32 * 96)()
+        """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups", "deferred_when_pipelined"}, ...]: how the
+        sub-band sequences of a `batch`-utterance forward are cut into kernel launches, the arithmetic each launch runs in under the
+        current set_precision mode, and whether the pipelined serving loop sends it to the side stream (fsnp_describe_plan_ex)."""
+        buf = (ctypes.c_int32 * 112)()
         n = _lib.load().fsnp_describe_plan_ex(self._handle, int(batch), int(parity), buf, 16)
         if n < 0:
             raise RuntimeError(_lib.last_error())
@@ -522,20 +640,22 @@ class _HipModel(nn.Module):
                  2: "lstm2_coopn_kernel (three-way column split)", 3: "sub-band TCN",
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
-                 12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)"}
+                 12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)",
+                 13: "lstm2_coopw_kernel (a wave owns 8 / 16 units over the whole K, layer-skewed, no workgroup barrier)"}
         prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}
-        return [{"kernel": names[buf[6 * i]], "sequences": buf[6 * i + 1], "tiles": buf[6 * i + 2], "valu_rows": buf[6 * i + 3],
-                 "precision": prec[buf[6 * i + 4]], "workgroups": buf[6 * i + 5]} for i in range(n)]
+        return [{"kernel": names[buf[7 * i]], "sequences": buf[7 * i + 1], "tiles": buf[7 * i + 2], "valu_rows": buf[7 * i + 3],
+                 "precision": prec[buf[7 * i + 4]], "workgroups": buf[7 * i + 5], "deferred_when_pipelined": bool(buf[7 * i + 6])} for i in range(n)]
 
     def debug_set_costs(self, costs=None, workgroups_per_cu=1, device="cuda"):
-        """Test hook: pin the planner's cost table (26 values, fsnp_get_costs order; None = built-in) and whether it may put
-        two column-split workgroups on a CU (fsnp_debug_set_costs).  A shorter table (20 values = the round-2 layout, 24 = before
-        the half-tile ping-pong kernel) prices the launch shapes it does not name (values 20..23: ping-pong K split, 24..25:
-        half-tile ping-pong) out of every plan."""
+        """Test hook: pin the planner's cost table (_lib.NUM_COSTS values, fsnp_get_costs order; None = built-in) and whether it
+        may put two column-split workgroups on a CU (fsnp_debug_set_costs).  A shorter table prices the launch shapes it does
+        not name out of every plan (19 values = no half-tile ping-pong kernel and no wave-owned column split, 21 = no wave-owned
+        column split)."""
         lib = self._ensure_handle(_resolve_device(device))
-        if costs is not None and len(costs) < 26:
-            costs = list(costs) + [1e9] * (26 - len(costs))
-        arr = (ctypes.c_double * 26)(*costs) if costs is not None else None
+        n = _lib.NUM_COSTS
+        if costs is not None and len(costs) < n:
+            costs = list(costs) + [1e9] * (n - len(costs))
+        arr = (ctypes.c_double * n)(*costs) if costs is not None else None
         _lib.check(lib.fsnp_debug_set_costs(self._handle, arr, int(workgroups_per_cu)), "fsnp_debug_set_costs")
 
     @staticmethod
@@ -543,11 +663,12 @@ class _HipModel(nn.Module):
         return {"ksplit_us": {u: {"one_per_cu": v[2 * i], "two_per_cu": v[2 * i + 1], "one_tile": v[14 + i]} for i, u in enumerate((8, 16, 32, 64))},
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
                 "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18],
-                "pingpong_us": {r: v[19 + r] for r in (1, 2, 3, 4)}, "halftile_pingpong_us": {"one_tile": v[24], "full_launch": v[25]}}
+                "halftile_pingpong_us": {"one_tile": v[19], "full_launch": v[20]},
+                "coopw_us": {u: {"one_tile": v[23 + i], "full_launch": v[21 + i]} for i, u in enumerate((32, 64))}}
 
     def measure_costs(self):
         """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""
-        buf = (ctypes.c_double * 26)()
+        buf = (ctypes.c_double * _lib.NUM_COSTS)()
         with torch.cuda.device(self._hip.device):
             _lib.check(_lib.load().fsnp_measure_costs(self._handle, ctypes.byref(buf)), "fsnp_measure_costs")
         return self._cost_dict(list(buf))
@@ -561,14 +682,14 @@ class _HipModel(nn.Module):
         return buf.value.decode()
 
     def planner_costs_raw(self):
-        """-> the 26 values of fsnp_get_costs (the layout debug_set_costs takes)."""
-        buf = (ctypes.c_double * 26)()
+        """-> the _lib.NUM_COSTS values of fsnp_get_costs (the layout debug_set_costs takes)."""
+        buf = (ctypes.c_double * _lib.NUM_COSTS)()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), None, None), "fsnp_get_costs")
         return list(buf)
 
     def planner_costs(self):
         """-> the per-step cost table (us) the sub-band planner minimises (fsnp_get_costs)."""
-        buf, cal, occ = (ctypes.c_double * 26)(), ctypes.c_int32(), ctypes.c_int32()
+        buf, cal, occ = (ctypes.c_double * _lib.NUM_COSTS)(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().fsnp_get_costs(self._handle, ctypes.byref(buf), ctypes.byref(cal), ctypes.byref(occ)), "fsnp_get_costs")
         return {**self._cost_dict(list(buf)), "calibrated": bool(cal.value), "workgroups_per_cu": occ.value}
 
@@ -652,7 +773,7 @@ class FullSubNet_Plus(_HipModel):
         self.sb_model_hidden_size = sb_model_hidden_size
         self._init_hip()
         if weight_init:
-            self.apply(_reference_style_init)
+            self.apply(self.weight_init)          # fullsubnet_plus.py:119-120
 
     # ------------------------------------------------------------------ handle / weights
     def _config(self):
@@ -745,7 +866,7 @@ class FullSubNet(_HipModel):
         self.sb_model_hidden_size = sb_model_hidden_size
         self._init_hip()
         if weight_init:
-            self.apply(_reference_style_init)
+            self.apply(self.weight_init)          # fullsubnet.py:65-66
 
     def _config(self):
         cfg = _lib.FsnpConfig()

@@ -12,7 +12,9 @@
  * fullsubnet_plus_amd.model.FullSubNet_Plus binds these with ctypes (see
  * INTEGRATION.md); nothing here takes a torch type.
  *
- * All functions return 0 on success, non-zero on error (message: fsnp_last_error()).
+ * All functions return 0 on success, non-zero on error (message: fsnp_last_error()).  Codes: 1 bad argument / HIP call failed, 2 bad
+ * value or state, 3 no usable device, 4 device-side set-up failed, 5 an inter-workgroup wait of an earlier forward timed out, 6 the
+ * watched source tensors no longer match the packed weights (fsnp_watch_weights), 7 exchange verification failed (fsnp_set_verify).
  * No function aborts.  A handle is not thread-safe; distinct handles are independent.
  * All device work is enqueued on the caller's HIP stream; no device synchronisation
  * happens inside fsnp_forward.
@@ -68,8 +70,8 @@ enum {
 
 /* B > 1 semantics */
 enum {
-    FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,2,F,T]          */
-    FSNP_MODE_PARITY = 1 /* reproduces drop_band (feature.py:254-285): out [B,2,F/2,T],      */
+    FSNP_MODE_FULL = 0,  /* every utterance keeps all num_freqs bins: out [B,OC,F,T]         */
+    FSNP_MODE_PARITY = 1 /* reproduces drop_band (feature.py:254-285): out [B,OC,F/2,T],     */
                          /* rows re-ordered even samples first - the reference's literal B>1 */
 };
 
@@ -134,7 +136,8 @@ int fsnp_reserve(fsnp_handle* h, int32_t max_batch, int32_t max_frames, int32_t 
  *   mag/real/imag : DEVICE pointers to the [B,1,F,T] fp32 inputs; strides[i] = element
  *                   strides (batch, freq, time) of input i - torch.stft views are
  *                   non-contiguous and are consumed in place (no .contiguous()).
- *   out           : DEVICE pointer, contiguous fp32 [B,2,F,T] (FULL) or [B,2,F/2,T] (PARITY).
+ *   out           : DEVICE pointer, contiguous fp32 [B,OC,F,T] (FULL) or [B,OC,F/2,T] (PARITY), OC = fsnp_config.output_size
+ *                   (2 in every configuration file: the cIRM).
  *   batch_offset/global_batch : this call's utterances are samples
  *                   [batch_offset, batch_offset+batch) of a global batch (multi-GPU
  *                   sharding of PARITY mode needs the global sample parity and the global
@@ -172,7 +175,8 @@ int fsnp_enhance_wave(fsnp_handle* h, const float* wav, int64_t wav_stride, floa
 /* the step right after the model in the reference inferencer
  * (`decompress_cIRM` speech_enhance/audio_zen/acoustics/mask.py:60-63 + complex multiply
  * speech_enhance/fullsubnet_plus/inferencer/inferencer.py:152-157) as one kernel.
- *   mask  : DEVICE fp32 [B,2,F,T] contiguous (what fsnp_forward wrote, FULL mode)
+ *   mask  : DEVICE fp32 [B,2,F,T] contiguous (what fsnp_forward wrote, FULL mode, for a handle with output_size = 2: the cIRM
+ *           has exactly two planes; fsnp_enhance_wave refuses handles with another output_size)
  *   noisy : DEVICE interleaved complex64, element (b,f,t) at noisy + 2*(b*strides[0]+f*strides[1]+t*strides[2])
  *           (strides in complex elements - torch.stft's [B][T][F] layout is consumed in place)
  *   out   : DEVICE interleaved complex64, same logical shape, strides out_strides (complex elements). */
@@ -206,13 +210,16 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
 int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
 /* How a forward of `batch` utterances runs its sub-band sequences: up to max_chunks records of 4 ints
  * {kernel (0 = lstm2_fc row-tile, 1 = lstm2_coop K-split, 2 = lstm2_coopn three-way split, 3 = sub-band TCN, 4 = lstm2_fc16
- *  half-tile: 16-row tiles, csrc/lstm16.hip, (5 was the role-split K split lstm2_coop_split_kernel, 7..10 the round-3 ping-pong
- *  K split csrc/lstm_pp.hip: both removed in round 4;) 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per workgroup,
- *  gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row tiles;
- *  FSNP_COOP_HP=0 = never),
+ *  half-tile: 16-row tiles, csrc/lstm16.hip, 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per
+ *  workgroup, gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row
+ *  tiles, FSNP_COOP_HP=0 = never; 13 = lstm2_coopw: a wave owns 8 / 16 hidden units over the whole K, 12 / 6 workgroups per row
+ *  tile, no workgroup barrier in the time loop, csrc/lstm_coopw.hip - planned from 11 row tiles up, FSNP_COOP_W=0 = never),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
-/* The same with 6 ints per record: {kernel, sequences, tiles, VALU rows, precision, workgroups}; precision = the arithmetic of
+/* The same with 7 ints per record: {kernel, sequences, tiles, VALU rows, precision, workgroups, deferred}; deferred = 1: in the
+ * pipelined serving loop (fsnp_set_pipeline) this launch runs on the side stream, beside the next forward's full-band stages - the
+ * planner's decision: only launches that leave at least 32 CUs free are deferred (a remainder that fills the chip would only slow
+ * the stages it shares it with: B = 40, B = 21); precision = the arithmetic of
  * THAT launch under the handle's fsnp_set_precision mode: 0 = fp32, 1 = fp32 with the layer-1 ih-GEMM in bf16 (BASELINE
  * configs[4]), 2 = fp32 emulated by split bf16.  The bf16 variants exist for the one-tile-per-CU LSTM kernel only: the
  * sequences a plan hands to any other kernel (small batches, the remainder of a chip-filling batch) run in fp32. */
@@ -221,24 +228,24 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
  * out[0..7] = K-split kernel at 8 / 16 / 32 / 64 hidden units per workgroup x {at most one, two workgroups per CU} when the
  * launch is full, out[14..17] = the same four with ONE row tile (costs in between are interpolated in the tile count),
  * out[8..11] = three-way split with 1 / 2 row tiles per group x {one, two}, out[12] = one round of the one-tile-per-CU
- * kernel, out[13] = its relative surcharge per VALU row.  The built-in table holds round-2 measurements from 128-step runs
- * (profiles/r02_column_split.md), so plans - and performance - are reproducible from run to run and box to box.
- * fsnp_measure_costs MEASURES the same 18 numbers on the device (every launch shape on zeros at two step counts, slope;
+ * kernel, out[13] = its relative surcharge per VALU row, out[18] = one round of the half-tile kernel, out[19..20] = half-tile ping-pong
+ * kernel (csrc/lstm_hp.hip): one row tile, a full launch; out[21..22] = wave-owned column split (csrc/lstm_coopw.hip) at 32 / 64
+ * units per workgroup, a full launch, out[23..24] = the same with ONE row tile.  The built-in table holds measurements
+ * (profiles/r03_planner_costs.json, profiles/r05_planner_costs.json), so plans - and performance - are reproducible from run to run
+ * and box to box.  fsnp_measure_costs MEASURES the same numbers on the device (every launch shape on zeros at two step counts, slope;
  * ~0.3 s, synchronises; cached per process) without touching the plan: tests/test_gpu_parity.py asserts that the built-in
  * table has not drifted from the kernels.  FSNP_CALIBRATE=1 makes a handle ADOPT the measured table at its first planning
  * call (*calibrated = 1 from then on) - short calibration launches run at other clocks than a forward, so measured tables
  * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
  * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
  * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
-int fsnp_get_costs(const fsnp_handle* h, double out[26], int32_t* calibrated, int32_t* occ);   /* out[18] = one round of the half-tile kernel,
-                                                                                                out[20..23] = ping-pong K split, 1..4 row tiles per group,
-                                                                                                out[24..25] = half-tile ping-pong kernel (csrc/lstm_hp.hip):
-                                                                                                one row tile, a full launch */
-int fsnp_measure_costs(fsnp_handle* h, double out[26]);
+#define FSNP_NUM_COSTS 25
+int fsnp_get_costs(const fsnp_handle* h, double out[FSNP_NUM_COSTS], int32_t* calibrated, int32_t* occ);
+int fsnp_measure_costs(fsnp_handle* h, double out[FSNP_NUM_COSTS]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with
  * `num_cus` CUs.  Records of 8 ints {kernel, first sequence, sequences, tiles, VALU rows per tile, units per workgroup
- * (kernel 1) or groups (kernel 2, 6), row tiles per group, first slot}; kernel 6 = the ping-pong K split, 8 = the half-tile
- * ping-pong kernel.  Used by the CPU tests. */
+ * (kernels 1, 9) or groups (kernel 2), row tiles per group, first slot}; kernel 8 = the half-tile ping-pong kernel, 9 = the
+ * wave-owned column split.  Used by the CPU tests. */
 int fsnp_debug_plan_rows(int32_t num_rows, int32_t num_cus, int32_t hidden, int32_t gru, int32_t coop, double composite_gain,
                          int32_t* out, int32_t max_chunks);
 
@@ -305,6 +312,29 @@ int fsnp_poll_errors(fsnp_handle* h);
  * anything consumes `out`; a serving loop calls it once per batch it hands on, a benchmark once before its final
  * synchronisation.  Results are bit-identical to the non-pipelined call.  Switching the mode synchronises the device. */
 int fsnp_set_pipeline(fsnp_handle* h, int32_t enable);
+
+/* Round 5 - the two ways a forward could be silently wrong, made detectable.
+ *
+ * fsnp_watch_weights: the packed device weights are a COPY of the caller's parameters (fsnp_set_weight); a caller that edits its source
+ * tensors in place afterwards (PyTorch: `p.data.add_()`, `init.normal_(m.weight.data)` as the reference's own BaseModel.weight_init does,
+ * audio_zen/model/base_model.py:339-355, EMA / weight averaging) changes no pointer and no version counter.  Register the n SOURCE
+ * tensors (device pointers of fp32 data, numels[i] elements each; they must stay valid until the next fsnp_watch_weights / fsnp_destroy)
+ * right after fsnp_commit_weights: every `every`-th forward then starts with ONE fingerprint kernel over them (~35 MB for the default
+ * model: ~10 us) and flags the handle when they no longer match the pack - fsnp_poll_errors / fsnp_check_errors / the next call return 6
+ * with an explanatory message (the forwards since the edit ran on the old weights: re-pack and register again).  n = 0 unregisters.
+ *
+ * fsnp_set_verify: the column-split recurrent kernels (small batches, remainder tiles) exchange h between workgroups through global
+ * memory; their hand-off can only detect a TIME-OUT (code 5).  With every = N > 0, every Nth forward whose plan holds such a launch runs
+ * the same sequences AGAIN on the one-tile-per-CU kernel (no exchange at all) into a scratch mask and compares on the device
+ * (|a - b| <= 1e-4 + 1e-3 |b|); a mismatch flags the handle with code 7 and the first differing (utterance, bin, frame).  Cost: one
+ * one-tile-per-CU pass (~208 us per step and round of 256 row tiles) per N forwards - at N = 64 and 2 s clips +0.42 ms per forward.
+ * fsnp_verify_count = verification passes run so far.  0 = off (default; FSNP_VERIFY_EVERY=N at fsnp_create time sets it). */
+int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_t* numels, int32_t n, int32_t every, void* hip_stream);
+int fsnp_set_verify(fsnp_handle* h, int32_t every);
+int64_t fsnp_verify_count(const fsnp_handle* h);
+/* Test hook: the next forward's column-split launches publish ONE wrong h0 value (row 0, unit 0 of their row tile 0, step `step` - 1;
+ * the publisher's own state stays right) - what a stale or corrupted exchange image looks like to its consumers.  0 = off. */
+int fsnp_debug_corrupt_exchange(fsnp_handle* h, int32_t step);
 int fsnp_flush(fsnp_handle* h, void* hip_stream);
 
 /* Tuning hook: 1 (default) = the sub-band sequences are planned over all three kernels - the column-split kernels
@@ -314,10 +344,8 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * with other work).  Ignored by GRU models, which have no one-tile-per-CU kernel. */
 int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but the K-split kernel runs its serial (round-1) step
                                                                   schedule instead of the layer-skewed one (also FSNP_COOP_SKEW=0);
-                                                                  3 = 1 (selected the ping-pong K split csrc/lstm_pp.hip until
-                                                                  round 4 removed it);
                                                                   4 = as 1 + the planner may use the half-tile ping-pong kernel
-                                                                  (csrc/lstm_hp.hip, also FSNP_COOP_HP=1 at fsnp_create time) */
+                                                                  even where FSNP_COOP_HP=0 was set at fsnp_create time */
 /* Tuning hook: 1 (default) = the conv1x1 / sconv GEMMs of the full-band TCN stacks run on tcn_gemm_dma_kernel (operands by
  * LDS DMA, GroupNorm folded into the sconv weights at fsnp_create; csrc/tcn.hip) where its layout requirements hold;
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
@@ -361,11 +389,17 @@ int fsnp_debug_lstm_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t
 int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, int32_t units, const float* wih0,
                               const float* whh0, const float* wih1, const float* whh1, float* out, int64_t out_floats);
 
+/* Same for the wave-owned column split (csrc/lstm_coopw.hip): ONE array for every split width, [k-group (layer 0: x | h0, then layer
+ * 1: h1 | h0)][8-unit block, columns gate-interleaved: column c = gate c & 3 of unit c >> 2][lane][4]; (kx/8 + 3*hidden/8) * (hidden/8) *
+ * 256 floats. */
+int fsnp_debug_lstm_coopw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
+                               const float* whh1, float* out, int64_t out_floats);
+
 const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a
  * binding compares both with its own idea before the first real call (fullsubnet_plus_amd/_lib.py does). */
-#define FSNP_ABI_VERSION 8
+#define FSNP_ABI_VERSION 9
 int32_t fsnp_abi_version(void);
 int32_t fsnp_config_size(void);
 

@@ -103,12 +103,12 @@ def test_forward_sharded_fullsubnet_world2_gloo():
     assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, batch=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     sd = make_state_dict(3)
-    mag, real, imag = make_spec(5, 12, 42)
+    mag, real, imag = make_spec(batch, 12, 42)
     model = _OracleShardModel(sd, mode)
     out = fdist.forward_sharded(model, mag, real, imag, gather=True)
     if rank == 0:
@@ -139,3 +139,27 @@ def test_forward_sharded_world2_gloo(mode):
         want = fsnp_torch.forward(sd, mag, real, imag).numpy()              # the reference's literal B>1 call
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("world,batch,mode", [(4, 3, "full"), (4, 3, "parity"), (8, 5, "full"), (8, 5, "parity")])
+def test_forward_sharded_ragged_and_empty_shards_gloo(world, batch, mode):
+    """More ranks than utterances (the 8-GPU node with a small batch): shards of one utterance and EMPTY shards, both batch
+    modes - the parity-mode gather moves row blocks + an index scatter (no all_reduce of zero-filled global tensors)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q, batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sd = make_state_dict(3)
+    mag, real, imag = make_spec(batch, 12, 42)
+    want = (fsnp_torch.forward_full if mode == "full" else fsnp_torch.forward)(sd, mag, real, imag).numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+    assert [fdist.shard_bounds(batch, r, world) for r in range(world)].count((batch, batch)) + sum(1 for r in range(world) if fdist.shard_bounds(batch, r, world)[0] == fdist.shard_bounds(batch, r, world)[1]) >= world - batch

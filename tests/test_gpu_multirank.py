@@ -36,6 +36,22 @@ def test_bench_plain_gpus2_self_launches_two_ranks():
     assert r["gather_ms"] > 0
 
 
+def test_bench_eight_ranks_on_one_device():
+    """eight processes loading the library, creating handles, packing weights and running at once had never happened.
+    `bench.py --gpus 8 --same-device`: eight ranks share GPU 0 (gloo for the collectives: RCCL wants a GPU per rank; the exchange-free
+    kernel, because eight processes' co-resident launches could hold parts of one chip against each other) - what remains is exactly
+    the N = 8 plumbing: self-launch, rendezvous, per-rank inputs, barrier-bracketed timing, max over ranks, the mask gather, and the
+    roofline block of the slowest rank."""
+    res = _run([sys.executable, "bench.py", "--gpus", "8", "--same-device", "--dist-backend", "gloo", "--steps", "2",
+                "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-alt"], timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["dist"]["world_size_seen"] == 8 and r["config"]["global_batch"] == 16
+    assert r["dist"]["gathered_shape"][0] == 16 and 0 <= r["dist"]["roofline_of_rank"] < 8
+    assert r["dist"]["per_rank_ms_per_step"]["max"] >= r["dist"]["per_rank_ms_per_step"]["min"] > 0
+    assert r["roofline"]["avg_launch_ms"] > 0 and r["roofline"]["subband_plan"][0]["kernel"].startswith("lstm2_fc_kernel")
+
+
 def test_bench_refuses_more_gpus_than_visible():
     n = torch.cuda.device_count()
     res = _run([sys.executable, "bench.py", "--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])

@@ -139,7 +139,7 @@ def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
     m.check_errors()
     m.debug_set_lstm_coop(1)
     m.debug_set_costs(None, 1)
-    m.debug_set_costs(m.planner_costs_raw()[:24], 1)      # (built-in table minus the half-tile ping-pong kernel, which sums K in another order)
+    m.debug_set_costs(m.planner_costs_raw()[:19], 1)      # (built-in table minus the half-tile ping-pong kernel and the wave-owned split, which sum K in another order)
     assert all(c["kernel"].startswith("lstm2_coop_kernel") for c in m.describe_plan(1))
     skew = m.lstm2_fc(x).cpu().numpy()       # (the skewed schedule is used from 16 units per workgroup up: n >= 257 here)
     m.check_errors()
@@ -151,12 +151,18 @@ def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
 
 
 # K split at 8 units cheap (a full launch and one tile), everything else priced out
-_SERIAL_8_UNITS_COSTS = [5.0, 900.0] + [900.0] * 6 + [900.0] * 4 + [900.0, 0.11] + [5.0, 900.0, 900.0, 900.0] + [900.0, 0.0] + [1e9] * 4
+_SERIAL_8_UNITS_COSTS = [5.0, 900.0] + [900.0] * 6 + [900.0] * 4 + [900.0, 0.11] + [5.0, 900.0, 900.0, 900.0] + [900.0]      # (19 values: the other launch shapes are priced out)
 
 
 def _hp_only_costs():
-    """A cost table (fsnp_get_costs layout, 26 values) under which every column-split launch is the half-tile ping-pong kernel."""
-    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0]
+    """A cost table (fsnp_get_costs layout) under which every column-split launch is the half-tile ping-pong kernel."""
+    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [5.0, 5.0]
+
+
+def _coopw_only_costs(units):
+    """A cost table under which every column-split launch is the wave-owned split at `units` (32 / 64) units per workgroup."""
+    w = [5.0 if 32 * (i + 1) == units else 900.0 for i in range(2)]
+    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + w + w
 
 
 @pytest.mark.parametrize("n,steps,hidden,fbn", [(1, 1, 384, 0), (16, 2, 384, 0), (17, 3, 384, 0), (32, 40, 384, 0), (33, 5, 384, 0), (257, 41, 384, 0),
@@ -182,6 +188,34 @@ def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden, fbn):
     m.check_errors()
     want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
     assert rel_err(got, want) < 2e-5, rel_err(got, want)
+    for _ in range(3):
+        assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), got)
+    m.check_errors()
+
+
+@pytest.mark.parametrize("units,n,steps,fbn", [(32, 1, 1, 0), (32, 33, 2, 0), (32, 514, 41, 0), (32, 672, 3, 0), (32, 700, 9, 0),
+                                               (64, 40, 1, 0), (64, 17, 2, 0), (64, 1285, 33, 0), (64, 1344, 7, 0), (64, 1400, 5, 0),
+                                               (64, 2056, 128, 0), (32, 514, 9, 2), (64, 300, 5, 3), (64, 96, 300, 0)])
+def test_wave_owned_column_split_kernel_vs_oracle(units, n, steps, fbn):
+    """csrc/lstm_coopw.hip: a wave owns 8 / 16 hidden units (1 / 2 gate-interleaved accumulator tiles) over the whole K, 12 / 6
+    workgroups share a row tile, layer-skewed schedule with the waves as participants, no workgroup barrier in the time loop, x in
+    registers, h out as one 16-byte store per tile.  1 ... 300 steps, ragged tiles, one tile, a full launch (672 / 1344 sequences),
+    a full launch + a second one (700 / 1400), B = 8's 2056 sequences at 128 steps (two launches), sub-band inputs of 46 / 52
+    features (the K = 64 instantiations).  Same oracle tolerance as every other recurrent kernel, bitwise repeatable."""
+    args = {**DEFAULT_MODEL_ARGS, "fb_num_neighbors": fbn}
+    sd = make_state_dict(3, "harsh", fb_num_neighbors=fbn)
+    m = _model(args, sd)
+    rng = np.random.Generator(np.random.PCG64(4177 + n + steps))
+    x = torch.from_numpy(rng.standard_normal((n, 31 + 3 * (2 * fbn + 1), steps)).astype(np.float32)).cuda()
+    m.lstm2_fc(x[:1])
+    m.debug_set_costs(_coopw_only_costs(units), 1)
+    assert all(c["kernel"].startswith("lstm2_coopw_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
+    got = m.lstm2_fc(x).cpu().numpy()
+    m.check_errors()
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
+    per_step = np.abs(got - want).max(axis=(0, 1)) / np.abs(want).max()
+    _record(f"lstm_coopw_{units}_{n}x{steps}_fbn{fbn}", rel=float(per_step.max()), first_steps=per_step[:4].tolist())
+    assert per_step.max() < 2e-5, (per_step.max(), per_step[:6])
     for _ in range(3):
         assert np.array_equal(m.lstm2_fc(x).cpu().numpy(), got)
     m.check_errors()
@@ -250,7 +284,7 @@ def test_half_tile_kernel(n, steps):
     want = fsnp_torch.lstm2_fc(x, sd).numpy()
     m.lstm2_fc(x[:1].cuda())
     if n < 3000:                                   # make the half-tile kernel the cheapest shape for any size
-        m.debug_set_costs([900] * 8 + [900] * 4 + [900, 0.11] + [900] * 4 + [10, 0], 1)
+        m.debug_set_costs([900] * 8 + [900] * 4 + [900, 0.11] + [900] * 4 + [10], 1)
     plan = m.describe_plan(1)                      # (the plan of lstm2_fc depends on n, not on this)
     got = m.lstm2_fc(x.cuda()).cpu().numpy()
     err = rel_err(got, want)
@@ -270,7 +304,7 @@ def test_parity_b32_runs_on_half_tiles(b32):
     assert plan[0]["kernel"].startswith("lstm2_fc16_kernel") and plan[0]["sequences"] == 4096 and len(plan) == 1, plan
 
 
-CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000, 0]   # a table in which two workgroups per CU pay
+CHEAP_TWO_PER_CU = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000]   # a table in which two workgroups per CU pay
 
 
 @pytest.mark.parametrize("n,steps", [(257, 40), (514, 20), (1285, 12), (2700, 9), (4112, 7), (5440, 6), (8000, 5), (10870, 4)])
@@ -352,9 +386,11 @@ def test_measured_cost_table_can_be_adopted(tmp_path):
     assert abs(res["0"]["sum"] - res["1"]["sum"]) <= 1e-4 * abs(res["0"]["sum"])
 
 
-def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle():
-    """B = 8 (65 row tiles -> lstm_coopn.hip, one row tile per group) through the whole forward, cumulative norm
-    (per-row (m, d) tables) included."""
+@pytest.mark.parametrize("plan", ["default", "round4"])
+def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle(plan):
+    """B = 8 (65 row tiles) through the whole forward, cumulative norm (per-row (m, d) tables) included: the default plan (round 5:
+    42 row tiles on the wave-owned split at 64 units + 21 at 32 + 2 on the K split) and the round-4 plan (lstm_coopn.hip, one row
+    tile per group - what GRU models and the other hidden sizes still run)."""
     for norm in ("offline_laplace_norm", "cumulative_layer_norm"):
         args = {**DEFAULT_MODEL_ARGS, "norm_type": norm}
         sd = make_state_dict(21, "harsh")
@@ -362,12 +398,17 @@ def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle():
         cpu_in = make_spec(8, 22, 77)
         ins = _cuda(cpu_in)
         m.debug_set_lstm_coop(1)
+        if plan == "round4":
+            m.debug_set_costs(m.planner_costs_raw()[:21], 1)
+            assert [c["kernel"][:18] for c in m.describe_plan(8)] == ["lstm2_coopn_kernel"]
+        else:
+            assert [c["kernel"][:18] for c in m.describe_plan(8)][:2] == ["lstm2_coopw_kernel"] * 2
         a = m(*ins).cpu().numpy()
         m.check_errors()
         m.debug_set_lstm_coop(0)
         b = m(*ins).cpu().numpy()
         want = fsnp_torch.forward_full(sd, *[t[2:4] for t in cpu_in], norm_type=norm).numpy()
-        _record(f"forward_b8_coopn_{norm}", coop_vs_tile=rel_err(a, b), coop_vs_oracle=rel_err(a[2:4], want))
+        _record(f"forward_b8_{plan}_{norm}", coop_vs_tile=rel_err(a, b), coop_vs_oracle=rel_err(a[2:4], want))
         assert rel_err(a, b) < 1e-5 and rel_err(a[2:4], want) < TOL
 
 
@@ -908,6 +949,44 @@ def test_weight_update_repacks_device_weights():
         m.sb_model.fc_output_layer.bias += 0.5           # in-place edit bumps the parameter version
     c = m(*ins).cpu().numpy()
     assert abs(float((c - b).mean()) - 0.5) < 1e-4
+    # an edit through .data bumps NOTHING (no pointer, no version): the handle's weight watch (fsnp_watch_weights: one fingerprint
+    # kernel over the parameters' storage in front of every forward) notices it; under error_check="sync" the forward re-packs
+    # and re-runs, so the caller never sees a result for the old weights
+    key = m._weights_key()
+    m.sb_model.fc_output_layer.bias.data.add_(0.25)
+    assert m._weights_key() == key
+    d = m(*ins).cpu().numpy()
+    assert abs(float((d - c).mean()) - 0.25) < 1e-4
+    assert np.array_equal(m(*ins).cpu().numpy(), d)                       # (the new pack is watched again: no re-pack, same result)
+    m.fb_model.sequence_model[0].conv1x1.weight.data.copy_(torch.from_numpy(make_state_dict(5, "harsh")["fb_model.sequence_model.0.conv1x1.weight"].numpy()))
+    e = m(*ins).cpu().numpy()
+    sd3 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert rel_err(e, fsnp_torch.forward(sd3, *g.inputs(), **g.fwd_kwargs()).numpy()) < TOL and rel_err(e, d) > 1e-4
+    # the reference's own entry point (base_model.py:332-397, `model.apply(model.weight_init)`) edits through .data too
+    torch.manual_seed(3)
+    m.apply(m.weight_init)
+    f = m(*ins).cpu().numpy()
+    sd4 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert rel_err(f, fsnp_torch.forward(sd4, *g.inputs(), **g.fwd_kwargs()).numpy()) < TOL
+    # deferred mode does not wait for the watch: the stale forward is reported by poll_errors / check_errors ...
+    m.error_check = "deferred"
+    m(*ins)
+    m.check_errors()
+    m.sb_model.fc_output_layer.bias.data.add_(0.5)
+    stale = m(*ins)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        m.check_errors()
+    assert np.array_equal(stale.cpu().numpy(), f)                         # (that result WAS computed with the old weights)
+    # ... or, if nobody asked, by the next forward, which re-packs with a warning and runs on the new weights
+    m.sb_model.fc_output_layer.bias.data.add_(0.5)
+    m(*ins)
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="through .data"):
+        h = m(*ins)
+    m.check_errors()
+    assert abs(float((h.cpu().numpy() - f).mean()) - 1.0) < 1e-4
+    m.refresh_weights()                                                    # the explicit form
+    m.check_errors()
 
 
 def _sleep_cycles_for(seconds):
@@ -1128,6 +1207,45 @@ def test_sync_error_policy_reruns_on_the_row_tile_kernel():
     with pytest.raises(RuntimeError, match="timed out"):
         m.poll_errors()
     m.poll_errors()
+
+
+@pytest.mark.parametrize("batch,kernel", [(1, "lstm2_coop_hp_kernel"), (2, "lstm2_coopw_kernel"), (8, "lstm2_coopw_kernel")])
+def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel):
+    """the column-split kernels' hand-off can only detect a TIME-OUT; a stale or corrupted exchange image would give a
+    silently wrong mask.  fsnp_set_verify (model.verify_every = N): every Nth forward whose plan holds a column-split launch runs
+    those sequences again on the one-tile-per-CU kernel (no exchange) and compares on the device.  fsnp_debug_corrupt_exchange makes
+    ONE published h0 value wrong (row 0, unit 0 of a launch's first row tile at one step; the publisher's own state stays right) -
+    exactly what a stale exchange looks like to the consumers: the detector must fire, name the place, and the sync policy must
+    hand back the right mask.  Without the corruption nothing fires and the verified forward equals the plain one bit for bit."""
+    sd = make_state_dict(0, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    ins = _cuda(make_inputs(batch, 0.6, 40 + batch))
+    plain = m(*ins).cpu().numpy()
+    assert any(c["kernel"].startswith(kernel) for c in m.describe_plan(batch)), m.describe_plan(batch)
+    m.verify_every = 1
+    assert np.array_equal(m(*ins).cpu().numpy(), plain) and m.verify_count() == 1
+    m.verify_every = 3                                                   # every third forward
+    for _ in range(3):
+        assert np.array_equal(m(*ins).cpu().numpy(), plain)
+    assert m.verify_count() == 2
+    m.verify_every = 1
+    m.error_check = "deferred"
+    m.debug_corrupt_exchange(5)
+    bad = m(*ins)
+    with pytest.raises(RuntimeError, match="exchange verification failed.*utterance 0, bin 0, frame") as ei:
+        m.check_errors()
+    assert rel_err(bad.cpu().numpy(), plain) > 1e-4                      # (the corruption really moved the mask)
+    frame = int(str(ei.value).split("frame ")[1].split(";")[0])
+    assert frame <= 4                                                    # h0 of step 4 is wrong: visible from frame 4 - look_ahead on
+    assert np.array_equal(m(*ins).cpu().numpy(), plain)                  # one forward only
+    m.check_errors()
+    m.error_check = "sync"
+    m.debug_corrupt_exchange(9)
+    with pytest.warns(RuntimeWarning, match="exchange verification failed"):
+        fixed = m(*ins).cpu().numpy()
+    assert rel_err(fixed, plain) < 1e-5                                  # re-run on the one-tile-per-CU kernel
+    m.verify_every = 0
+    assert np.array_equal(m(*ins).cpu().numpy(), plain)
 
 
 def test_two_handles_overlapped_on_two_streams():

@@ -101,10 +101,56 @@ def test_weights_key_sees_every_way_of_replacing_a_parameter():
     m.double()
     changed()
     del m.sb_model.fc_output_layer.bias                   # no registration hook fires for a deletion ...
-    n_before = len(m._weights_key())
+    n_before = len(m._weights_key()[0])
     for _ in range(256):
         k = m._weights_key()                              # ... the periodic full walk catches it
-    assert len(k) == n_before - 1
+    assert len(k[0]) == n_before - 1
+
+
+def test_edits_through_dot_data_are_not_silently_ignored():
+    """`p.data.add_()` / `p.data.copy_()` - the idiom of the reference's own BaseModel.weight_init (base_model.py:339-355:
+    `init.normal_(m.weight.data)`), of EMA / weight averaging - change neither a storage pointer nor a version counter, so the
+    (pointer, version) key alone would keep the handle on the previous weights for ever.  Nets (model.py: _weights_key): the key carries
+    a content fingerprint refreshed by the periodic walk (here, on CPU parameters; on a GPU the handle watches the storage itself:
+    tests/test_gpu_parity.py::test_weight_update_repacks_device_weights), refresh_weights() forces the re-pack at once, and
+    `model.apply(model.weight_init)` - the method the reference exposes - goes through it."""
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    m._hip.packed_key = k0 = m._weights_key()
+
+    def noticed_within_a_walk():
+        for _ in range(256):
+            if m._weights_key() != m._hip.packed_key:
+                return True
+        return False
+
+    assert not noticed_within_a_walk()                          # nothing changed: 256 calls, one walk, same key
+    m.sb_model.fc_output_layer.bias.data.add_(1.0)
+    assert m._weights_key()[0] == k0[0]                         # pointer and version did not move: the hole
+    assert noticed_within_a_walk()                              # ... the fingerprint of the next walk does
+    m._hip.packed_key = m._weights_key()
+    m.fb_model.sequence_model[3].sconv.weight.data.copy_(torch.randn_like(m.fb_model.sequence_model[3].sconv.weight))
+    assert noticed_within_a_walk()
+    m._hip.packed_key = m._weights_key()
+    m.refresh_weights()                                         # the explicit form: the next forward re-packs whatever the key says
+    assert m._hip.packed_key is None
+    # the reference's entry point: model.apply(model.weight_init) (fullsubnet_plus.py:119-120) re-initialises through .data
+    m._hip.packed_key = m._weights_key()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(11)
+    m.apply(m.weight_init)
+    assert m._hip.packed_key is None
+    after = m.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert any("sequence_model.weight_hh_l0" in k for k in moved) and any("conv1x1.weight" in k for k in moved) and any("fc1.bias" in k for k in moved)
+    w = after["sb_model.sequence_model.weight_hh_l1"]            # orthogonal_ on the [1536, 384] matrix: orthonormal columns
+    assert torch.allclose(w.T @ w, torch.eye(384), atol=1e-4)
+    untouched = [k for k in before if k not in moved]            # PReLU / GroupNorm parameters: not in weight_init's list
+    assert untouched and all(("prelu" in k or "norm" in k) for k in untouched), untouched[:5]
+    from fullsubnet_plus_amd import FullSubNet
+    f = FullSubNet(**FULLSUBNET_MODEL_ARGS)
+    f._hip.packed_key = f._weights_key()
+    f.apply(f.weight_init)
+    assert f._hip.packed_key is None
 
 
 def test_subband_num_follows_the_reference():
@@ -743,6 +789,94 @@ def test_column_split_kernels_keep_their_asm_invariants():
         assert r["sc1_loads"] > 0 and r["sc1_stores"] > 0, (name, r)
 
 
+def test_wave_owned_column_split_index_maps_and_asm():
+    """csrc/lstm_coopw.hip restated on the CPU.  (1) The packed stream: participant `part` of an NT-tile split multiplies 8-unit
+    blocks part * NT + n of every k-group; column c of a block = gate c & 3 of unit c >> 2; the B operand of MFMA p of k-group g in
+    lane l is k = 8 g' + 2 p + (l >> 5) - emulating the kernel's indexing on the packer's output reproduces W x for both layers, for
+    both split widths, K = 40 and 64.  (2) Lane / slot identities: lane (row, hi)'s features hi + 2 i are the components of ITS A
+    fragment of x k-group i >> 2, and its cells (units hi + 2 j of block ub) are the components of ITS float4 of k-group ub of the h
+    image (a_frag_index).  (3) The staging tile [32][32 NT + 4]: the write pattern of a 32x32x2 accumulator and the read-back of
+    (i, f, g, o) cover every element once, ds_write_b32 / ds_read_b128 conflict-free per lane group (MI355X_MICROARCH.md, LDS).
+    (4) The layer-skewed schedule with per-wave participants is the one test_exchange_schedules_are_race_free_under_any_interleaving
+    model-checks (three h0 images, two h1 images).  (5) Static asm: clean k-group loops, no scratch, no workgroup barrier in the time
+    loop, no cache maintenance, 16-byte sc1 stores."""
+    import ctypes as ct
+    import importlib.util
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(5))
+    H = 384
+    for NIN, KX in ((34, 40), (52, 64)):
+        wih0, whh0 = rng.standard_normal((4 * H, NIN)).astype(np.float32), rng.standard_normal((4 * H, H)).astype(np.float32)
+        wih1, whh1 = rng.standard_normal((4 * H, H)).astype(np.float32), rng.standard_normal((4 * H, H)).astype(np.float32)
+        KGX, KGH = KX // 8, H // 8
+        KG0, NUB = KGX + KGH, H // 8
+        out = np.zeros((KG0 + 2 * KGH) * NUB * 256, dtype=np.float32)
+        vp = lambda a: a.ctypes.data_as(ct.c_void_p)
+        assert lib.fsnp_debug_lstm_coopw_pack(H, NIN, KX, vp(wih0), vp(whh0), vp(wih1), vp(whh1), vp(out), out.size) == 0, lib.fsnp_last_error()
+        pack = out.reshape(KG0 + 2 * KGH, NUB, 64, 4)
+        x, h0, h1 = rng.standard_normal(NIN).astype(np.float32), rng.standard_normal(H).astype(np.float32), rng.standard_normal(H).astype(np.float32)
+        k0 = np.concatenate([x, np.zeros(KX - NIN, np.float32), h0]).astype(np.float64)       # layer 0: [x (padded) | h0]
+        k1 = np.concatenate([h1, h0]).astype(np.float64)                                      # layer 1: [h1 | h0]
+        want0 = wih0.astype(np.float64) @ x + whh0.astype(np.float64) @ h0
+        want1 = whh1.astype(np.float64) @ h1 + wih1.astype(np.float64) @ h0
+        lane = np.arange(64)
+        for NT in (1, 2):
+            for part in (0, 5, H // (8 * NT) - 1):
+                for n in range(NT):
+                    ub = part * NT + n
+                    for c in (0, 1, 2, 3, 17, 31):
+                        lanes = lane[(lane & 31) == c]                                        # the two k halves of column c
+                        a0 = sum(float(pack[g, ub, l, p]) * k0[8 * g + 2 * p + (l >> 5)] for g in range(KG0) for l in lanes for p in range(4))
+                        a1 = sum(float(pack[KG0 + g, ub, l, p]) * k1[8 * g + 2 * p + (l >> 5)] for g in range(2 * KGH) for l in lanes for p in range(4))
+                        gate, unit = c & 3, 8 * ub + (c >> 2)
+                        assert abs(a0 - want0[gate * H + unit]) < 1e-9 * (1 + abs(a0)) and abs(a1 - want1[gate * H + unit]) < 1e-9 * (1 + abs(a1))
+    a_frag = lambda row, k: (((k >> 3) * 64) + ((k & 1) * 32) + row) * 4 + ((k >> 1) & 3)      # lstm_common.h: a_frag_index
+    for l in range(64):
+        row, hi = l & 31, l >> 5
+        for i in range(32):                                                                   # x: feature hi + 2 i <-> component i & 3 of float4 (i >> 2) * 64 + l
+            assert a_frag(row, hi + 2 * i) == ((i >> 2) * 64 + l) * 4 + (i & 3)
+        for ub in (0, 7, 47):
+            for j in range(4):                                                                # h: unit 8 ub + hi + 2 j <-> component j of float4 ub * 64 + l
+                assert a_frag(row, 8 * ub + hi + 2 * j) == (ub * 64 + l) * 4 + j
+    groups128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups128 += [[g + 32 for g in grp] for grp in groups128]                                 # ds_read_b128 lane groups
+    for NT in (1, 2):
+        stride = 32 * NT + 4
+        seen = np.zeros((32, 32 * NT), dtype=int)
+        for n in range(NT):
+            for q in range(16):
+                addr = [((q & 3) + 8 * (q >> 2) + 4 * (l >> 5)) * stride + n * 32 + (l & 31) for l in range(64)]
+                for half in (addr[:32], addr[32:]):
+                    assert len({a % 32 for a in half}) == 32                                 # ds_write_b32: 32 lanes, 32 banks
+                for l in range(64):
+                    seen[(q & 3) + 8 * (q >> 2) + 4 * (l >> 5), n * 32 + (l & 31)] += 1
+        assert (seen == 1).all()
+        read = np.zeros((32, 32 * NT), dtype=int)
+        for n in range(NT):
+            for j in range(4):
+                addr = [(l & 31) * stride + n * 32 + 4 * ((l >> 5) + 2 * j) for l in range(64)]
+                for grp in groups128:
+                    banks = [(addr[l] + e) % 64 for l in grp for e in range(4)]
+                    assert len(set(banks)) == 64                                              # ds_read_b128: 16 lanes x 4 banks, all distinct
+                for l in range(64):
+                    assert addr[l] % 4 == 0
+                    read[l & 31, n * 32 + 4 * ((l >> 5) + 2 * j): n * 32 + 4 * ((l >> 5) + 2 * j) + 4] += 1
+        assert (read == 1).all()
+    spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.analyse_wave_owned()
+    assert len(res) == 4, sorted(res)                                                         # NT in {1, 2} x K in {40, 64}
+    for name, r in res.items():
+        nt = int(re.search(r"ILi384ELi\d+ELi(\d)E", name).group(1))
+        depth = 8 if nt == 1 else 4
+        assert r["scratch"] == 0 and r["cache_maint"] == 0 and r["barriers_after_first_mfma"] == 0, (name, r)
+        assert r["sc1_stores16"] >= 2 * nt and r["sc1_loads"] > 0 and len(r["loops"]) >= 3, (name, r)
+        for lp in r["loops"]:
+            assert lp["mfma"] == depth * nt * 4 and lp["loads"] == depth * (nt + 1), (name, lp)
+            assert lp["scratch"] == 0 and lp["drain"] == 0 and lp["acc_moves"] == 0, (name, lp)
+
+
 def test_round3_kernels_keep_their_asm_invariants():
     """Static checks of the round-3 kernels (tools/check_lstm_asm.py).  lstm2_coop_hp_kernel: exactly the
     16x16x4 MFMAs of two unrolled half-phases, layer-1 weights from AGPRs, operands by LDS DMA, 16-byte sc1 stores, DPP row sums, no
@@ -797,6 +931,8 @@ def test_subband_plans_cover_every_sequence_and_fit_the_chip(rows, gru):
             assert c["par"] in (8, 16, 32, 64) and c["tiles"] * (384 // c["par"]) <= 256
         elif c["kind"] == 2:
             assert c["rpg"] in (1, 2) and c["par"] * 3 <= 256 and c["par"] * c["rpg"] >= c["tiles"]
+        elif c["kind"] == 9:
+            assert not gru and c["par"] in (32, 64) and c["tiles"] * (384 // c["par"]) <= 256       # wave-owned column split (lstm_coopw.hip)
         else:
             assert not gru, "there is no row-tile GRU kernel"
     assert nxt == rows
@@ -811,21 +947,25 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(257) == [(8, 257)] and _plan(257)[0]["tiles"] == 9                 # B = 1: 9 row tiles on the half-tile ping-pong kernel (lstm_hp.hip)
     assert kinds(257, gru=1) == [(1, 257)] and _plan(257, gru=1)[0]["par"] == 16    # (GRU: K split, 16 units)
     assert kinds(160) == [(1, 160)] and _plan(160)[0]["par"] == 8 and kinds(192) == [(8, 192)]   # up to 5 row tiles: K split at 8 units; 6 ... 10: lstm_hp
-    assert kinds(1285) == [(1, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles
-    assert kinds(2056) == [(2, 2056)] and _plan(2056)[0]["rpg"] == 1                # B = 8: three-way split
+    assert kinds(514) == [(9, 514)] and _plan(514)[0]["par"] == 32 and _plan(514)[0]["tiles"] == 17     # B = 2: wave-owned split, 12 workgroups per tile
+    assert kinds(1285) == [(9, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles, 6 workgroups per tile
+    assert kinds(1285, gru=1) == [(1, 1285)] and _plan(1285, gru=1)[0]["par"] == 64   # (GRU: the K split, as in round 4)
+    p = _plan(2056)                                                                 # B = 8: 42 tiles at 64 units + 21 at 32 + 2 on the K split
+    assert [(c["kind"], c["par"], c["tiles"]) for c in p] == [(9, 64, 42), (9, 32, 21), (1, 8, 2)] and sum(c["rows"] for c in p) == 2056
+    assert kinds(2056, gru=1) == [(2, 2056)] and _plan(2056, gru=1)[0]["rpg"] == 1  # (GRU: three-way split)
     assert kinds(4096) == [(4, 4096)] and _plan(4096)[0]["tiles"] == 256            # parity-mode B = 32: one round of 256 half tiles
     assert kinds(4112) == [(4, 4096), (1, 16)]                                      # B = 16: a half-tile round + 16 sequences K split
     p = _plan(4096, gru=1)                                                          # GRU has no half-tile kernel: 128 tiles = one per
     assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # group + 42 + 1
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert kinds(3200) == [(4, 3200)] and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~95 row tiles up
-    assert kinds(2800)[0][0] == 2
+    assert kinds(3300) == [(4, 3300)] and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~103 row tiles up
+    assert seq(2800) == [9, 9, 1] and kinds(2800, gru=1)[0][0] == 2
     assert seq(4256) == [4, 1]                                                      # 133 tiles: half-tile round + 5 tiles K split
-    assert kinds(5397) == [(4, 4096), (1, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles K split
+    assert kinds(5397) == [(4, 4096), (9, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles wave-owned split
     assert kinds(5397, gru=1) == [(2, 5397)] and _plan(5397, gru=1)[0]["rpg"] == 2  # (108 + 48.5 us against 157 for two per group); GRU: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert _plan(8224)[1]["rpg"] == 0 and _plan(16448)[1]["rpg"] == 0 and _plan(16448)[1]["tiles"] == 2   # (the role-split schedule was removed in round 4)
-    assert kinds(10280) == [(0, 8192), (2, 2088)]                                   # B = 40
+    assert seq(10280) == [0, 9, 9, 1] and kinds(10280)[0] == (0, 8192)              # B = 40: a full round + 42 + 21 + 3 tiles
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
     assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
     assert kinds(8224, coop=0) == [(0, 8224)] and _plan(8224, coop=0)[0]["ex"] == 1  # column-split kernels off: VALU rows
@@ -836,11 +976,13 @@ def test_subband_plan_choices_match_the_design():
     assert sum(c["rows"] for c in g) == 65792 and all(c["kind"] == 1 for c in g[12:])   # the short rest K split
     g = _plan(8224, gru=1)                                                          # GRU, B = 32: 257 tiles = 170 + 85 + 2
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
-    assert kinds(3084) == [(4, 3084)]                                               # B = 12: 193 half tiles, one round
+    assert seq(3084) == [9, 9, 9] and kinds(3400) == [(4, 3400)]                    # B = 12: 97 tiles = 42 + 42 + 13 on the wave-owned split (half tiles from ~103 tiles)
     p = _plan(3084, gru=1)                                                          # (GRU: 97 tiles = one per group + the rest K split)
     assert p[0]["kind"] == 2 and p[0]["rpg"] == 1 and p[0]["tiles"] == 85 and all(c["kind"] == 1 for c in p[1:]) and sum(c["rows"] for c in p) == 3084
     assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2
-    p = _plan(1376)                                                                 # 43 tiles: a full K-split launch + a tiny one
+    p = _plan(1376)                                                                 # 43 tiles: a full wave-owned launch + one tile on the K split
+    assert [(c["kind"], c["par"], c["tiles"]) for c in p] == [(9, 64, 42), (1, 8, 1)] and sum(c["rows"] for c in p) == 1376
+    p = _plan(1376, gru=1)                                                          # (GRU: a full K-split launch + a tiny one)
     assert [c["kind"] for c in p] == [1, 1] and p[0]["par"] == 64 and p[1]["par"] == 8 and sum(c["rows"] for c in p) == 1376
 
 
@@ -854,13 +996,14 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
 
     def plan(rows, occ, costs=None, gru=0):
         buf = (ct.c_int32 * (8 * 64))()
-        arr = (ct.c_double * 26)(*(list(costs) + [1e9] * (26 - len(costs)))) if costs else None      # (opt-in launch shapes priced out unless given)
+        nc = _lib.NUM_COSTS
+        arr = (ct.c_double * nc)(*(list(costs) + [1e9] * (nc - len(costs)))) if costs else None      # (launch shapes the table does not name are priced out)
         n = lib.fsnp_debug_plan_rows2(rows, 256, 384, gru, 1, 0.97, occ, arr, buf, 64)
         assert n > 0, lib.fsnp_last_error()
         keys = ("kind", "row0", "rows", "tiles", "ex", "par", "rpg", "slot0")
         return [dict(zip(keys, buf[8 * i:8 * i + 8])) for i in range(n)]
 
-    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000, 0]
+    cheap2 = [9, 12, 19, 25, 29, 38, 55, 70, 76, 95, 151, 190, 208, 0.11, 9, 19, 29, 55, 1000]
     p = plan(257, 2, cheap2)
     assert len(p) == 1 and p[0]["kind"] == 1 and p[0]["par"] == 8 and 9 * 48 <= 512
     p = plan(4112, 2, cheap2)                    # 129 tiles
@@ -870,16 +1013,13 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     for rows in (257, 514, 1285, 2056, 4096, 4112, 5440, 8224, 10280, 65792):
         for gru in (0, 1):
             for c in plan(rows, 2, cheap2, gru):
-                wgs = c["tiles"] * (384 // c["par"]) if c["kind"] == 1 else c["par"] * 3 if c["kind"] == 2 else 0
+                wgs = c["tiles"] * (384 // c["par"]) if c["kind"] in (1, 9) else c["par"] * 3 if c["kind"] == 2 else 0
                 assert wgs <= 512 and (c["kind"] != 2 or c["par"] * c["rpg"] >= c["tiles"])
-    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100, 1000, 0]      # K split suddenly slow: 9 tiles move
+    slow_k = [100, 100, 100, 100, 100, 100, 100, 100, 76, 95, 151, 190, 208, 0.11, 100, 100, 100, 100, 1000]      # K split suddenly slow: 9 tiles move
     p = plan(257, 1, slow_k)
     assert p[0]["kind"] == 2
-    # (kernel 6, the round-3 ping-pong K split, was removed in round 4: however cheap its four table slots are made, it is never planned)
-    cheap_pp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 9, 11, 15, 19]
-    assert all(c["kind"] != 6 for rows in (32, 257, 640, 1285, 8224) for c in plan(rows, 1, cheap_pp))
     # the half-tile ping-pong kernel (kernel 8: 24 workgroups per row tile, at most 10 row tiles per launch)
-    cheap_hp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 0, 1e9, 1e9, 1e9, 1e9, 9, 11]
+    cheap_hp = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 9, 11]
     p = plan(257, 1, cheap_hp)
     assert len(p) == 1 and p[0]["kind"] == 8 and p[0]["tiles"] == 9 and p[0]["rows"] == 257
     p = plan(32, 1, cheap_hp)
@@ -889,6 +1029,15 @@ def test_planner_follows_the_cost_table_and_two_workgroups_per_cu():
     p = plan(8224, 1, cheap_hp)                  # B = 32: the leftover tile
     assert [(c["kind"], c["rows"]) for c in p] == [(0, 8192), (8, 32)]
     assert [c["kind"] for c in plan(257, 1)] == [8] and all(c["kind"] != 8 for rows in (32, 160, 640, 8224) for c in plan(rows, 1))   # built-in table: B = 1
+    # the wave-owned column split (kernel 9: 12 / 6 workgroups per row tile at 32 / 64 units, at most 21 / 42 row tiles per launch)
+    cheap_w = [100] * 8 + [760, 950, 1510, 1900, 208, 0.11, 100, 100, 100, 100, 1000, 1e9, 1e9, 11, 19, 10, 18]
+    p = plan(514, 1, cheap_w)
+    assert len(p) == 1 and p[0]["kind"] == 9 and p[0]["par"] == 32 and p[0]["tiles"] == 17
+    p = plan(1344, 1, cheap_w)                   # 42 tiles: one launch at 64 units (19) beats two at 32 (22)
+    assert [(c["kind"], c["par"], c["tiles"]) for c in p] == [(9, 64, 42)]
+    p = plan(2056, 1, cheap_w)                   # 65 tiles: never more than 21 / 42 tiles per launch
+    assert all(c["kind"] == 9 and c["tiles"] <= (21 if c["par"] == 32 else 42) for c in p) and sum(c["rows"] for c in p) == 2056
+    assert all(c["kind"] != 9 for rows in (514, 1285, 2056) for c in plan(rows, 1, cheap_w, gru=1))          # LSTM only
 
 
 def test_oracle_is_only_reachable_from_the_allowed_places():

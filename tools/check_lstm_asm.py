@@ -89,6 +89,36 @@ def analyse_half_tile_ping_pong(flags=("-fno-slp-vectorize",)):
     return res
 
 
+def analyse_wave_owned(flags=("-fno-slp-vectorize",)):
+    """lstm2_coopw_kernel (lstm_coopw.hip), per instantiation: the k-group loops (depth-2 loops with MFMAs: NT x 4 MFMAs and NT + 1
+    16-byte loads per k-group, D groups per iteration, counted waits only - no drain, no scratch, no accumulator moves), and
+    whole-kernel facts: no scratch anywhere, no cache maintenance, no workgroup barrier behind the first MFMA, 16-byte sc1 stores."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        src = os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", "lstm_coopw.hip")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN4fsnp18lstm2_coopw_kernelI\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        cnt = lambda seg, pat: sum(1 for x in seg if re.search(pat, x))
+        labels = {mm.group(1): i for i, l in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", l)] if mm}
+        loops = []
+        for i, l in enumerate(body):
+            mm = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+                seg = body[labels[mm.group(1)]:i]
+                if 0 < cnt(seg, r"v_mfma") <= 64 and len(seg) < 200:
+                    loops.append(dict(mfma=cnt(seg, r"v_mfma"), loads=cnt(seg, r"buffer_load_dwordx4"), scratch=cnt(seg, r"scratch_"),
+                                      drain=cnt(seg, r"vmcnt\(0\)"), acc_moves=cnt(seg, r"v_accvgpr"), lines=len(seg)))
+        first = next(i for i, l in enumerate(body) if "v_mfma" in l)
+        res[name] = dict(loops=loops, scratch=cnt(body, r"scratch_"), cache_maint=cnt(body, r"buffer_wbl2|buffer_inv"),
+                         barriers_after_first_mfma=cnt(body[first:], r"s_barrier"), sc1_stores16=cnt(body, r"buffer_store_dwordx4.*sc1"),
+                         sc1_loads=cnt(body, r"buffer_load_dwordx4.*sc1"), mfma=cnt(body, r"v_mfma_f32_32x32x2_f32"))
+    return res
+
+
 def analyse_splitk_gemm(flags=("-fno-slp-vectorize",)):
     """tcn_gemm_sk_kernel (tcn.hip), per instantiation: one k-tile body per wave (16 MFMAs, 6 fragment reads, 6 DMA pieces + the 6 of the
     first tile), no scratch, and NO workgroup barrier between the first and the last MFMA (a wave waits for its own DMA only)."""

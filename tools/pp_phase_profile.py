@@ -26,6 +26,21 @@ def main_hp(s, n, steps):
     print(json.dumps(res, indent=1))
 
 
+def main_coopw(s, n, steps, units):
+    """csrc/lstm_coopw.hip: stamps 0..6 in A_t (layer 0), 8..14 in C_{t-1} (layer 1), wave 0 of workgroup 0."""
+    a = ["A: h0 k-groups", "A: x k-groups", "A: x fetch, wait b1, prefill C", "A: staging + cells + h0 stores", "A: x normalise", "A: drain + arrive"]
+    c = ["C: h1 k-groups", "C: h0 k-groups", "C: wait b0, prefill A", "C: staging + cells + h1 stores", "C: Linear partial", "C: drain + arrive"]
+    res = {"kernel": "lstm2_coopw_kernel", "units_per_workgroup": units, "sequences": n, "steps": steps, "us_per_step": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01)}
+    da, dc = np.diff(s[:, 0:7], axis=1) * 0.01, np.diff(s[:, 8:15], axis=1) * 0.01
+    for i, nm in enumerate(a):
+        res[nm] = round(float(da[:, i].mean()), 3)
+    res["gap A -> C (epilogue of step t - 2 on participant 0)"] = round(float((s[:, 8] - s[:, 6]).mean() * 0.01), 3)
+    for i, nm in enumerate(c):
+        res[nm] = round(float(dc[:, i].mean()), 3)
+    res["gap C -> next A"] = round(float((s[1:, 0] - s[:-1, 14]).mean() * 0.01), 3)
+    print(json.dumps(res, indent=1))
+
+
 def main():
     n, steps, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
@@ -35,6 +50,11 @@ def main():
     out = torch.empty(n, 2, steps, device="cuda")
     m.lstm2_fc(x.permute(0, 2, 1)[:8])          # creates the handle
     lib = _lib.load()
+    if r in (32, 64):
+        stamps = np.zeros(steps * 16, dtype=np.uint64)
+        for _ in range(2):
+            _lib.check(lib.fsnp_debug_pp_profile(m._handle, x.data_ptr(), out.data_ptr(), n, steps, r, stamps.ctypes.data, stamps.size), "profile")
+        return main_coopw(stamps.reshape(steps, 16).astype(np.int64)[4:-1], n, steps, r)
     hp = r == 0
     rr = 2 if hp else r
     if hp and n <= 16:

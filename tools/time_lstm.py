@@ -23,18 +23,16 @@ x = torch.randn(n, 34, steps, device="cuda")
 out = m.lstm2_fc(x)
 if os.environ.get("PIN_R01"):
     m.debug_set_costs(None, 1)
-if os.environ.get("PP_R") is not None:          # PP_R=0: never the ping-pong K split; 1..4: only it, that many row tiles per group
-    r = int(os.environ["PP_R"])
-    if r == 0:
-        m.debug_set_costs(list(m.planner_costs_raw())[:20] + [1e9] * 4, 1)
-    else:
-        pp = [900.0] * 4
-        pp[r - 1] = 5.0
-        m.debug_set_lstm_coop(3)
-        m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + pp, 1)
+if os.environ.get("COOPW"):                     # only the wave-owned column split (csrc/lstm_coopw.hip) at COOPW = 32 / 64 units per workgroup
+    u = int(os.environ["COOPW"])
+    wv = [5.0 if 32 * (i + 1) == u else 900.0 for i in range(2)]
+    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + wv + wv, 1)
+    assert all(c["kernel"].startswith("lstm2_coopw_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
+if os.environ.get("NOCOOPW"):                   # the round-4 plans: no wave-owned column split
+    m.debug_set_costs(list(m.planner_costs_raw())[:21], 1)
 if os.environ.get("HP"):                        # only the half-tile ping-pong kernel (csrc/lstm_hp.hip)
     m.debug_set_lstm_coop(4)
-    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0, 0.0] + [900.0] * 4 + [5.0, 5.0], 1)
+    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [5.0, 5.0], 1)
     assert all(c["kernel"].startswith("lstm2_coop_hp_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
 torch.cuda.synchronize()
 best = 1e9
@@ -45,4 +43,4 @@ for _ in range(reps):
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
 m.check_errors()
-print(f"H={hidden} HP={os.environ.get('HP')} PP_R={os.environ.get('PP_R')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
+print(f"H={hidden} HP={os.environ.get('HP')} COOPW={os.environ.get('COOPW')} NOCOOPW={os.environ.get('NOCOOPW')} n={n} steps={steps} env XCD={os.environ.get('FSNP_COOP_XCD', '0')}: {best * 1e3:.3f} ms, {best * 1e6 / steps:.2f} us/step, checksum {float(out.double().sum()):.6f}")
