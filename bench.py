@@ -44,9 +44,8 @@ def parse():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--mode", default="full", choices=["full", "parity"])
     ap.add_argument("--norm", default="offline_laplace_norm")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_ih", "bf16x3"],
-                    help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM); bf16x3 = optional: fp32 "
-                         "products of the LSTM emulated by three bf16 MFMAs (NOT the headline either)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_ih"],
+                    help="bf16_ih = BASELINE.json configs[4] (NOT the headline: reduced-precision ih-GEMM)")
     ap.add_argument("--model", default="plus", choices=["plus", "fullsubnet"],
                     help="plus = FullSubNet+ (the headline); fullsubnet = the original FullSubNet Model (SURVEY.md 8f-2)")
     ap.add_argument("--sequence-model", default="LSTM", choices=["LSTM", "GRU", "TCN"],
@@ -291,7 +290,7 @@ def main():
         # the arithmetic type per launch of the sub-band plan (the bf16 variants exist for the one-tile-per-CU LSTM kernel only)
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else
                        "; ".join(f"{c['precision']} on {c['sequences']} sequences" for c in plan) +
-                       (" (BASELINE configs[4])" if args.precision == "bf16_ih" else " - optional mode"),
+                       " (BASELINE configs[4])",
         "data": "synthetic",
         "config": {"workload": f"batch={B} x {args.seconds:g} s clips per GPU (T={T} frames, 257 bins), "
                                f"{args.mode} mode, num_neighbors=15, {args.norm}, random-init weights (seed 0)" +

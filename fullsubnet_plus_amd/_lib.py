@@ -75,7 +75,6 @@ SYMBOLS = {
     "fsnp_config_size": (c_i32, []),
     "fsnp_debug_set_lstm_coop": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_gemm_dma": (c_i32, [c_vp, c_i32]),
-    "fsnp_debug_set_graph": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_inject_error": (c_i32, [c_vp]),
     "fsnp_debug_set_chaos": (c_i32, [c_vp, c_i32]),
     "fsnp_debug_set_lstm_waves": (c_i32, [c_vp, c_i32]),

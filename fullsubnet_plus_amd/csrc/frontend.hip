@@ -7,13 +7,15 @@
 // (paths relative to /root/reference/speech_enhance).
 //
 // Pipeline (all tiny, HBM/latency bound):
-//   repack : strided [B,1,F,T] view (torch.stft layout or any other) -> raw[branch][utt][t][FP], zero padded
-//   frame  : per-frame (sum, sumsq) over F in fp64
-//   scan   : per utterance -> (m_t, d_t) for every frame, normalised = (x - m_t) / d_t   [all 4 norm types]
-//   fsum   : per-frequency sum over t of the normalised input, fp64 atomics
-//   gate   : TSSE squeeze + MLP.  conv -> AdaptiveAvgPool is linear, so
-//            mean_t(conv_K(x))[f] = sum_j w[f,j] * (S_f - prefix_j - suffix_{K-1-j}) / (T'-K+1) + b[f]
-//   apply  : att = normalised * gate[f]
+//   repack : strided [B,1,F,T] view (torch.stft layout or any other) -> raw[branch][utt][t][FP], zero padded; on the way it
+//            accumulates, per branch and utterance, the column sums over t and the plane's (sum, sum of squares) in fp64
+//   offline norms (m, d constant per utterance; round 5: THREE launches instead of six):
+//     gate   : (m, d) from the plane's totals, written for every frame; S_f = (column sum - T' m) / d; TSSE squeeze + MLP.
+//              conv -> AdaptiveAvgPool is linear, so mean_t(conv_K(x))[f] = sum_j w[f,j] * (S_f - prefix_j - suffix_{K-1-j}) / (T'-K+1) + b[f]
+//     apply  : att = normalised * gate[f]
+//   cumulative norms (m_t, d_t per frame):
+//     frame  : per-frame (sum, sumsq) over F in fp64;  scan : prefix over frames -> (m_t, d_t);  fsum : per-frequency sum over t of
+//              the normalised input, fp64 atomics;  gate, apply as above
 #include "fsnp_common.h"
 
 namespace fsnp {
@@ -23,9 +25,38 @@ struct StridedIn {
     long sb[3], sf[3], st[3];
 };
 
-__global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __restrict__ raw, int B, int T, int Tp,
-                                                        int F, int FP) {
+// Statistics of one 32 x 32 tile (rows = frames, columns = bins; zeros outside the clip / the bins): column sums -> colsum[f],
+// the tile's (sum, sum of squares) -> tot[2], all fp64 atomics.  tile(r, c) = value of frame t0 + r, bin f0 + c.
+template <typename TileFn>
+__device__ __forceinline__ void repack_tile_stats(TileFn tile, double* __restrict__ colsum, double* __restrict__ tot, int f0, int F,
+                                                  double (*red)[33], double* wred) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const double v = tile(ty + 8 * i, tx); s += v; q += v * v; }
+    red[ty][tx] = s;
+    double ts = s, tq = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ts += __shfl_xor(ts, o); tq += __shfl_xor(tq, o); }
+    if ((threadIdx.x & 63) == 0) { wred[(threadIdx.x >> 6) * 2] = ts; wred[(threadIdx.x >> 6) * 2 + 1] = tq; }
+    __syncthreads();
+    if (ty == 0 && f0 + tx < F) {
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += red[k][tx];
+        atomicAdd(colsum + f0 + tx, c);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(tot, wred[0] + wred[2] + wred[4] + wred[6]);
+        atomicAdd(tot + 1, wred[1] + wred[3] + wred[5] + wred[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __restrict__ raw, double* __restrict__ colsum,
+                                                        double* __restrict__ tot, int B, int T, int Tp, int F, int FP) {
     __shared__ float tile[32][33];
+    __shared__ double red[8][33];
+    __shared__ double wred[8];
     const int branch = blockIdx.z / B, b = blockIdx.z % B;
     const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -50,6 +81,10 @@ __global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __r
         const int t = t0 + r, f = f0 + tx;
         if (t < Tp && f < FP) raw[(((long)branch * B + b) * Tp + t) * FP + f] = tile[r][tx];
     }
+    if (colsum != nullptr) {
+        const long ub = (long)branch * B + b;
+        repack_tile_stats([&](int r, int c) -> double { return (double)tile[r][c]; }, colsum + ub * FP, tot + ub * 2, f0, F, red, wred);
+    }
 }
 
 // the same repack straight from the interleaved complex64 STFT buffer (torch.stft's output; strides
@@ -57,9 +92,12 @@ __global__ __launch_bounds__(256) void fe_repack_kernel(StridedIn in, float* __r
 // torch op (audio_zen/acoustics/feature.py:24-31 `mag_phase`, inferencer.py:143-147).  nbr = 3: [mag, real, imag]
 // planes; nbr = 1: magnitude only (original FullSubNet).
 __global__ __launch_bounds__(256) void fe_repack_complex_kernel(const float2* __restrict__ x, long sb, long sf, long st,
-                                                                float* __restrict__ raw, int nbr, int B, int T, int Tp,
+                                                                float* __restrict__ raw, double* __restrict__ colsum,
+                                                                double* __restrict__ tot, int nbr, int B, int T, int Tp,
                                                                 int F, int FP) {
     __shared__ float2 tile[32][33];
+    __shared__ double red[8][33];
+    __shared__ double wred[8];
     const int b = blockIdx.z;
     const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -87,6 +125,16 @@ __global__ __launch_bounds__(256) void fe_repack_complex_kernel(const float2* __
             const long o = ((long)b * Tp + t) * FP + f;
             raw[o] = hypotf(v.x, v.y);
             if (nbr == 3) { raw[plane + o] = v.x; raw[2 * plane + o] = v.y; }
+        }
+    }
+    if (colsum != nullptr) {           // [mag | real | imag] planes: branch-major [branch][utt]
+        repack_tile_stats([&](int r, int c) -> double { const float2 v = tile[r][c]; return (double)hypotf(v.x, v.y); },
+                          colsum + (long)b * FP, tot + (long)b * 2, f0, F, red, wred);
+        if (nbr == 3) {
+            __syncthreads();
+            repack_tile_stats([&](int r, int c) -> double { return (double)tile[r][c].x; }, colsum + ((long)B + b) * FP, tot + ((long)B + b) * 2, f0, F, red, wred);
+            __syncthreads();
+            repack_tile_stats([&](int r, int c) -> double { return (double)tile[r][c].y; }, colsum + (2L * B + b) * FP, tot + (2L * B + b) * 2, f0, F, red, wred);
         }
     }
 }
@@ -181,8 +229,10 @@ __global__ __launch_bounds__(512) void fe_fsum_kernel(const float* __restrict__ 
 
 struct GateArgs {
     FrontendWeights w;
-    const float* raw; const NormMD* md; const double* fsum; float* gate;
+    const float* raw; NormMD* md; const double* fsum; const double* tot; float* gate;
     int B, Tp, F, FP;
+    int offline_norm;          // FSNP_NORM_OFFLINE_*: (m, d) come from `tot` here and are WRITTEN to md for every frame; fsum = raw column
+                               // sums.  -1: cumulative norms - md and fsum (of the normalised input) were produced by fe_scan / fe_fsum
 };
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -207,24 +257,33 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
 
     const int att = g.w.attention;
     float* sqmax = edge;               // [FP] CBAM: max over t (edge is unused then)
+    // offline norms: one (m, d) per branch and utterance, from the plane's totals the repack kernel accumulated; every later
+    // consumer (fe_apply_kernel) reads the per-frame table, written here
+    const bool offline = g.offline_norm >= 0;
+    NormMD mu{0.0f, 1.0f};
+    if (offline) {
+        mu = norm_md(g.offline_norm, g.tot[ub * 2], g.tot[ub * 2 + 1], (double)F * Tp);
+        for (int t = tid; t < Tp; t += 256) g.md[ub * Tp + t] = mu;
+    }
     if (att == FSNP_ATT_TSSE) {
         for (int i = tid; i < 2 * (kmax - 1) * F; i += 256) {
             const int side = i / ((kmax - 1) * F), r = (i / F) % (kmax - 1), f = i % F;
             const int t = side == 0 ? r : Tp - 1 - r;                    // r-th frame from the start / from the end
-            const NormMD m = g.md[ub * Tp + t];
+            const NormMD m = offline ? mu : g.md[ub * Tp + t];
             edge[(side * MAXK + r) * FP + f] = (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d;
         }
         __syncthreads();
     }
     for (int f = tid; f < F; f += 256) {
-        const double S = g.fsum[ub * FP + f];
+        // sum over t of the normalised input: sum_t (x - m) / d = (column sum - T' m) / d for the offline norms
+        const double S = offline ? (g.fsum[ub * FP + f] - (double)Tp * (double)mu.m) / (double)mu.d : g.fsum[ub * FP + f];
         if (att != FSNP_ATT_TSSE) {
             // SE / ECA / CBAM squeeze = mean over time (attention_model.py:31, :349, :320)
             sq[f] = (float)(S / (double)Tp);
             if (att == FSNP_ATT_CBAM) {                      // + max over time (attention_model.py:321)
                 float mx = -3.4e38f;
                 for (int t = 0; t < Tp; ++t) {
-                    const NormMD m = g.md[ub * Tp + t];
+                    const NormMD m = offline ? mu : g.md[ub * Tp + t];
                     mx = fmaxf(mx, (g.raw[(ub * Tp + t) * FP + f] - m.m) / m.d);
                 }
                 sqmax[f] = mx;
@@ -389,32 +448,34 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
 }
 
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
-                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s, int phase) {
-    if (phase == FE_PHASE_REST) {
-        // the caller's tensors are only touched by the repack kernels
-    } else if (is_complex) {
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s) {
+    const bool offline = norm_type == FSNP_NORM_OFFLINE_LAPLACE || norm_type == FSNP_NORM_OFFLINE_GAUSSIAN;
+    double* colsum = offline ? buf.fsum : nullptr;       // (cumulative norms: fsum is the sum of the NORMALISED input, fe_fsum_kernel)
+    if (is_complex) {
         hipLaunchKernelGGL(fe_repack_complex_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s,
                            reinterpret_cast<const float2*>(in[0]), (long)strides[0][0], (long)strides[0][1],
-                           (long)strides[0][2], buf.raw, 3, d.B, d.T, d.Tp, d.F, d.FP);
+                           (long)strides[0][2], buf.raw, colsum, buf.tot, 3, d.B, d.T, d.Tp, d.F, d.FP);
     } else {
         StridedIn si;
         for (int i = 0; i < 3; ++i) {
             si.p[i] = in[i];
             si.sb[i] = strides[i][0]; si.sf[i] = strides[i][1]; si.st[i] = strides[i][2];
         }
-        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw,
+        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), 3 * d.B), dim3(256), 0, s, si, buf.raw, colsum, buf.tot,
                            d.B, d.T, d.Tp, d.F, d.FP);
     }
-    if (phase == FE_PHASE_REPACK) return;
-    hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
-    hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
-    const int frows = fsum_rows_per_wg(d.B);
-    const int fthreads = d.F <= 256 ? 256 : d.F >= 512 ? 512 : (d.F + 63) / 64 * 64;
-    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 3), dim3(fthreads), 0, s, buf.raw, buf.md, buf.fsum,
-                       d.B, d.Tp, d.F, d.FP, frows);
+    if (!offline) {
+        hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 3), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);
+        hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 3), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
+        const int frows = fsum_rows_per_wg(d.B);
+        const int fthreads = d.F <= 256 ? 256 : d.F >= 512 ? 512 : (d.F + 63) / 64 * 64;
+        hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 3), dim3(fthreads), 0, s, buf.raw, buf.md, buf.fsum,
+                           d.B, d.Tp, d.F, d.FP, frows);
+    }
     GateArgs g;
-    g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.gate = buf.gate;
+    g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.tot = buf.tot; g.gate = buf.gate;
     g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
+    g.offline_norm = offline ? norm_type : -1;
     // 34 FP floats of dynamic LDS: beyond 64 KiB (num_freqs > 480) the kernel needs the opt-in; beyond a CU's LDS the launch fails
     // loudly (hipGetLastError in fsnp_forward)
     static PerDeviceOnce gate_once;
@@ -433,14 +494,14 @@ void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const i
     if (is_complex) {
         hipLaunchKernelGGL(fe_repack_complex_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s,
                            reinterpret_cast<const float2*>(mag), (long)strides[0], (long)strides[1], (long)strides[2],
-                           buf.raw, 1, d.B, d.T, d.Tp, d.F, d.FP);
+                           buf.raw, nullptr, nullptr, 1, d.B, d.T, d.Tp, d.F, d.FP);
     } else {
         StridedIn si;
         for (int i = 0; i < 3; ++i) {
             si.p[i] = mag;
             si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2];
         }
-        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw,
+        hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw, nullptr, nullptr,
                            d.B, d.T, d.Tp, d.F, d.FP);
     }
     hipLaunchKernelGGL(fe_frame_kernel, dim3(d.Tp, d.B, 1), dim3(64), 0, s, buf.raw, buf.frame, d.B, d.Tp, d.F, d.FP);

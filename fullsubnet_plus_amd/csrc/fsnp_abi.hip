@@ -16,6 +16,7 @@
 #include "lstm_common.h"
 #include "planner.h"
 #include "fsnp_handle.h"
+#include "weight_watch.h"
 
 namespace fsnp {
 
@@ -74,58 +75,6 @@ static PlannerCtx pctx(const fsnp_handle* h) {
 }
 
 
-void drop_graphs(fsnp_handle* h) {
-    for (auto& e : h->graphs) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
-    h->graphs.clear();
-}
-
-// Launches a cached graph on the handle's private stream, ordered after / before the caller's stream with events
-// (the caller's stream is usually torch's legacy default stream, which cannot be captured; keeping the replay on the
-// capture stream makes the ordering explicit instead of relying on default-stream semantics).
-static int launch_graph_between(fsnp_handle* h, hipGraphExec_t exec, hipStream_t s) {
-    if (h->use_graph == 2) { FSNP_HIP_CHECK(hipGraphLaunch(exec, s)); return 0; }     // straight into the caller's stream
-    FSNP_HIP_CHECK(hipEventRecord(h->ev_in, s));
-    FSNP_HIP_CHECK(hipStreamWaitEvent(h->cap_stream, h->ev_in, 0));
-    FSNP_HIP_CHECK(hipGraphLaunch(exec, h->cap_stream));
-    FSNP_HIP_CHECK(hipEventRecord(h->ev_out, h->cap_stream));
-    FSNP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_out, 0));
-    return 0;
-}
-
-// Replays `middle` (workspace-only launches) from a cached hipGraph; captures it on the private stream the first time.
-template <typename F>
-static int run_graphed(fsnp_handle* h, const GraphKey& key, hipStream_t s, F middle) {
-    if (!h->cap_stream) {
-        FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
-    }
-    for (auto& e : h->graphs)
-        if (e.key == key) return launch_graph_between(h, e.exec, s);
-    FSNP_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    middle(h->cap_stream);
-    hipGraph_t g = nullptr;
-    const hipError_t ec = hipStreamEndCapture(h->cap_stream, &g);
-    if (ec != hipSuccess || g == nullptr) {
-        set_error("hipGraph capture of the full-band stages failed: %s (set FSNP_GRAPH=0 to launch kernel by kernel)", hipGetErrorString(ec));
-        return 4;
-    }
-    hipGraphExec_t ex = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    if (ei != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        set_error("hipGraphInstantiate failed: %s (set FSNP_GRAPH=0 to launch kernel by kernel)", hipGetErrorString(ei));
-        return 4;
-    }
-    if (h->graphs.size() >= 8) {
-        (void)hipGraphExecDestroy(h->graphs.front().exec);
-        (void)hipGraphDestroy(h->graphs.front().graph);
-        h->graphs.erase(h->graphs.begin());
-    }
-    h->graphs.push_back({key, g, ex});
-    return launch_graph_between(h, ex, s);
-}
-
 // Row slots of the sub-band problem.  Tile i owns `rt` slots (32 MFMA rows + ex VALU rows) and gets
 // base (+1 for the first rem tiles) consecutive sequences; slot -> (utterance, frequency, output offset).
 __global__ void build_rows_kernel(RowDesc* rows, int num_rows, int num_tiles, int rt, int F, int T, int mode,
@@ -171,6 +120,66 @@ static void launch_zero_region(void* p, size_t bytes, hipStream_t s) {      // b
     if (n16 == 0) return;
     const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
     hipLaunchKernelGGL(zero_region_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16);
+}
+
+// ---- the forward's prologue as ONE launch (round 5; it used to be a zeroing kernel, a build_rows launch per chunk and, with a weight
+// watch, the fingerprint kernel - three to six dependent launches of ~5 us each in front of a 250 us full-band stage at B = 1):
+// blocks [0, zb) zero the accumulator / exchange / counter region, [zb, zb + rb) describe the sub-band rows of every chunk, the rest
+// fingerprint the watched source tensors (fsnp_watch_weights).
+struct PrologueChunk { int slot0, nrows, tiles, rt, row0, blocks; };
+struct PrologueArgs {
+    uint4* zero; size_t n16; int zero_blocks;
+    RowDesc* rows; PrologueChunk chunk[8]; int nchunks, rows_blocks;
+    int F, T, mode, batch_offset, global_batch, groups, OC;
+    const WatchSeg* segs; int nseg, watch_blocks; unsigned long long* watch_acc; unsigned* err_host;
+};
+__device__ __forceinline__ void build_rows_slot(RowDesc* rows, int slot, int num_rows, int num_tiles, int rt, int F, int T, int mode,
+                                                int batch_offset, int global_batch, int n_base, int groups, int OC) {
+    const int tile = slot / rt, sl = slot % rt;
+    const int base = num_rows / num_tiles, rem = num_rows % num_tiles;
+    const int cnt = base + (tile < rem ? 1 : 0);
+    const int n = n_base + tile * base + (tile < rem ? tile : rem) + sl;
+    RowDesc r{0, 0, 0, 0};
+    if (sl < cnt) {
+        r.valid = 1;
+        if (mode == FSNP_MODE_FULL) {
+            r.b = n / F; r.f = n % F;
+            r.out_off = ((r.b * OC) * F + r.f) * T;
+        } else {                       // drop_band: see build_rows_kernel
+            const int G = groups, Fh = F / G;
+            r.b = n / Fh;
+            const int i = n % Fh;
+            const int s = batch_offset + r.b, p = s % G;
+            int orow = s / G;
+            for (int q = 0; q < p; ++q) orow += (global_batch - q + G - 1) / G;
+            r.f = p + G * i;
+            r.out_off = ((orow * OC) * Fh + i) * T;
+        }
+    }
+    rows[slot] = r;
+}
+__global__ __launch_bounds__(256) void prologue_kernel(PrologueArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.zero_blocks) {
+        const size_t stride = (size_t)a.zero_blocks * 256;
+        for (size_t i = (size_t)b * 256 + threadIdx.x; i < a.n16; i += stride) a.zero[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    int rb = b - a.zero_blocks;
+    if (rb < a.rows_blocks) {
+        for (int c = 0; c < a.nchunks; ++c) {
+            const PrologueChunk k = a.chunk[c];
+            if (rb < k.blocks) {
+                const int slot = rb * 256 + threadIdx.x;
+                if (slot < k.tiles * k.rt)
+                    build_rows_slot(a.rows + k.slot0, slot, k.nrows, k.tiles, k.rt, a.F, a.T, a.mode, a.batch_offset, a.global_batch, k.row0, a.groups, a.OC);
+                return;
+            }
+            rb -= k.blocks;
+        }
+        return;
+    }
+    weight_watch_block(a.segs, a.nseg, a.watch_acc, 0, a.err_host, b - a.zero_blocks - a.rows_blocks, a.watch_blocks);
 }
 
 // Column-split launches need all their workgroups co-resident.  Two of them running at once (two handles / two streams
@@ -223,7 +232,6 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
         if (c.kind == 0) {
             if (h->gru) launch_gru(h->lw, ca, s);
-            else if (h->ih_bf16 == 2 && c.ex == 0) launch_lstm_bf3(h->lw, ca, s);      // (VALU-row tiles exist in fp32 / bf16-ih only)
             else launch_lstm(h->lw, ca, s);
             continue;
         }
@@ -237,15 +245,14 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         ca.coop_chaos = h->coop_chaos;
         // pipelined loop: a deferred K-split chunk shares the chip with the next forward's full-band GEMMs; a GEMM workgroup that
         // lands on one of its CUs runs at ~0.6x (and each GEMM launch lasts as long as its slowest workgroup: stage 1.25 -> 1.85 ms),
-        // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs (FSNP_OWN_CU=0: off)
-        static const int own_cu = [] { const char* e = getenv("FSNP_OWN_CU"); return e && e[0] == '0' ? 0 : 1; }();
+        // so the chunk claims its CUs' whole LDS and the GEMM workgroups go to the other CUs
         // (never for a launch planned with two workgroups per CU: they would no longer be co-resident)
-        ca.coop_own_cu = (own_cu && h->side_stream && s == h->side_stream && chunk_workgroups(h, c) <= h->num_cus_real) ? 160 * 1024 - 256 : 0;
+        ca.coop_own_cu = (h->side_stream && s == h->side_stream && chunk_workgroups(h, c) <= h->num_cus_real) ? 160 * 1024 - 256 : 0;
         ca.coop_err = h->d_err;
         ca.coop_abort = abort_word;
         ca.coop_units = c.units; ca.coop_groups = c.groups; ca.coop_rows_per_group = c.rpg;
-        // XCD-local workgroup placement (lstm_common.h), unless FSNP_COOP_XCD=0 or a launch planned with two workgroups per CU
-        static const int xcd_local = [] { const char* e = getenv("FSNP_COOP_XCD"); return e && e[0] == '0' ? 0 : 1; }();
+        // XCD-local workgroup placement (lstm_common.h), unless the launch was planned with two workgroups per CU
+        constexpr int xcd_local = 1;
         {
             const int S = c.kind == 8 ? h->H / 16 : (c.kind == 1 || c.kind == 9) ? h->H / c.units : h->H / 128;
             const int T = c.kind == 2 ? c.groups : c.num_tiles, cpx = h->num_cus_real / 8;
@@ -330,6 +337,7 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
     w.sbt_x0 = take(sbt_x); w.sbt_x = take(sbt_x); w.sbt_fb = take(sbt_x); w.sbt_y1 = take(sbt_y); w.sbt_y2 = take(sbt_y);
     w.zero_begin = o;
     w.fsum = take(fsn ? 0 : (size_t)3 * B * h->FP * 8);
+    w.fe_tot = take(fsn ? 0 : (size_t)3 * B * 2 * 8);
     w.gn = take(fsn ? 0 : (size_t)h->NB * 2 * 3 * B * kGnStride * 8);
     w.sb_acc = take((size_t)B * 2 * 8);
     w.coop_hx = take(lstm_coop_exchange_bytes(h->H, plan.coop_tiles));
@@ -352,7 +360,6 @@ static Workspace plan_workspace(const fsnp_handle* h, int B, int T, int mode) {
 static int ensure_workspace(fsnp_handle* h, size_t bytes, hipStream_t s) {
     bytes = align_up(bytes, 4096);
     if (bytes <= h->ws_bytes) return 0;
-    drop_graphs(h);
     unsigned char* nw = nullptr;
     FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&nw), bytes * h->ws_slots, s));
     // a fresh workspace is all zeros: tcn_gemm_dma_kernel DMAs the pad columns [K, lda) of its operand planes (they meet zero
@@ -479,7 +486,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         auto it = g_cal_cache.find(key);
         if (it != g_cal_cache.end()) {
             if (measured) *measured = it->second;
-            if (adopt) { h->cost = it->second; drop_graphs(h); }
+            if (adopt) h->cost = it->second;
             return 0;
         }
     }
@@ -589,7 +596,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
     }
     t.calibrated = 1;
     if (measured) *measured = t;
-    if (adopt) { h->cost = t; drop_graphs(h); }
+    if (adopt) h->cost = t;
     std::lock_guard<std::mutex> lk(g_cal_mu);
     g_cal_cache[key] = t;
     return 0;
@@ -785,12 +792,12 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         h->hp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
     }
     {
+        const char* ve = getenv("FSNP_VERIFY_EVERY");      // N > 0: fsnp_set_verify(h, N) from the start (models with an exchange-free kernel)
+        if (ve && atoi(ve) > 0 && h->rowtile_ok && !generic_sb && cfg->sequence_model != FSNP_SEQ_TCN) h->verify_every = atoi(ve);
         const char* we = getenv("FSNP_COOP_W");           // 0 = never plan the wave-owned column split (lstm_coopw.hip)
         h->coop_w = we && we[0] == '0' ? 0 : 1;
         h->coopw_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && cfg->sb_hidden == 384;
     }
-    const char* dsm = getenv("FSNP_DEFER_SMALL");
-    if (dsm && dsm[0] == '0') h->defer_small = 0;
     const char* sk = getenv("FSNP_COOP_SKEW");
     if (sk && sk[0] == '0') h->coop_skew = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&h->d_err), 256, hipHostMallocMapped) != hipSuccess) {
@@ -800,14 +807,6 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     }
     memset(h->d_err, 0, 256);
     h->d_err[4] = 0xFFFFFFFFu;                     // smallest (utterance, bin, frame) key of a failed verification (atomic min)
-    const char* cg = getenv("FSNP_COMPOSITE_GAIN");      // tuning: 0 = never split a batch into row-tile rounds + remainder
-    if (cg) h->composite_gain = atof(cg);
-    const char* gp = getenv("FSNP_GRAPH");
-    if (gp && gp[0] == '1') h->use_graph = 1;
-    if (gp && gp[0] == '2') h->use_graph = 2;
-    const char* nw = getenv("FSNP_LSTM_WAVES");
-    if (nw && atoi(nw) == 4) h->lstm_waves = 4;
-    if (nw && atoi(nw) == 12) h->lstm_waves = 12;
     const char* dbg = getenv("FSNP_DEBUG_STAGES");
     h->debug = dbg && dbg[0] == '1';
     *out = h;
@@ -818,8 +817,6 @@ void fsnp_destroy(fsnp_handle* h) {
     if (!h) return;
     fsnp::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    drop_graphs(h);
-    if (h->cap_stream) { (void)hipStreamDestroy(h->cap_stream); (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); }
     if (h->ws) (void)hipFreeAsync(h->ws, nullptr);        // (allocated from the stream-ordered pool; the device is idle here)
     if (h->io) (void)hipFreeAsync(h->io, nullptr);
     (void)hipDeviceSynchronize();
@@ -891,8 +888,6 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     unsigned char* base = h->ws + (size_t)slot * h->ws_bytes;
     auto fptr = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
 
-    // fsnp_watch_weights: fingerprint the caller's source tensors in front of this forward (a .data edit since the pack flags the handle)
-    if (h->watch_nseg > 0 && (h->watch_calls++ % h->watch_every) == 0 && launch_weight_watch(h, s, false)) return 4;
     TimingRec rec{};
     if (h->timing) {
         if (take_timing_rec(h, rec)) return 4;
@@ -908,16 +903,40 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     sbuf.acc = reinterpret_cast<double*>(base + w.sb_acc);
     sbuf.md_utt = reinterpret_cast<NormMD*>(base + w.md_utt);
     sbuf.md_row = cumulative ? reinterpret_cast<NormMD*>(base + w.md_row) : nullptr;
-    // workspace-only prologue shared by both models: zero the accumulators, describe the sub-band rows
-    auto prologue = [&](hipStream_t st) {
-        launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
-        launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, h->cfg.output_size, st);
+    // the prologue of both models, one launch: zero the accumulators / exchange images / counters, describe the sub-band rows, and
+    // - fsnp_watch_weights - fingerprint the caller's source tensors (a .data edit since the pack flags the handle)
+    auto prologue = [&](hipStream_t st) -> int {
+        const bool watch = h->watch_nseg > 0 && (h->watch_calls++ % h->watch_every) == 0;
+        if (plan.chunks.size() > 8) {                     // (more chunks than the argument block holds: the separate kernels)
+            launch_zero_region(base + w.zero_begin, w.zero_end - w.zero_begin, st);
+            launch_build_rows(plan, rows, h->F, frames, mode, batch_offset, global_batch, 0, h->cfg.num_groups_in_drop_band, h->cfg.output_size, st);
+            return watch ? launch_weight_watch(h, st, false) : 0;
+        }
+        PrologueArgs pa{};
+        pa.zero = reinterpret_cast<uint4*>(base + w.zero_begin);
+        pa.n16 = (w.zero_end - w.zero_begin) / 16;
+        pa.zero_blocks = (int)std::min<size_t>((pa.n16 + 255) / 256, 2048);
+        pa.rows = rows;
+        for (const SbChunk& c : plan.chunks) {
+            PrologueChunk& k = pa.chunk[pa.nchunks++];
+            k.slot0 = c.slot0; k.nrows = c.nrows; k.tiles = c.num_tiles; k.rt = c.rps; k.row0 = c.row0; k.blocks = cdiv(c.num_tiles * c.rps, 256);
+            pa.rows_blocks += k.blocks;
+        }
+        pa.F = h->F; pa.T = frames; pa.mode = mode; pa.batch_offset = batch_offset; pa.global_batch = global_batch;
+        pa.groups = h->cfg.num_groups_in_drop_band; pa.OC = h->cfg.output_size;
+        pa.segs = static_cast<const WatchSeg*>(h->watch_segs); pa.nseg = watch ? h->watch_nseg : 0;
+        pa.watch_blocks = watch ? std::min(h->watch_nseg, kWatchBlocks) : 0;
+        pa.watch_acc = h->watch_acc; pa.err_host = h->d_err;
+        hipLaunchKernelGGL(prologue_kernel, dim3(pa.zero_blocks + pa.rows_blocks + pa.watch_blocks), dim3(256), 0, st, pa);
+        return 0;
     };
+    if (prologue(s)) return 4;
 
     if (!fsn) {
         FrontendBuffers fbuf;
         fbuf.raw = fptr(w.raw); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
         fbuf.md = reinterpret_cast<NormMD*>(base + w.md); fbuf.fsum = reinterpret_cast<double*>(base + w.fsum);
+        fbuf.tot = reinterpret_cast<double*>(base + w.fe_tot);
         fbuf.gate = fptr(w.gate); fbuf.att = fptr(w.att);
         const float* in[3] = {mag, real, imag};
         TcnBuffers tbuf;
@@ -925,22 +944,10 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         tbuf.gn = reinterpret_cast<double*>(base + w.gn); tbuf.fb = fptr(w.fb);
         tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
         // the caller's tensors are read by the repack kernel only; everything up to the LSTM then stays in the workspace
-        launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s, FE_PHASE_REPACK);
-        auto middle = [&](hipStream_t st) {
-            prologue(st);
-            launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, st, FE_PHASE_REST);
-            launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, st);
-            launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, st);
-        };
-        if (h->use_graph) {
-            const GraphKey key{batch, frames, mode, batch_offset, global_batch, h->num_cus, h->lstm_coop, h->ih_bf16,
-                               h->debug ? 1 : 0, base, h->d_weights};
-            if (run_graphed(h, key, s, middle)) return 4;
-        } else {
-            middle(s);
-        }
+        launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s);
+        launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+        launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     } else {
-        prologue(s);
         // fullsubnet.py:82-90: pad, norm(noisy_mag), 2-layer LSTM(F -> CH), Linear(CH, F) + fb_act
         FrontendBuffers fbuf{};
         fbuf.raw = fptr(w.att); fbuf.frame = reinterpret_cast<double*>(base + w.frame);
@@ -962,6 +969,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int chp = (int)align_up(d.CH, 4);           // row stride of the h1 sequence (a float4 multiple; pad columns written as zeros)
         fa.seq_stride = chp;
         if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
+        else if (h->fb_valu && lstm_fbv_available(h->fbw, batch)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); });   // B <= 4: VALU
         else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
         launch_linear_act(fptr(w.y1), chp, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
@@ -1224,7 +1232,6 @@ int fsnp_debug_set_costs(fsnp_handle* h, const double* costs, int32_t workgroups
     if (costs) costs_from_array(h->cost, costs);
     h->cost.calibrated = 1;          // pinned: the lazy calibration will not replace it
     h->coop_occ = workgroups_per_cu;
-    drop_graphs(h);
     return 0;
 }
 
@@ -1252,10 +1259,10 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
     for (int i = 0; i < n; ++i) {
         const SbChunk& c = plan.chunks[i];
         for (int k = 0; k < 4; ++k) out[7 * i + k] = base[4 * i + k];
-        // arithmetic of THIS chunk: the bf16 variants exist for the one-tile-per-CU LSTM kernel only (lstm.hip / lstm_bf3.hip);
+        // arithmetic of THIS chunk: the bf16 variants exist for the one-tile-per-CU LSTM kernel only (lstm.hip) and the half-tile kernel (lstm16.hip);
         // sequences that the plan hands to any other kernel run in fp32 whatever fsnp_set_precision says
         int prec = 0;
-        if (!h->sb_tcn && !h->gru && c.kind == 0) prec = h->ih_bf16 == 1 ? 1 : (h->ih_bf16 == 2 && c.ex == 0) ? 2 : 0;
+        if (!h->sb_tcn && !h->gru && c.kind == 0) prec = h->ih_bf16 == 1 ? 1 : 0;
         if (!h->sb_tcn && !h->gru && c.kind == 4 && h->ih_bf16 == 1 && h->lw.wpack16_bf) prec = 1;       // half-tile kernel: bf16 ih-GEMM too (round 4)
         out[7 * i + 4] = prec;
         out[7 * i + 5] = h->sb_tcn ? 0 : chunk_workgroups(h, c);
@@ -1327,7 +1334,7 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
 }
 
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
-    if (!h || ih_bf16 < 0 || ih_bf16 > 2) { set_error("fsnp_set_precision: 0 (fp32), 1 (bf16 ih-GEMM) or 2 (split-bf16 emulation of fp32)"); return 1; }
+    if (!h || ih_bf16 < 0 || ih_bf16 > 1) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM, BASELINE.json configs[4])"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
     if (ih_bf16 && h->H != 384) { set_error("fsnp_set_precision: the bf16 variants exist for sb_model_hidden_size = 384 only"); return 2; }
     if (ih_bf16 && h->KX != 40) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 40 features only"); return 2; }
@@ -1366,17 +1373,15 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable) {
     FSNP_HIP_CHECK(hipDeviceSynchronize());              // nothing of either mode is in flight while the workspace is re-shaped
     if (enable && !h->side_stream) {
         // the deferred remainder chunk is a latency-bound chain of inter-workgroup hand-offs: at the highest stream priority
-        // its waves win the arbitration against the full-band GEMMs it shares CUs with (FSNP_SIDE_PRIO=0: default priority)
+        // its waves win the arbitration against the full-band GEMMs it shares CUs with
         int lo = 0, hi = 0;
-        const char* pe = getenv("FSNP_SIDE_PRIO");
-        if (!(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
             FSNP_HIP_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi));
         else
             FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
         for (auto& e : h->ev_side) FSNP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    drop_graphs(h);
     if (h->ws) { FSNP_HIP_CHECK(hipFreeAsync(h->ws, nullptr)); FSNP_HIP_CHECK(hipDeviceSynchronize()); h->ws = nullptr; h->ws_bytes = 0; }
     h->have_last = false;
     h->pipeline = enable;
@@ -1419,22 +1424,18 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("model=%s num_freqs=%d look_ahead=%d sb_hidden=%d tcn_hidden=%d sub-band inputs=%d (kernels instantiated for K=%d) sequence_model=%s norm_type=%d attention=%d subband_num=%d\n",
         h->model == FSNP_MODEL_FULLSUBNET ? "FullSubNet" : "FullSubNet+", h->F, h->cfg.look_ahead, h->H, h->CH, h->NIN, h->KX,
         h->sb_tcn ? "TCN" : h->gru ? "GRU" : "LSTM", h->cfg.norm_type, h->cfg.attention, h->cfg.subband_num > 0 ? h->cfg.subband_num : 1);
-    add("weights committed=%d precision=%d (0 fp32, 1 bf16 ih-GEMM, 2 split-bf16) pipeline=%d timing=%d workspace=%zu bytes x %d\n",
+    add("weights committed=%d precision=%d (0 fp32, 1 bf16 ih-GEMM) pipeline=%d timing=%d workspace=%zu bytes x %d\n",
         (int)h->committed, h->ih_bf16, h->pipeline, (int)h->timing, h->ws_bytes, h->ws_slots);
     add("effective settings (environment variable as read at fsnp_create = value in force):\n");
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
     add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
     add("  FSNP_COOP_W=%s -> wave-owned column split (lstm_coopw.hip) %s\n", env("FSNP_COOP_W"), !h->coopw_ok ? "not built for this model" : h->coop_w ? "planned" : "never");
-    add("  FSNP_COOP_SKEW=%s -> K-split schedule %s (FSNP_SKEW_MIN_UNITS=%s: smallest units per workgroup that run it, default 8)\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial", env("FSNP_SKEW_MIN_UNITS"));
+    add("  FSNP_COOP_SKEW=%s -> K-split schedule %s\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial");
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
-    add("  FSNP_COOP_XCD=%s (0 = no XCD-local workgroup placement)  FSNP_OWN_CU=%s (0 = deferred chunks do not claim their CUs' LDS)\n", env("FSNP_COOP_XCD"), env("FSNP_OWN_CU"));
     add("  FSNP_LSTM16=%s -> half-tile kernel %s\n", env("FSNP_LSTM16"), h->lstm16_ok ? "planned" : "not used");
-    add("  FSNP_LSTM_WAVES=%s -> %d (0 = auto)\n", env("FSNP_LSTM_WAVES"), h->lstm_waves);
     add("  FSNP_CALIBRATE=%s -> cost table %s\n", env("FSNP_CALIBRATE"), h->cost.calibrated ? "measured / pinned" : h->calibrate ? "to be measured at the first plan" : "built-in");
-    add("  FSNP_COMPOSITE_GAIN=%s -> %.3f\n", env("FSNP_COMPOSITE_GAIN"), h->composite_gain);
-    add("  FSNP_DEFER_SMALL=%s -> %d  FSNP_SIDE_PRIO=%s\n", env("FSNP_DEFER_SMALL"), h->defer_small, env("FSNP_SIDE_PRIO"));
-    add("  FSNP_GRAPH=%s -> %d (0 plain launches, 1 / 2 hipGraph replay of the full-band stages)\n", env("FSNP_GRAPH"), h->use_graph);
-    add("  FSNP_GEMM_DMA=%s -> %d  FSNP_GEMM_BN=%s FSNP_GEMM_PF=%s (tuning of the general GEMM kernel)  FSNP_GEMM_SPLITK=%s (small-batch split-K GEMM up to this many workgroups per CU, default 6, 0 = never)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma, env("FSNP_GEMM_BN"), env("FSNP_GEMM_PF"), env("FSNP_GEMM_SPLITK"));
+    add("  FSNP_GEMM_DMA=%s -> %d (0 = the general GEMM kernel everywhere)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma);
+    add("  FSNP_VERIFY_EVERY=%s -> exchange verification every %d forwards (0 = off)\n", env("FSNP_VERIFY_EVERY"), h->verify_every);
     add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
     add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, half-tile ping-pong %.1f / %.1f, wave-owned split full %.1f / %.1f, one tile %.1f / %.1f\n",
         h->cost.ksplit[0][0], h->cost.ksplit[1][0], h->cost.ksplit[2][0], h->cost.ksplit[3][0], h->cost.ksplit1[0], h->cost.ksplit1[1],
@@ -1460,16 +1461,9 @@ int fsnp_debug_set_chaos(fsnp_handle* h, int32_t seed) {
     return 0;
 }
 
-int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 2) { set_error("fsnp_debug_set_graph: mode must be 0 (plain launches), 1 or 2 (hipGraph replay)"); return 1; }
-    h->use_graph = mode;
-    return 0;
-}
-
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
     if (!h || mode < 0 || mode > 3) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply), 2 (as 1, never the small-batch split-K kernel) or 3 (the 128-row DMA kernel only)"); return 1; }
     h->tw.gemm_dma = mode;
-    drop_graphs(h);          // a captured full-band chain holds the other kernels
     return 0;
 }
 
@@ -1478,9 +1472,9 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
     h->lstm_coop = mode != 0;
     h->coop_skew = mode != 2;
     h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
+    h->fb_valu = mode != 2;        // (FullSubNet: mode 2 also keeps the full-band LSTM on the K-split kernel, whatever the batch)
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
-    drop_graphs(h);            // a captured chain holds row descriptors / a zero region laid out for the old plan
     return 0;
 }
 

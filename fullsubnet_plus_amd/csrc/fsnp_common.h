@@ -47,7 +47,9 @@ struct FrontendBuffers {
     float* raw;       // [3][B][Tp][FP]
     double* frame;    // [3][B][Tp][2]   per-frame (sum, sum of squares) over F
     NormMD* md;       // [3][B][Tp]
-    double* fsum;     // [3][B][FP]      per-frequency sum over t of the normalised input
+    double* fsum;     // [3][B][FP]      per-frequency sum over t: of the RAW input (offline norms: accumulated by the repack kernel) or of
+                      //                 the normalised input (cumulative norms: fe_fsum_kernel)
+    double* tot;      // [3][B][2]       (sum, sum of squares) of the raw input per branch and utterance (repack kernel), zeroed per forward
     float* gate;      // [3][B][FP]
     float* att;       // [3][B][Tp][FP]
 };
@@ -56,11 +58,9 @@ void launch_apply_cirm(const float* mask, const float* noisy, const int64_t stri
                        const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
 // is_complex: in[0] is the interleaved complex64 STFT buffer (strides[0] in complex elements); mag / real / imag are
 // derived inside the repack kernel
-// phase: everything, only the repack of the caller's tensors into buf.raw, or everything after it (workspace only:
-// the part fsnp_forward replays from a hipGraph)
-enum { FE_PHASE_ALL = 0, FE_PHASE_REPACK = 1, FE_PHASE_REST = 2 };
+// (buf.fsum and buf.tot must be zero when this is called: the repack kernel accumulates the offline norms' statistics into them)
 void launch_frontend(const Dims& d, int norm_type, const float* const in[3], const int64_t strides[3][3], bool is_complex,
-                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s, int phase = FE_PHASE_ALL);
+                     const FrontendWeights& w, const FrontendBuffers& buf, hipStream_t s);
 // original FullSubNet: magnitude only - repack into buf.raw [B][Tp][FP] and the norm's (m_t, d_t) table into buf.md
 void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const int64_t strides[3], bool is_complex,
                          const FrontendBuffers& buf, hipStream_t s);
@@ -155,14 +155,14 @@ struct LstmWeights {
     const float* wpack;  // MFMA-fragment-ordered [wave][layer-0 stream | layer-1 stream], KX = 40
     const float* wpack12; // same for the 12-wave kernel (32 hidden units per wave)
     const float* wpack_bf[2];   // bf16-ih streams (4-wave, 12-wave): layer-1 W_ih as bf16 k-steps (configs[4])
-    int ih_bf16;                // 1 = use them; 2 = the split-bf16 variant (wpack_bf3, lstm_bf3.hip)
+    int ih_bf16;                // 1 = use them
     const float* wpack_coop[4]; // column-split kernel, 8 << i hidden units per workgroup: [split][k-group][tile][lane][4]
     const float* wpack_coopn;   // three-way column-split kernel (lstm_coopn.hip): [32-unit block][k-group][gate][lane][4]
     const float* wpack16;       // half-tile kernel (lstm16.hip): [wave][k-group of 16][24 tiles of 16 columns][lane][4]
     const float* wpack16_bf;    // its bf16-ih stream: layer-1 W_ih as bf16 k-steps of 32 (configs[4]); nullptr = not packed
-    const float* wpack_bf3;     // split-bf16 variant (lstm_bf3.hip): [wave][k-step of 16][tile][hi | lo][lane][8 x bf16]
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     const float* wpack_hp;      // half-tile ping-pong kernel (lstm_hp.hip): [column slice of 16 units][gate][k-group of 16][lane][4]
+    const float* wpack_fbv;     // full-band LSTM of FullSubNet for <= 4 utterances on the VALU (lstm_fbv.hip): [slice][fragment][thread][4]; nullptr = not packed
     const float* wpack_coopw;   // wave-owned column split (lstm_coopw.hip): [k-group][8-unit block, gate-interleaved columns][lane][4]; nullptr = not packed
     const float* wgen;          // runtime-sized kernel (lstm_generic.hip): transposed [layer][k][4H], layer 0 k = [x | h0], layer 1 = [h0 | h1]
     int gru;             // 1 = nn.GRU cell (column-split kernels only); weights / biases are packed as 4 slots r, z, n_x, n_h
@@ -225,11 +225,6 @@ size_t lstm16_pack_floats(int H, int KX);
 size_t lstm16_pack_floats_bf16ih(int H, int KX);
 void lstm16_pack_weights_bf16ih(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack);
 void lstm16_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* wpack);
-// lstm_bf3.hip: the same decomposition with every fp32 product emulated by three bf16 MFMAs (optional precision mode 2)
-void launch_lstm_bf3(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
-size_t lstm_bf3_pack_floats(int H, int KX, int NW);
-void lstm_bf3_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
-                           const float* whh1, float* wpack);
 // lstm_gru.hip: the same decomposition for nn.GRU (three live gate tiles per k-group, no VALU rows)
 void launch_gru(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 size_t gru_pack_floats(int H, int KX, int NW);
@@ -255,6 +250,12 @@ bool lstm_coopw_available(const LstmWeights& w, int units);
 int lstm_coopw_occupancy(const LstmWeights& w, int units);
 size_t lstm_coopw_pack_floats(int H, int KX);
 void lstm_coopw_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
+// lstm_fbv.hip: the full-band LSTM(num_freqs -> 512 x 2) of the original FullSubNet for 1 ... 4 utterances as matrix-VECTOR products
+// on the VALU (weights resident, H / 8 workgroups, serial schedule with one hand-off per step); h1 sequence out
+void launch_lstm_fbv(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+bool lstm_fbv_available(const LstmWeights& w, int batch);
+size_t lstm_fbv_pack_floats(int H);
+void lstm_fbv_pack_weights(int H, int NIN, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 // lstm_generic.hip: runtime-sized fp32-FMA kernel for the sizes no tuned kernel is instantiated for (any hidden size / input width);
 // a.num_tiles workgroups of a.coop_rows_per_group (1, 2, 4, 8) sequences; seq = the full-band model of the original FullSubNet
 void launch_lstm_generic(const LstmWeights& w, const LstmArgs& a, bool seq, hipStream_t s);

@@ -19,22 +19,8 @@ struct WeightSpec {
 struct Workspace {
     // offsets in bytes from the workspace base
     size_t att, fb, raw, x, y1, y2, gate, md, md_utt, md_row, rows, fb_rows, frame, sbt_x0, sbt_x, sbt_fb, sbt_y1, sbt_y2, zero_begin,
-        fsum, gn, sb_acc, coop_hx, coop_bar, coop_abort, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
+        fsum, fe_tot, gn, sb_acc, coop_hx, coop_bar, coop_abort, fb_hx, fb_bar, sbt_gn, zero_end, dbg_tcn0, total;
 };
-
-// The full-band part of a FullSubNet+ forward is ~75 tiny launches that only touch the workspace (0.9 ms at B = 1); it
-// can be captured once per (shape, mode, plan) into a hipGraph and replayed (opt-in: FSNP_GRAPH=1).  Measured: no gain -
-// the launches are asynchronous and the host runs ahead of the GPU, so the chain is bound by the kernels' own latency.
-struct GraphKey {
-    int B, T, mode, boff, gb, num_cus, coop, bf16, debug;
-    const void* ws;
-    const void* weights;
-    bool operator==(const GraphKey& o) const {
-        return B == o.B && T == o.T && mode == o.mode && boff == o.boff && gb == o.gb && num_cus == o.num_cus &&
-               coop == o.coop && bf16 == o.bf16 && debug == o.debug && ws == o.ws && weights == o.weights;
-    }
-};
-struct GraphEntry { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
 
 struct TimingRec {
     hipEvent_t e[4];  // start, after full-band stages, after the sub-band model (= end), after its FIRST chunk
@@ -108,6 +94,8 @@ struct fsnp_handle {
     bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
     int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0: never; fsnp_debug_set_lstm_coop(h, 4): even then)
+    int fb_valu = 1;             // FullSubNet: the full-band LSTM of <= 4 utterances runs on the VALU kernel (lstm_fbv.hip); fsnp_debug_set_gemm_dma-like
+                                 // test switch: fsnp_debug_set_lstm_coop(h, 2) turns it off together with the other round-3+ schedules
     bool coopw_ok = false;       // the wave-owned column split (lstm_coopw.hip) exists for this handle's sub-band model (LSTM, H = 384) ...
     int coop_w = 1;              // ... and the planner may use it (FSNP_COOP_W=0: never)
     unsigned* d_err = nullptr;   // [0] = error bits of finished launches (kErr*): an inter-workgroup wait timed out in a column-split LSTM
@@ -116,7 +104,7 @@ struct fsnp_handle {
                                  // the handle can fail loudly without a device synchronisation
     // fsnp_watch_weights: the caller's SOURCE tensors of the packed weights, fingerprinted on the device in front of every forward
     void* watch_segs = nullptr;              // device: WatchSeg[watch_nseg]
-    unsigned long long* watch_acc = nullptr; // device: {running sum, finished blocks, baseline}
+    unsigned long long* watch_acc = nullptr; // device: {-, finished blocks, baseline, ..., [8 + b] partial sum of block b}
     int watch_nseg = 0, watch_every = 1;
     long long watch_calls = 0;
     // fsnp_set_verify: every Nth forward whose plan holds a column-split launch is re-run on the one-tile-per-CU kernel and compared
@@ -133,11 +121,6 @@ struct fsnp_handle {
     size_t io_bytes = 0;
 
     double composite_gain = 0.97;   // a row-tile + remainder plan must be estimated this much cheaper to be chosen
-    int use_graph = 0;           // 0 = plain launches (default: measured no gain), 1 = replay on the
-                                 // private stream, 2 = replay straight into the caller's stream (FSNP_GRAPH=1|2)
-    hipStream_t cap_stream = nullptr;   // private stream: graph capture and replay
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    std::vector<GraphEntry> graphs;
 
     bool timing = false;
     std::vector<TimingRec> timing_recs;   // recorded, not yet read back (drained by fsnp_get_timing, or when 256 pile up)
@@ -166,12 +149,15 @@ namespace fsnp {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // bits of the host-mapped error word (fsnp_handle::d_err[0])
 constexpr unsigned kErrTimeout = 1u, kErrStaleWeights = 2u, kErrVerify = 4u;
-// fsnp_weights.hip: fingerprint of the watched source tensors on stream s (no-op without a watch)
+// fsnp_weights.hip: fingerprint of the watched source tensors on stream s (no-op without a watch); the device function is shared with
+// the forward's prologue kernel (fsnp_abi.hip), which runs the same blocks beside its zeroing / row-descriptor blocks
 int launch_weight_watch(fsnp_handle* h, hipStream_t s, bool baseline);
+struct WatchSeg { const unsigned* p; unsigned n; unsigned long long first; };      // (device function: weight_watch.h)
+constexpr int kWatchSeg = 8192;              // elements per segment of the watched tensors (8 uint4 loads per thread of a 256-thread block)
+constexpr int kWatchBlocks = 512;            // blocks of one fingerprint pass (each walks its share of the segments)
 void drop_weight_watch(fsnp_handle* h);
 // decodes and clears the error word: 0 = clean, else the return code of the call that notices (5 time-out, 6 stale weights, 7 verify) + message
 int take_device_errors(fsnp_handle* h, const char* where);
-void drop_graphs(fsnp_handle* h);
 // fsnp_weights.hip
 void build_specs(fsnp_handle* h);
 // cross-stream ordering of a handle's shared buffers (fsnp_abi.hip)

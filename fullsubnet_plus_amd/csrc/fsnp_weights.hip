@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fsnp_handle.h"
+#include "weight_watch.h"
 
 namespace fsnp {
 
@@ -110,36 +111,13 @@ void build_specs(fsnp_handle* h) {
 // ---- fsnp_watch_weights: a 64-bit fingerprint of the caller's source tensors, taken on the device in front of every forward.
 // sum over all elements of bits(x_i) * (2 i + 1) mod 2^64 (i = position in the concatenation): any single changed element changes
 // it, the sum is order-independent (integer adds), so blocks accumulate with one atomic each and the LAST block to finish compares.
-struct WatchSeg { const unsigned* p; unsigned n; unsigned long long first; };
 __global__ __launch_bounds__(256) void weight_watch_kernel(const WatchSeg* __restrict__ segs, int nseg, unsigned long long* acc,
                                                            int baseline, unsigned* err_host) {
-    unsigned long long sum = 0;
-    for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
-        const WatchSeg g = segs[sg];
-        for (unsigned i = threadIdx.x; i < g.n; i += 256) sum += (unsigned long long)g.p[i] * (2ull * (g.first + i) + 1ull);
-    }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
-    __shared__ unsigned long long part[4];
-    __shared__ int last;
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(acc, part[0] + part[1] + part[2] + part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = __hip_atomic_fetch_add(acc + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1;
-        if (last) {
-            const unsigned long long total = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (baseline) acc[2] = total;
-            else if (total != acc[2]) __hip_atomic_fetch_or(err_host, kErrStaleWeights, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    weight_watch_block(segs, nseg, acc, baseline, err_host, (int)blockIdx.x, (int)gridDim.x);
 }
 int launch_weight_watch(fsnp_handle* h, hipStream_t s, bool baseline) {
     if (h->watch_nseg <= 0) return 0;
-    const int grid = h->watch_nseg < 1024 ? h->watch_nseg : 1024;
+    const int grid = h->watch_nseg < kWatchBlocks ? h->watch_nseg : kWatchBlocks;
     hipLaunchKernelGGL(weight_watch_kernel, dim3(grid), dim3(256), 0, s, static_cast<const WatchSeg*>(h->watch_segs), h->watch_nseg,
                        h->watch_acc, baseline ? 1 : 0, h->d_err);
     FSNP_HIP_CHECK(hipGetLastError());
@@ -165,7 +143,7 @@ int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_
     if (n == 0) return 0;
     std::vector<WatchSeg> segs;
     unsigned long long first = 0;
-    constexpr int64_t kSeg = 32768;                   // elements per segment: ~270 segments of work for the default model
+    constexpr int64_t kSeg = kWatchSeg;               // elements per segment (32 KB): ~1400 segments for the default model
     for (int i = 0; i < n; ++i) {
         if (!dev_ptrs[i] || numels[i] < 0) { set_error("fsnp_watch_weights: tensor %d is null / negative", i); return 1; }
         for (int64_t o = 0; o < numels[i]; o += kSeg) {
@@ -176,9 +154,9 @@ int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_
     }
     if (segs.empty()) return 0;
     FSNP_HIP_CHECK(hipMalloc(&h->watch_segs, segs.size() * sizeof(WatchSeg)));
-    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->watch_acc), 256));
+    FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->watch_acc), (8 + kWatchBlocks) * 8));     // {-, tickets, baseline, -, ...; a partial sum per block}
     FSNP_HIP_CHECK(hipMemcpy(h->watch_segs, segs.data(), segs.size() * sizeof(WatchSeg), hipMemcpyHostToDevice));
-    FSNP_HIP_CHECK(hipMemset(h->watch_acc, 0, 256));
+    FSNP_HIP_CHECK(hipMemset(h->watch_acc, 0, (8 + kWatchBlocks) * 8));
     h->watch_nseg = (int)segs.size();
     return launch_weight_watch(h, static_cast<hipStream_t>(hip_stream), true);
 }
@@ -396,11 +374,6 @@ int fsnp_commit_weights(fsnp_handle* h) {
             have16_bf = true;
         }
     }
-    size_t o_wpack_bf3 = 0;
-    if (!h->gru && tuned && h->KX == 40 && H == 384) {      // optional split-bf16 variant of the one-tile-per-CU kernel
-        o_wpack_bf3 = alloc(lstm_bf3_pack_floats(H, h->KX, 12));
-        lstm_bf3_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_bf3);
-    }
     size_t o_wpack_gru = 0;
     if (h->gru && tuned && H == 384) {
         o_wpack_gru = alloc(gru_pack_floats(H, h->KX, 4));
@@ -429,7 +402,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
                                 blob.data() + o_wpack_coopn);
     // ---- original FullSubNet: full-band recurrent model (cooperative kernel, KX = 264) + Linear(CH, F) as a GEMM operand
     constexpr int KXF = 264;
-    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0, o_fbgen = 0;
+    size_t o_fbpack[3] = {0, 0, 0}, o_fbbias = 0, o_fsn_wf = 0, o_fsn_bf = 0, o_fbgen = 0, o_fbv = 0;
+    bool have_fbv = false;
     const int fsn_kp = (int)align_up(CH, 16), fsn_np = (int)align_up(F, 384);
     if (fsn) {
         const Rnn4 fbw = expand("fb_model.sequence_model.", CH, F);
@@ -442,6 +416,11 @@ int fsnp_commit_weights(fsnp_handle* h) {
             o_fbpack[ui] = alloc(lstm_coop_pack_floats(CH, KXF, units));
             lstm_coop_pack_weights(CH, F, KXF, units, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(),
                                    blob.data() + o_fbpack[ui]);
+        }
+        if (!h->generic_fb && !h->gru && CH == 512 && F <= 288) {          // small batches: matrix-vector products on the VALU (lstm_fbv.hip)
+            o_fbv = alloc(lstm_fbv_pack_floats(CH));
+            lstm_fbv_pack_weights(CH, F, fbw.wih0.data(), fbw.whh0.data(), fbw.wih1.data(), fbw.whh1.data(), blob.data() + o_fbv);
+            have_fbv = true;
         }
         o_fbbias = alloc(fbw.bias.size());
         std::copy(fbw.bias.begin(), fbw.bias.end(), blob.begin() + o_fbbias);
@@ -465,7 +444,6 @@ int fsnp_commit_weights(fsnp_handle* h) {
     }
 
     FSNP_ON_DEVICE(h);
-    drop_graphs(h);
     if (h->d_weights) { FSNP_HIP_CHECK(hipDeviceSynchronize()); FSNP_HIP_CHECK(hipFree(h->d_weights)); h->d_weights = nullptr; }
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_weights), blob.size() * sizeof(float)));
     FSNP_HIP_CHECK(hipMemcpy(h->d_weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -485,7 +463,6 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack_hp = d + o_wpack_hp;
     h->lw.wpack_coopw = h->coopw_ok ? d + o_wpack_coopw : nullptr;
     h->lw.wpack_gru = d + o_wpack_gru;
-    h->lw.wpack_bf3 = d + o_wpack_bf3;
     h->lw.wpack16 = d + o_wpack16;
     h->lw.wpack16_bf = have16_bf ? d + o_wpack16_bf : nullptr;
     h->lw.wpack_bf[0] = d + o_wpack_bf[0]; h->lw.wpack_bf[1] = d + o_wpack_bf[1]; h->lw.ih_bf16 = h->ih_bf16; h->lw.waves = h->lstm_waves; h->lw.bias = d + o_lbias; h->lw.wfc = d + o_wfc; h->lw.bfc = d + o_bfc;
@@ -498,6 +475,7 @@ int fsnp_commit_weights(fsnp_handle* h) {
         h->fbw.bias = d + o_fbbias;
         h->fbw.H = CH; h->fbw.NIN = F; h->fbw.KX = KXF; h->fbw.OUT = 0; h->fbw.gru = h->gru;
         h->fbw.wgen = d + o_fbgen;
+        h->fbw.wpack_fbv = have_fbv ? d + o_fbv : nullptr;
         h->fsn_wf = d + o_fsn_wf; h->fsn_bf = d + o_fsn_bf; h->fsn_kp = fsn_kp;
     }
     h->d_refl_w = d + o_refl;

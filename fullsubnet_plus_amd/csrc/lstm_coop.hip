@@ -838,9 +838,8 @@ static void launch_coop_inst(const LstmWeights& w, const LstmArgs& a, hipStream_
         // workgroup and up: 9 tiles 19.8 -> 18.0 us per step, 17 tiles 28.1 -> 25.8, 41 tiles 53.0 -> 48.4.  At 8 units it did not
         // pay in round 2 (1 tile 11.0 -> 10.8, 5 tiles 16 -> 28) - its two arrival counters per tile sat in the one cache line all
         // counters shared; with a line per counter (round 3, profiles/r03_column_split.md section 8) it does: 1 tile 9.7 -> 8.8,
-        // 5 tiles 10.4 -> 9.1.  FSNP_SKEW_MIN_UNITS=16 restores the round-2 choice.
-        static const int skew_min_units = [] { const char* e = getenv("FSNP_SKEW_MIN_UNITS"); return e ? atoi(e) : 8; }();
-        if (a.coop_skew && UNITS >= skew_min_units) {
+        // 5 tiles 10.4 -> 9.1.
+        if (a.coop_skew) {
             auto skew = lstm2_coop_skew_kernel<HID, KX, UNITS, GRU>;
             static PerDeviceOnce skew_once;
             skew_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds); });

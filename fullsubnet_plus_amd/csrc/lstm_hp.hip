@@ -25,6 +25,9 @@
 //     half-phase's first barrier (which thereby doubles as the "staging complete" barrier), the arrival a quarter pass later
 //     behind an honest vmcnt(0) - wave 0's queue holds nothing else;
 //   * fused phase as in lstm_pp.hip: [layer 1 of step t, layer 0 of step t + 1] is ONE pass over h0_t.
+// (Round 5 measured the alternative of fetching the next half-phase's operands BEHIND the pass, under the cell phase - an LDS-DMA issue
+//  costs 100-185 matrix-pipe cycles inside an MFMA stream: the pass shrank by 0.5 us, but the DMA then lands 0.75 us into the next
+//  half-phase and the cell phase grew by 0.2: 13.8 -> 14.2 us per step, profiles/r05_column_split.md.  The in-pass fetch stays.)
 // Exchange region and abort protocol: those of lstm_coop.hip; arrival counters: one per half tile, each in a 128-byte line of its own.
 // 16x16x4 MFMAs sum K in another order than the 32x32x2 kernels, so results are bit-identical to no sibling kernel; same
 // oracle tolerance (tests/test_gpu_parity.py::test_half_tile_ping_pong_kernel_vs_oracle), bitwise repeatable.

@@ -209,7 +209,7 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     // half tiles (lstm16.hip, LSTM at the default sizes, fp32): 16 CUs-worth of sequences per round in about half the time of a
     // 32-row round - the cheapest shape between the column-split kernels' range and a chip-filling round (parity-mode B = 32:
     // 4096 sequences = 256 half tiles, one launch), alone or as one full round + a column-split remainder
-    if (h.lstm16_ok && h.ih_bf16 != 2) {          // (fp32 and, round 4, the bf16 ih-GEMM mode; the split-bf16 mode exists on 32-row tiles only)
+    if (h.lstm16_ok) {                           // (fp32 and, round 4, the bf16 ih-GEMM mode)
         const int per_round = h.num_cus * 16;
         const SbChunk all16{4, 0, num_rows, cdiv(num_rows, 16), 0, 16, 0, 0, 0, 0, 0};
         const double c_all = est_step_us(h, all16) + 1.2;

@@ -838,8 +838,6 @@ template <int EPI>
 static bool launch_gemm_dma64(const GemmArgs& g, int n, int num_cus, hipStream_t s, int branches) {
     if constexpr (EPI != EPI_RESIDUAL) return false;      // (sconv only: conv1x1 and the final Linear have K = 257 -> a 16-deep k tail)
     else {
-    static const int on = [] { const char* e = getenv("FSNP_GEMM_BM64"); return e && e[0] == '0' ? 0 : 1; }();
-    if (!on) return false;
     if (n % 64 != 1 || g.K % BK64 || g.lda != g.K || g.ldw != g.K || g.K > 1024 || g.a_us || g.a_cols) return false;
     if (g.ldc % 4 || g.ldc < n + 3 || g.ldr % 4) return false;            // the float4 {column N - 1, three pad columns}
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W) | reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.R)) & 15) return false;
@@ -871,8 +869,8 @@ static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus
     ga.ntiles_n = cdiv(n, 64); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
     // small problems: 32-row tiles whose four waves split K (tcn_gemm_sk_kernel) while that launch has at most 6 workgroups per CU
     // (B <= 16 at 2 s clips; measured B = 1 ... 32, profiles/r03_fullband.md: full-band stage B = 1 0.47 -> 0.27 ms, B = 4 0.53 -> 0.32,
-    // B = 8 0.56 -> 0.41, B = 16 0.66 -> 0.65, B = 32 0.92 -> 1.05: not there).  FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never
-    static const int sk = [] { const char* e = getenv("FSNP_GEMM_SPLITK"); return e ? atoi(e) : 6; }();
+    // B = 8 0.56 -> 0.41, B = 16 0.66 -> 0.65, B = 32 0.92 -> 1.05: not there)
+    constexpr int sk = 6;
     const int row_tiles32 = cdiv(g.Tp, BMS) * g.B;
     if (allow_splitk && sk && (long)ga.ntiles_n * row_tiles32 * branches <= (long)sk * num_cus && row_tiles == cdiv(g.Tp, BM) * g.B) {
         ga.row_tiles = row_tiles32; ga.row_tiles_all = row_tiles32 * branches;
@@ -888,8 +886,6 @@ static bool launch_gemm_dma(const GemmArgs& g, int n, int row_tiles, int num_cus
 // ceil(blocks / CUs) * BN; pick the BN in {64, 96, 128} that minimises it (ties -> the narrower tile: more,
 // smaller workgroups balance better).  Weights are zero-padded to a multiple of 384 rows so any choice is valid.
 static int pick_bn(int n, int row_tiles, int num_cus, int branches) {
-    static const int forced = [] { const char* e = getenv("FSNP_GEMM_BN"); return e ? atoi(e) : 0; }();   // tuning override
-    if (forced == 64 || forced == 96 || forced == 128) return forced;
     int best = 64;
     long best_cost = -1;
     const int cand[3] = {64, 96, 128};
@@ -911,14 +907,12 @@ static void launch_gemm_pf(const GemmArgs& g, int bn, const dim3& grid, hipStrea
 template <int PRO, int EPI>
 static void launch_gemm(const GemmArgs& g, int n, int row_tiles, int num_cus, hipStream_t s, int branches = 3) {
     // measured (profiles/r02_tcn_gemm.md): the prefetch distance makes no difference (1.99 / 1.90 / 1.93 / 1.93 ms full-band
-    // stage for PF = 1..4): the kernel was never latency-bound.  2 is kept (FSNP_GEMM_PF=1 = the round-1 schedule).
-    static const int pf = [] { const char* e = getenv("FSNP_GEMM_PF"); const int v = e ? atoi(e) : 0; return v == 1 ? 1 : 2; }();
+    // stage for PF = 1..4): the kernel was never latency-bound.  2 is kept.
     const int bn = pick_bn(n, row_tiles, num_cus, branches);
     GemmArgs ga = g;
     ga.ntiles_n = cdiv(n, bn); ga.row_tiles = row_tiles; ga.row_tiles_all = row_tiles * branches;
     const dim3 grid(xcd_grid(ga.ntiles_n, ga.row_tiles_all));
-    if (pf == 1) launch_gemm_pf<PRO, EPI, 1>(ga, bn, grid, s);
-    else launch_gemm_pf<PRO, EPI, 2>(ga, bn, grid, s);
+    launch_gemm_pf<PRO, EPI, 2>(ga, bn, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -591,17 +591,11 @@ class _HipModel(nn.Module):
         lib = self._ensure_handle(_resolve_device(device))
         _lib.check(lib.fsnp_debug_set_gemm_dma(self._handle, int(mode)), "fsnp_debug_set_gemm_dma")
 
-    def debug_set_graph(self, mode, device="cuda"):
-        """Tuning hook: 1 / 2 = replay the full-band stages from a hipGraph, 0 = launch kernel by kernel (default)."""
-        lib = self._ensure_handle(_resolve_device(device))
-        _lib.check(lib.fsnp_debug_set_graph(self._handle, int(mode)), "fsnp_debug_set_graph")
-
     def set_precision(self, mode, device="cuda"):
-        """"fp32" (default), "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16) or "bf16x3"
-        (optional: every fp32 product of the one-tile-per-CU LSTM kernel emulated by three bf16 MFMAs, fsnp.h)."""
-        assert mode in ("fp32", "bf16_ih", "bf16x3")
+        """"fp32" (default) or "bf16_ih" (BASELINE.json configs[4]: layer-1 ih-GEMM of the sub-band LSTM in bf16; fsnp.h)."""
+        assert mode in ("fp32", "bf16_ih")
         lib = self._ensure_handle(_resolve_device(device))
-        _lib.check(lib.fsnp_set_precision(self._handle, {"fp32": 0, "bf16_ih": 1, "bf16x3": 2}[mode]), "fsnp_set_precision")
+        _lib.check(lib.fsnp_set_precision(self._handle, {"fp32": 0, "bf16_ih": 1}[mode]), "fsnp_set_precision")
 
     def debug_set_chaos(self, seed, device="cuda"):
         """Test hook: drift injection for the column-split recurrent kernels (fsnp_debug_set_chaos); 0 = off."""
@@ -642,7 +636,7 @@ class _HipModel(nn.Module):
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
                  12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)",
                  13: "lstm2_coopw_kernel (a wave owns 8 / 16 units over the whole K, layer-skewed, no workgroup barrier)"}
-        prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM", 2: "f32 emulated by split bf16"}
+        prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM"}
         return [{"kernel": names[buf[7 * i]], "sequences": buf[7 * i + 1], "tiles": buf[7 * i + 2], "valu_rows": buf[7 * i + 3],
                  "precision": prec[buf[7 * i + 4]], "workgroups": buf[7 * i + 5], "deferred_when_pipelined": bool(buf[7 * i + 6])} for i in range(n)]
 

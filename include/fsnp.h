@@ -221,7 +221,7 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
  * planner's decision: only launches that leave at least 32 CUs free are deferred (a remainder that fills the chip would only slow
  * the stages it shares it with: B = 40, B = 21); precision = the arithmetic of
  * THAT launch under the handle's fsnp_set_precision mode: 0 = fp32, 1 = fp32 with the layer-1 ih-GEMM in bf16 (BASELINE
- * configs[4]), 2 = fp32 emulated by split bf16.  The bf16 variants exist for the one-tile-per-CU LSTM kernel only: the
+ * configs[4]).  The bf16 variant exists for the one-tile-per-CU and the half-tile LSTM kernels only: the
  * sequences a plan hands to any other kernel (small batches, the remainder of a chip-filling batch) run in fp32. */
 int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The planner's per-step cost table (microseconds), which it minimises when it cuts the sub-band sequences into launches:
@@ -284,12 +284,6 @@ int fsnp_debug_lstm_profile(fsnp_handle* h, const float* x, float* out, int32_t 
  * mode vs the fp32 reference: 2.5e-3 rel on the recurrent model, 6e-3 on the whole forward at B = 32 (measured 1.2e-3 /
  * 4.9e-3; tests/test_gpu_parity.py::test_bf16_ih_variant, ::test_bf16_ih_forward_b32).  Sub-band inputs of <= 40 features only. */
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
-/* ih_bf16 = 2: OPTIONAL, not a BASELINE.json configuration and never the headline: the one-tile-per-CU LSTM kernel with
- * every fp32 product emulated by three bf16 MFMAs on operands split into hi + lo bf16 parts (csrc/lstm_bf3.hip: 16
- * significant bits per operand, fp32 accumulation, the lo x lo term dropped; column-split chunks stay fp32).  The only way
- * past the 157 TFLOP/s fp32 matrix roof; error vs the fp32 path and speed: tests/test_gpu_parity.py::test_bf16x3_variant,
- * profiles/r02_bf16x3.md. */
-
 /* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
  * inter-workgroup wait in a column-split LSTM kernel, whose workgroups must all be co-resident).  0 = none.
  * The error word is host-mapped: without calling this, the NEXT fsnp_forward on the handle fails instead (once) as soon
@@ -319,8 +313,8 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable);
  * tensors in place afterwards (PyTorch: `p.data.add_()`, `init.normal_(m.weight.data)` as the reference's own BaseModel.weight_init does,
  * audio_zen/model/base_model.py:339-355, EMA / weight averaging) changes no pointer and no version counter.  Register the n SOURCE
  * tensors (device pointers of fp32 data, numels[i] elements each; they must stay valid until the next fsnp_watch_weights / fsnp_destroy)
- * right after fsnp_commit_weights: every `every`-th forward then starts with ONE fingerprint kernel over them (~35 MB for the default
- * model: ~10 us) and flags the handle when they no longer match the pack - fsnp_poll_errors / fsnp_check_errors / the next call return 6
+ * right after fsnp_commit_weights: every `every`-th forward then fingerprints them (35 MB for the default model) inside its prologue
+ * launch - 8 us more on that launch, which zeroes the accumulators and describes the sub-band rows anyway - and flags the handle when they no longer match the pack - fsnp_poll_errors / fsnp_check_errors / the next call return 6
  * with an explanatory message (the forwards since the edit ran on the old weights: re-pack and register again).  n = 0 unregisters.
  *
  * fsnp_set_verify: the column-split recurrent kernels (small batches, remainder tiles) exchange h between workgroups through global
@@ -354,11 +348,6 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but t
  * workgroup barrier in the k-loop (FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never) and the sconv GEMMs of larger problems
  * on the 64-row kernel (FSNP_GEMM_BM64=0: never); mode 2 = as 1 but never the split-K kernel; mode 3 = the 128-row DMA kernel only. */
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
-/* Tuning hook: 0 (default) = plain launches; 1 / 2 (env FSNP_GRAPH=1|2) = the ~75 workspace-only launches between the
- * input repack and the sub-band model of a FullSubNet+ forward are captured once per (shape, mode, plan) into a hipGraph
- * and replayed on a private stream ordered by events (1) or straight into the caller's stream (2).  Off by default:
- * bit-identical, but no faster - the chain is bound by kernel latency, not by launch overhead. */
-int fsnp_debug_set_graph(fsnp_handle* h, int32_t mode);
 /* Test hook: sets the device error word as a timed-out inter-workgroup wait would (the next fsnp_forward /
  * fsnp_check_errors on the handle must then fail, once). */
 int fsnp_debug_inject_error(fsnp_handle* h);

@@ -101,6 +101,42 @@ def test_fullsubnet_batch_vs_oracle(batch):
         assert np.abs(par[r] - full[s][:, p:256:2, :]).max() <= 1e-6 * np.abs(full).max()
 
 
+@pytest.mark.parametrize("batch,seconds", [(1, 2.0), (2, 0.7), (3, 1.0), (4, 0.5), (1, 30.0)])
+def test_fullsubnet_small_batches_run_the_full_band_lstm_on_the_valu(batch, seconds):
+    """csrc/lstm_fbv.hip (round 5): with 1 ... 4 utterances the full-band LSTM(257 -> 512 x 2) of fullsubnet.py:39-47 is a matrix-VECTOR
+    product per step - 64 workgroups x 8 units, weights resident, plain FMAs, one hand-off per step - instead of 32-row MFMA tiles with
+    one live row.  Against the oracle, against the K-split kernel it replaces (debug mode 2 keeps that one), bitwise repeatable, under
+    drift injection; 1 ... 4 rows (NB = 1, 2, 4 instantiations, a padded row at B = 3) and a 30 s clip (1,877 steps)."""
+    sd = make_state_dict_fullsubnet(14, "harsh")
+    mag = make_inputs(batch, seconds, 60 + batch)[0]
+    m = _model(dict(FULLSUBNET_MODEL_ARGS), sd, "full")
+    x = _cuda(mag)
+    out = m(x)
+    m.check_errors()
+    assert torch.equal(m(x), out)
+    T = mag.shape[-1]
+    fb_valu = m.read_stage("fb_mag", batch, T).numpy()
+    for seed in (3, 99):
+        m.debug_set_chaos(seed)
+        assert torch.equal(m(x), out), seed
+    m.debug_set_chaos(0)
+    m.debug_set_lstm_coop(2)                       # the round-4 kernels: K-split full-band LSTM, serial schedules
+    ref = m(x)
+    m.check_errors()
+    fb_mfma = m.read_stage("fb_mag", batch, T).numpy()
+    m.debug_set_lstm_coop(1)
+    assert rel_err(fb_valu, fb_mfma) < 1e-5 and not np.array_equal(fb_valu, fb_mfma)      # (another kernel really ran)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    if seconds <= 2.0:
+        kw = {k: FULLSUBNET_MODEL_ARGS[k] for k in ("look_ahead", "sb_num_neighbors", "fb_num_neighbors", "norm_type",
+                                                    "num_groups_in_drop_band", "fb_output_activate_function",
+                                                    "sb_output_activate_function")}
+        want = fsnp_torch.forward_fullsubnet_full(sd, mag, **kw).numpy()
+        err = rel_err(out.cpu().numpy(), want)
+        _record(f"fullsubnet_valu_b{batch}", rel=err, fb_valu_vs_mfma=rel_err(fb_valu, fb_mfma))
+        assert err < TOL, err
+
+
 def test_fullsubnet_enhance_epilogue():
     sd = make_state_dict_fullsubnet(12, "default")
     mag, real, imag = make_inputs(2, 1.0, 32)

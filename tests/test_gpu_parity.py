@@ -62,7 +62,7 @@ def test_lstm2_fc_dense_vs_oracle(profile, n, steps):
     """Fused LSTM kernel alone on dense inputs (ragged tile counts) vs torch.lstm + linear.  ("harsh", 96, 260): cell states
     reach |c| ~ 40-60 - the packed cell update (lstm_common.h) forms sigmoid * tanh with ONE reciprocal of the product of
     both denominators, which must not overflow next to a saturated tanh (a clamp at 2^126 instead of 2^64 returned h = 0
-    there: caught at B = 32 x 2 s by test_bf16x3_forward_b32, now pinned here)."""
+    there: caught at B = 32 x 2 s in round 2, now pinned here)."""
     sd = make_state_dict(3, profile)
     m = _model(DEFAULT_MODEL_ARGS, sd)
     m.debug_set_lstm_coop(0)
@@ -132,14 +132,14 @@ def test_layer_skewed_k_split_equals_serial_schedule(n, steps, seq):
     rng = np.random.Generator(np.random.PCG64(321 + n))
     x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32)).cuda()
     m.lstm2_fc(x[:1])
-    m.debug_set_costs(None, 1)                # both runs on the same (round-1) plan
-    m.debug_set_lstm_coop(2)
     m.debug_set_costs(None, 1)
+    ksplit_only = m.planner_costs_raw()[:19]  # both runs on the same plan: the built-in table minus the half-tile ping-pong kernel and the
+    m.debug_set_lstm_coop(2)                  # wave-owned split, which sum K in another order
+    m.debug_set_costs(ksplit_only, 1)
     serial = m.lstm2_fc(x).cpu().numpy()
     m.check_errors()
     m.debug_set_lstm_coop(1)
-    m.debug_set_costs(None, 1)
-    m.debug_set_costs(m.planner_costs_raw()[:19], 1)      # (built-in table minus the half-tile ping-pong kernel and the wave-owned split, which sum K in another order)
+    m.debug_set_costs(ksplit_only, 1)
     assert all(c["kernel"].startswith("lstm2_coop_kernel") for c in m.describe_plan(1))
     skew = m.lstm2_fc(x).cpu().numpy()       # (the skewed schedule is used from 16 units per workgroup up: n >= 257 here)
     m.check_errors()
@@ -622,42 +622,6 @@ def test_bf16_ih_forward_parity_mode_b32_and_b16():
         assert e_ref < TOL and 1e-6 < rel_err(got, ref) and e_bf < 6e-3, (e_ref, e_bf)
 
 
-@pytest.mark.parametrize("n,steps", [(70, 24), (700, 40), (8192, 24)])
-def test_bf16x3_variant(n, steps):
-    """Optional precision mode 2 (csrc/lstm_bf3.hip, fsnp.h: fsnp_set_precision): every fp32 product of the one-tile-per-CU
-    LSTM kernel emulated by three bf16 MFMAs on operands split into hi + lo bf16 parts (16 significant bits, fp32
-    accumulation).  Not fp32-exact, but two orders of magnitude inside the 1e-3 bar: asserted < 1e-4 vs the fp32 oracle."""
-    sd = make_state_dict(10, "default")
-    m = _model(DEFAULT_MODEL_ARGS, sd)
-    m.debug_set_lstm_coop(0)
-    rng = np.random.Generator(np.random.PCG64(66 + n))
-    x = torch.from_numpy(rng.standard_normal((n, 34, steps)).astype(np.float32))
-    want = fsnp_torch.lstm2_fc(x, sd).numpy()
-    m.set_precision("bf16x3")
-    got = m.lstm2_fc(x.cuda()).cpu().numpy()
-    assert np.array_equal(m.lstm2_fc(x.cuda()).cpu().numpy(), got)
-    m.set_precision("fp32")
-    got32 = m.lstm2_fc(x.cuda()).cpu().numpy()
-    err = rel_err(got, want)
-    _record(f"bf16x3_{n}x{steps}", rel_bf16x3=err, rel_fp32=rel_err(got32, want))
-    assert rel_err(got32, want) < 2e-5
-    assert 1e-9 < rel_err(got, got32) and err < 1e-4, err
-
-
-def test_bf16x3_forward_b32():
-    sd = make_state_dict(0, "default")
-    mag, real, imag = make_inputs(32, 2.0, 100)
-    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
-    ins = _cuda((mag, real, imag))
-    ref = m(*ins).cpu().numpy()
-    m.set_precision("bf16x3")
-    got = m(*ins).cpu().numpy()
-    m.set_precision("fp32")
-    err = rel_err(got, ref)
-    _record("bf16x3_forward_b32_vs_fp32_hip", rel=err)
-    assert 1e-9 < err < 2e-4, err
-
-
 def test_batch2_raises_like_reference():
     g = Golden("b4_t16_default")
     m = _model(g.args, g.state_dict(), "parity")
@@ -1043,24 +1007,18 @@ def test_host_time_per_forward_b1():
     for _ in range(3):
         m(*ins)
     torch.cuda.synchronize()
-    res = {}
-    for graph in (0, 1):
-        m.debug_set_graph(graph)
-        for _ in range(2):
-            m(*ins)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(8):                               # 8 forwards stay far below the HIP queue depth: pure host time
-            m(*ins)
-        host = (time.perf_counter() - t0) / 8
-        torch.cuda.synchronize()
-        dev = (time.perf_counter() - t0) / 8
-        res[graph] = (host, dev)
-    m.debug_set_graph(0)
+    for _ in range(2):
+        m(*ins)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):                                   # 8 forwards stay far below the HIP queue depth: pure host time
+        m(*ins)
+    host = (time.perf_counter() - t0) / 8
+    torch.cuda.synchronize()
+    dev = (time.perf_counter() - t0) / 8
     m.check_errors()
-    _record("host_time_per_forward_b1", host_us_plain=res[0][0] * 1e6, device_us_plain=res[0][1] * 1e6,
-            host_us_graph=res[1][0] * 1e6, device_us_graph=res[1][1] * 1e6)
-    assert res[0][0] < 0.5 * res[0][1], res            # the host runs well ahead of the device
+    _record("host_time_per_forward_b1", host_us_plain=host * 1e6, device_us_plain=dev * 1e6)
+    assert host < 0.5 * dev, (host, dev)                 # the host runs well ahead of the device
 
 
 def test_pipelined_enhance_paths_equal_the_plain_ones():
@@ -1112,37 +1070,6 @@ def test_forward_on_side_stream_and_second_handle():
     assert np.array_equal(m3(*ins).cpu().numpy(), ref)
 
 
-def test_graph_replay_equals_plain_launches():
-    """The hipGraph replay of the full-band stages (fsnp_abi.hip run_graphed) is bit-identical to kernel-by-kernel
-    launches, survives shape changes (new graphs), workspace growth and weight re-packing (graphs dropped)."""
-    g = Golden("b1_t24_default_stages")
-    m = _model(g.args, g.state_dict(), "full")
-    ins = _cuda(g.inputs())
-    m.debug_set_graph(0)
-    plain = m(*ins).cpu().numpy()
-    m.debug_set_graph(1)
-    first = m(*ins).cpu().numpy()                      # captures
-    second = m(*ins).cpu().numpy()                     # replays
-    assert np.array_equal(plain, first) and np.array_equal(plain, second)
-    big = _cuda(make_spec(4, 40, 5))                   # other shape + workspace growth
-    b1 = m(*big).cpu().numpy()
-    m.debug_set_graph(0)
-    assert np.array_equal(m(*big).cpu().numpy(), b1)
-    m.debug_set_graph(1)
-    assert np.array_equal(m(*ins).cpu().numpy(), plain)    # back to the first shape (re-captured after the growth)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        on_side = m(*ins)
-    side.synchronize()
-    assert np.array_equal(on_side.cpu().numpy(), plain)
-    m.load_state_dict(make_state_dict(5, "harsh"), strict=True)
-    changed = m(*ins).cpu().numpy()
-    m.debug_set_graph(0)
-    assert np.array_equal(m(*ins).cpu().numpy(), changed) and not np.array_equal(changed, plain)
-
-
-# ---------------------------------------------------------------- SURVEY.md 8(f-4): sub-band TCN (sequence_model.py:47-58)
 def test_subband_tcn_b32_full_vs_oracle():
     """sequence_model="TCN": 8 TCNBlocks(34 -> 512 -> 34) + Linear(34, 2) over all 8224 sub-band sequences."""
     args = {**DEFAULT_MODEL_ARGS, "sequence_model": "TCN"}

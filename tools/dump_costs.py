@@ -25,7 +25,7 @@ for seq in ("LSTM", "GRU"):
     c = m.planner_costs()
     c["measured"] = m.measure_costs()
     c["first_forward_s"] = time.perf_counter() - t0
-    c["plans"] = {b: [f'{k["kernel"].split(" ")[0]} x{k["sequences"]}' for k in m.describe_plan(b)] for b in (1, 2, 3, 5, 8, 12, 16, 21, 32, 40)}
+    c["plans"] = {b: [f'{k["kernel"].split(" ")[0]} x{k["sequences"]}' for k in m.describe_plan(b)] for b in (1, 2, 3, 4, 5, 8, 12, 16, 21, 32, 40)}
     c["plan_parity_b32"] = [f'{k["kernel"].split(" ")[0]} x{k["sequences"]}' for k in m.describe_plan(32, parity=True)]
     print(seq, json.dumps(c, indent=1))
     with open(os.path.join(ROOT, "gpurun_out", f"planner_costs_{seq}.json"), "w") as f:
