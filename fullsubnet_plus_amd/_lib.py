@@ -82,6 +82,7 @@ SYMBOLS = {
     "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coop_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coopw_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_debug_lstm_fbv_pack": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_last_error": (ctypes.c_char_p, []),
     "fsnp_version": (ctypes.c_char_p, []),
 }

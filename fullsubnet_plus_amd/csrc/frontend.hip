@@ -235,24 +235,24 @@ struct GateArgs {
                                // sums.  -1: cumulative norms - md and fsum (of the normalised input) were produced by fe_scan / fe_fsum
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // one workgroup per (branch, utt).  The (kmax-1) first and last normalised frames are staged in LDS so that every
 // thread's prefix / suffix sums come from shared memory instead of 2*(kmax-1) dependent global round trips.
-__global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
+// Round 5: 1024 threads - the kernel is a chain of latency-bound phases on ONE workgroup per (branch, utt) (28 us whatever the
+// batch), so every phase is cut into as many independent items as the workgroup has threads: the squeeze per (conv, bin), fc1 and fc2
+// per (K slice, output).
+constexpr int kGateThreads = 1024;
+__global__ __launch_bounds__(kGateThreads) void fe_gate_kernel(GateArgs g) {
+    constexpr int NTHR = kGateThreads;
     extern __shared__ float sh[];
     const int F = g.F, Tp = g.Tp, Fr = F / 2, FP = g.FP;
     constexpr int MAXK = 16;
     float* sq = sh;                    // [FP]  squeeze
     float* hid = sh + FP;              // [FP]  (F/2 used)
     float* edge = sh + 2 * FP;         // [2][MAXK][FP] normalised first / last frames
+    float* feat3 = sh + (2 + 2 * MAXK) * FP;   // [3][FP] TSSE: the three conv branches' pooled features
     const int branch = blockIdx.y, b = blockIdx.x;
     const long ub = (long)branch * g.B + b;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int kmax = max(max(g.w.ksize[0], g.w.ksize[1]), g.w.ksize[2]);
 
     const int att = g.w.attention;
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     NormMD mu{0.0f, 1.0f};
     if (offline) {
         mu = norm_md(g.offline_norm, g.tot[ub * 2], g.tot[ub * 2 + 1], (double)F * Tp);
-        for (int t = tid; t < Tp; t += 256) g.md[ub * Tp + t] = mu;
+        for (int t = tid; t < Tp; t += NTHR) g.md[ub * Tp + t] = mu;
     }
     if (att == FSNP_ATT_TSSE) {
-        for (int i = tid; i < 2 * (kmax - 1) * F; i += 256) {
+        for (int i = tid; i < 2 * (kmax - 1) * F; i += NTHR) {
             const int side = i / ((kmax - 1) * F), r = (i / F) % (kmax - 1), f = i % F;
             const int t = side == 0 ? r : Tp - 1 - r;                    // r-th frame from the start / from the end
             const NormMD m = offline ? mu : g.md[ub * Tp + t];
@@ -274,12 +274,14 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         }
         __syncthreads();
     }
-    for (int f = tid; f < F; f += 256) {
-        // sum over t of the normalised input: sum_t (x - m) / d = (column sum - T' m) / d for the offline norms
-        const double S = offline ? (g.fsum[ub * FP + f] - (double)Tp * (double)mu.m) / (double)mu.d : g.fsum[ub * FP + f];
-        if (att != FSNP_ATT_TSSE) {
+    // sum over t of the normalised input: sum_t (x - m) / d = (column sum - T' m) / d for the offline norms
+    auto total_of = [&](int f) -> double {
+        return offline ? (g.fsum[ub * FP + f] - (double)Tp * (double)mu.m) / (double)mu.d : g.fsum[ub * FP + f];
+    };
+    if (att != FSNP_ATT_TSSE) {
+        for (int f = tid; f < F; f += NTHR) {
             // SE / ECA / CBAM squeeze = mean over time (attention_model.py:31, :349, :320)
-            sq[f] = (float)(S / (double)Tp);
+            sq[f] = (float)(total_of(f) / (double)Tp);
             if (att == FSNP_ATT_CBAM) {                      // + max over time (attention_model.py:321)
                 float mx = -3.4e38f;
                 for (int t = 0; t < Tp; ++t) {
@@ -288,12 +290,13 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
                 }
                 sqmax[f] = mx;
             }
-            continue;
         }
-        const float* first = edge + f;                       // first[r * FP] = r-th normalised frame
-        const float* last = edge + (long)MAXK * FP + f;      // last[r * FP]  = r-th frame from the end
-        float squeeze = g.w.cat_b[branch][0];
-        for (int c = 0; c < 3; ++c) {
+    } else {
+        for (int item = tid; item < 3 * F; item += NTHR) {   // one (conv branch, bin) per thread
+            const int c = item / F, f = item - c * F;
+            const double S = total_of(f);
+            const float* first = edge + f;                   // first[r * FP] = r-th normalised frame
+            const float* last = edge + (long)MAXK * FP + f;  // last[r * FP]  = r-th frame from the end
             const int K = g.w.ksize[c];
             const float* wk = g.w.conv_w[branch][c] + (long)f * K;
             // tap j sees frames [j, j + T' - K]: everything but the first j and the last K-1-j frames
@@ -303,11 +306,15 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
                 acc += (double)wk[j] * (S - pj - sj);
                 if (j + 1 < K) { pj += (double)first[j * FP]; sj -= (double)last[(K - 2 - j) * FP]; }
             }
-            float feat = (float)(acc / (double)(Tp - K + 1)) + g.w.conv_b[branch][c][f];
-            feat = fmaxf(feat, 0.f);
-            squeeze += g.w.cat_w[branch][c] * feat;
+            const float feat = (float)(acc / (double)(Tp - K + 1)) + g.w.conv_b[branch][c][f];
+            feat3[c * FP + f] = fmaxf(feat, 0.f);
         }
-        sq[f] = squeeze;
+        __syncthreads();
+        for (int f = tid; f < F; f += NTHR) {
+            float squeeze = g.w.cat_b[branch][0];
+            for (int c = 0; c < 3; ++c) squeeze += g.w.cat_w[branch][c] * feat3[c * FP + f];
+            sq[f] = squeeze;
+        }
     }
     __syncthreads();
     if (att == FSNP_ATT_ECA && branch == 0 && g.w.subband_num > 1) {
@@ -317,13 +324,13 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         // of channel f / sn, whose squeeze is the mean over the sn rows sn c .. sn c + sn - 1 (row F + k = row F - 2 - k).
         const int sn = g.w.subband_num, pad = sn - F % sn, C = (F + pad) / sn;
         const float w0 = g.w.cat_w[0][0], w1 = g.w.cat_w[0][1], w2 = g.w.cat_w[0][2];
-        for (int c = tid; c < C; c += 256) {
+        for (int c = tid; c < C; c += NTHR) {
             float m = 0.f;
             for (int r = 0; r < sn; ++r) { const int row = sn * c + r; m += sq[row < F ? row : 2 * (F - 1) - row]; }
             hid[c] = m / (float)sn;
         }
         __syncthreads();
-        for (int o = tid; o < F; o += 256) {
+        for (int o = tid; o < F; o += NTHR) {
             const int c = o / sn;
             const float y = w0 * (c > 0 ? hid[c - 1] : 0.f) + w1 * hid[c] + w2 * (c + 1 < C ? hid[c + 1] : 0.f);
             g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-y));
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     if (att == FSNP_ATT_ECA) {
         // Conv1d(1, 1, 3, padding=1, bias=False) ALONG THE CHANNEL AXIS of the pooled vector, then sigmoid
         const float w0 = g.w.cat_w[branch][0], w1 = g.w.cat_w[branch][1], w2 = g.w.cat_w[branch][2];
-        for (int o = tid; o < F; o += 256) {
+        for (int o = tid; o < F; o += NTHR) {
             const float y = w0 * (o > 0 ? sq[o - 1] : 0.f) + w1 * sq[o] + w2 * (o + 1 < F ? sq[o + 1] : 0.f);
             g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-y));
         }
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     }
     // fc1 + ReLU, fc2 + sigmoid over TRANSPOSED weights (coalesced, independent loads; a wave-per-output dot product is a chain of
     // dependent L2 round trips here: measured 120 us).  Round 3: the kernel is latency-bound (one workgroup per utterance and
-    // branch), so every thread works - fc1's K is cut into 256 / (F / 2) slices per output - and every chain keeps 16 loads in
-    // flight on 4 independent accumulators (31.8 -> ~10 us at B = 32).
+    // branch), so every thread works - fc1's K is cut into NTHR / (F / 2) slices per output, fc2's into NTHR / F - and every chain
+    // keeps 16 loads in flight on 4 independent accumulators.
     auto dot = [&](const float* wT, long stride, const float* x, int k0, int k1) -> float {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int k = k0;
@@ -361,18 +368,18 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
     // [slices][Fr] partial sums in `edge` (the staged edge frames are no longer needed; CBAM keeps its max vector in edge[0, FP): its
     // partials sit behind it).  part2 follows part's ns1 * Fr floats (a fixed + 256 aliased them from num_freqs = 514 up); the
     // slice count is capped so that FP + 2 ns1 Fr floats always fit edge's 32 FP (tiny num_freqs)
-    const int ns1 = Fr >= 256 ? 1 : min(256 / Fr, (31 * FP) / (2 * Fr)), chunk = cdiv(F, ns1);
+    const int ns1 = Fr >= NTHR ? 1 : min(NTHR / Fr, (31 * FP) / (2 * Fr)), chunk = cdiv(F, ns1);
     float* part = att == FSNP_ATT_CBAM ? edge + FP : edge;
     float* part2 = part + ns1 * Fr;
     __syncthreads();                                         // every thread is done with `edge`
-    for (int item = tid; item < Fr * ns1; item += 256) {
+    for (int item = tid; item < Fr * ns1; item += NTHR) {
         const int o = item % Fr, sl = item / Fr;
         const int k0 = sl * chunk, k1 = min(F, k0 + chunk);
         part[sl * Fr + o] = dot(g.w.fc1_wT[branch] + o, Fr, sq, k0, k1);
         if (att == FSNP_ATT_CBAM) part2[sl * Fr + o] = dot(g.w.fc1_wT[branch] + o, Fr, sqmax, k0, k1);
     }
     __syncthreads();
-    for (int o = tid; o < Fr; o += 256) {
+    for (int o = tid; o < Fr; o += NTHR) {
         float acc = g.w.fc1_b[branch][o];
         for (int sl = 0; sl < ns1; ++sl) acc += part[sl * Fr + o];
         float h = fmaxf(acc, 0.f);
@@ -384,16 +391,20 @@ __global__ __launch_bounds__(256) void fe_gate_kernel(GateArgs g) {
         hid[o] = h;
     }
     __syncthreads();
-    const int Fmain = F / 256 * 256;                         // outputs in whole passes of the workgroup: one chain each ...
-    for (int o = tid; o < Fmain; o += 256) {
-        const float acc = g.w.fc2_b[branch][o] + dot(g.w.fc2_wT[branch] + o, F, hid, 0, Fr);
-        g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
+    // fc2: K = F / 2 cut into ns2 slices per output ([ns2][F] partials over the fc1 partials, which hid has consumed), then bias +
+    // sigmoid per output
+    const int ns2 = F >= NTHR ? 1 : max(1, min(min(NTHR / F, (30 * FP) / F), Fr / 16)), chunk2 = cdiv(Fr, ns2);
+    float* part3 = edge + FP;
+    for (int item = tid; item < F * ns2; item += NTHR) {
+        const int sl = item / F, o = item - sl * F;
+        const int k0 = sl * chunk2, k1 = min(Fr, k0 + chunk2);
+        part3[sl * F + o] = dot(g.w.fc2_wT[branch] + o, F, hid, k0, k1);
     }
-    for (int o = Fmain + wave; o < F; o += 4) {              // ... the few left over (F = 257: one): a wave each, K across the lanes
-        float acc = 0.f;
-        for (int k = lane; k < Fr; k += 64) acc += g.w.fc2_wT[branch][(long)k * F + o] * hid[k];
-        acc = wave_sum_f(acc) + g.w.fc2_b[branch][o];
-        if (lane == 0) g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
+    __syncthreads();
+    for (int o = tid; o < F; o += NTHR) {
+        float acc = g.w.fc2_b[branch][o];
+        for (int sl = 0; sl < ns2; ++sl) acc += part3[sl * F + o];
+        g.gate[ub * FP + o] = 1.0f / (1.0f + expf(-acc));
     }
 }
 
@@ -476,11 +487,11 @@ void launch_frontend(const Dims& d, int norm_type, const float* const in[3], con
     g.w = w; g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.tot = buf.tot; g.gate = buf.gate;
     g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
     g.offline_norm = offline ? norm_type : -1;
-    // 34 FP floats of dynamic LDS: beyond 64 KiB (num_freqs > 480) the kernel needs the opt-in; beyond a CU's LDS the launch fails
+    // 37 FP floats of dynamic LDS: beyond 64 KiB (num_freqs > 440) the kernel needs the opt-in; beyond a CU's LDS the launch fails
     // loudly (hipGetLastError in fsnp_forward)
     static PerDeviceOnce gate_once;
     gate_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fe_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
-    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(256), (size_t)(2 + 2 * 16) * d.FP * sizeof(float), s, g);
+    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 3), dim3(kGateThreads), (size_t)(2 + 2 * 16 + 3) * d.FP * sizeof(float), s, g);
     const long rows = 3L * d.B * d.Tp;
     const long total = rows * d.FP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

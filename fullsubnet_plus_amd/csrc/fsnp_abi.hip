@@ -1531,6 +1531,18 @@ int fsnp_debug_lstm_coopw_pack(int32_t hidden, int32_t input_size, int32_t kx, c
     return 0;
 }
 
+int fsnp_debug_lstm_fbv_pack(int32_t hidden, int32_t input_size, const float* wih0, const float* whh0, const float* wih1, const float* whh1,
+                             float* out, int64_t out_floats) {
+    if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_fbv_pack: null argument"); return 1; }
+    if (hidden != 512 || input_size < 1 || input_size > 288) { set_error("fsnp_debug_lstm_fbv_pack: hidden 512, <= 288 inputs"); return 2; }
+    if ((int64_t)lstm_fbv_pack_floats(hidden) != out_floats) {
+        set_error("fsnp_debug_lstm_fbv_pack: need %lld floats", (long long)lstm_fbv_pack_floats(hidden));
+        return 2;
+    }
+    lstm_fbv_pack_weights(hidden, input_size, wih0, whh0, wih1, whh1, out);
+    return 0;
+}
+
 double fsnp_lstm_flops(const fsnp_handle* h, int64_t num_seq, int32_t steps) {
     if (!h) return 0;
     return (double)num_seq * steps * lstm_flops_per_step(h);

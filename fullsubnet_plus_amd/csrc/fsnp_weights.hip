@@ -156,7 +156,10 @@ int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_
     FSNP_HIP_CHECK(hipMalloc(&h->watch_segs, segs.size() * sizeof(WatchSeg)));
     FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->watch_acc), (8 + kWatchBlocks) * 8));     // {-, tickets, baseline, -, ...; a partial sum per block}
     FSNP_HIP_CHECK(hipMemcpy(h->watch_segs, segs.data(), segs.size() * sizeof(WatchSeg), hipMemcpyHostToDevice));
-    FSNP_HIP_CHECK(hipMemset(h->watch_acc, 0, (8 + kWatchBlocks) * 8));
+    // (on the CALLER's stream, like the baseline kernel behind it: a null-stream hipMemset of device memory returns before it has run
+    // and does not order with a non-blocking stream - on torch side streams it zeroed the tickets / the baseline under the running
+    // baseline kernel now and then: a false "stale weights" flag, profiles/r05_pytest_gpu_runA.log)
+    FSNP_HIP_CHECK(hipMemsetAsync(h->watch_acc, 0, (8 + kWatchBlocks) * 8, static_cast<hipStream_t>(hip_stream)));
     h->watch_nseg = (int)segs.size();
     return launch_weight_watch(h, static_cast<hipStream_t>(hip_stream), true);
 }

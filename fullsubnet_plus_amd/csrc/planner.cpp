@@ -96,7 +96,11 @@ double est_step_us(const PlannerCtx& h, const SbChunk& c) {
     // (bf16 ih-GEMM mode: the half-tile kernel streams 12 bf16 k-steps instead of 48 fp32 k-groups for layer 1's ih product - measured
     //  11.42 vs 14.16 ms at 4096 sequences, profiles/r04_bf16_half_tile_bench.jsonl: the fp32 entry scaled by that ratio)
     if (c.kind == 4) return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile16 * (h.ih_bf16 == 1 ? 0.81 : 1.0);
-    return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile * (1.0 + h.cost.rowtile_ex * c.ex);
+    // (the same for the one-tile-per-CU LSTM kernel: 155 us per round against 206 in fp32 - BASELINE configs[4], 20.9 vs 27.5 ms at
+    //  B = 32, profiles/r04_bench_configs.md.  Without this the cheaper column-split kernels of round 5 made the planner leave the
+    //  bf16 kernel for a half-tile round + three wave-owned launches at the fp32 kernel's price: 27.6 ms, profiles/r05_bench_configs.md)
+    const double bf = (h.ih_bf16 == 1 && !h.gru) ? 0.755 : 1.0;
+    return cdiv(c.num_tiles, h.num_cus) * h.cost.rowtile * bf * (1.0 + h.cost.rowtile_ex * c.ex);
 }
 static SbChunk rowtile_chunk(const PlannerCtx& h, int row0, int nrows) {
     if (h.gru || h.H != 384) return SbChunk{0, row0, nrows, cdiv(nrows, 32), 0, 32, 0, 0, 0, 0, 0};   // VALU rows: LSTM at H = 384 only

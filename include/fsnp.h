@@ -384,6 +384,13 @@ int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, in
 int fsnp_debug_lstm_coopw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
                                const float* whh1, float* out, int64_t out_floats);
 
+/* Same for the matrix-vector full-band kernel of the original FullSubNet (csrc/lstm_fbv.hip; hidden 512, <= 288 inputs):
+ * [column slice of 8 units][fragment j4 < 57][thread (c = tid & 31: gate c & 3 of unit c >> 2; ks = tid >> 5: k slice)][4] -
+ * fragments 0 .. 24 = layer 0 over [x (288, zero padded) | h0], k = 100 ks + 4 j4 + e; fragments 25 .. 56 = layer 1 over [h0 | h1],
+ * k = 128 ks + 4 (j4 - 25) + e; hidden / 8 * 57 * 1024 floats. */
+int fsnp_debug_lstm_fbv_pack(int32_t hidden, int32_t input_size, const float* wih0, const float* whh0, const float* wih1, const float* whh1,
+                             float* out, int64_t out_floats);
+
 const char* fsnp_last_error(void);
 const char* fsnp_version(void);
 /* Binding sanity: FSNP_ABI_VERSION of the header the library was built from and sizeof(fsnp_config) as it sees it; a

@@ -102,8 +102,8 @@ def test_bench_under_torchrun_initialises_rccl_at_world_size_1():
 
 @pytest.mark.parametrize("mode", ["full", "parity"])
 def test_forward_sharded_over_rccl_world_size_1(mode, tmp_path):
-    """forward_sharded(gather=True) on the nccl (= RCCL) backend: all_gather_into_tensor in "full" mode, the all_reduce that
-    merges the zero-initialised global tensor in "parity" mode - bit-identical to the plain forward (one rank = the same plan)."""
+    """forward_sharded(gather=True) on the nccl (= RCCL) backend: all_gather_into_tensor in "full" mode, the all_gather of row
+    blocks + index scatter in "parity" mode - bit-identical to the plain forward (one rank = the same plan)."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

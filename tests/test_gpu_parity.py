@@ -571,6 +571,10 @@ def test_bf16_ih_forward_b32():
             rel_vs_fp64_max=max(e64.values()), plan=[c["kernel"] + f" x{c['sequences']}" for c in m.describe_plan(32)])
     assert 1e-6 < err < 6e-3, err            # must differ from fp32 (the mode is really on)
     assert max(e32.values()) < 6e-3 and max(e64.values()) < 6e-3, (e32, e64)
+    # the plan keeps the chip-filling chunk on the one-tile-per-CU kernel (whose bf16 round is 0.75 of its fp32 round): a planner that
+    # prices it at the fp32 cost trades it for half-tile + column-split launches (27.6 instead of 20.9 ms: profiles/r05_bench_configs.md)
+    plan = m.describe_plan(32)
+    assert plan[0]["sequences"] == 8192 and "one 32-" in plan[0]["kernel"] and "bf16" in plan[0]["precision"], plan
 
 
 @pytest.mark.parametrize("n", [4096, 4000, 4112])
@@ -953,6 +957,35 @@ def test_weight_update_repacks_device_weights():
     m.check_errors()
 
 
+def test_weight_watch_registered_on_a_side_stream_raises_no_false_alarm():
+    """The watch's baseline fingerprint is taken on the CALLER's stream.  Round 5's first version zeroed its accumulators with a
+    null-stream hipMemset, which does not order with torch's non-blocking side streams: now and then the tickets / the baseline were
+    zeroed under the running baseline kernel and every later forward reported "weights modified" (seen once in the evidence run of
+    874326c, test_forward_on_side_stream_and_second_handle).  Here: 24 registrations on a side stream that is kept busy, each followed
+    by forwards that must neither flag nor re-pack, with a real .data edit in between to show the watch is alive."""
+    g = Golden("b3_t20_harsh")
+    m = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    ref = m(*ins).cpu().numpy()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    busy = torch.empty(64 << 20, device="cuda")
+    m.error_check = "deferred"                              # ("sync" would hide a false alarm behind its re-pack + re-run)
+    with torch.cuda.stream(side):
+        for i in range(24):
+            busy.add_(1.0)                                  # work in front of the registration on the side stream
+            m.refresh_weights()
+            for _ in range(2):
+                out = m(*ins)
+                m.check_errors()                            # raises on "weights modified"
+                assert np.array_equal(out.cpu().numpy(), ref), i
+        m.error_check = "sync"
+        m.sb_model.fc_output_layer.bias.data.add_(0.25)
+        out = m(*ins).cpu().numpy()
+    assert abs(float((out - ref).mean()) - 0.25) < 1e-4
+    m.check_errors()
+
+
 def _sleep_cycles_for(seconds):
     """torch.cuda._sleep counts device clock ticks: calibrate them against the wall clock once."""
     torch.cuda.synchronize()
@@ -1306,7 +1339,7 @@ def test_enhance_wave_vs_oracle():
 def test_sharded_parity_mode_on_one_gpu(b32, splits):
     """Multi-GPU plumbing on the real kernels: a shard passes (batch_offset, global_batch) and writes only its rows of
     the GLOBAL drop_band output (frequency parity and row order follow the global sample index, feature.py:254-285);
-    the shards' outputs sum to the unsharded call (what dist.forward_sharded's all_reduce does)."""
+    the shards' outputs sum to the unsharded call (what dist.forward_sharded's gather of row blocks assembles)."""
     sd, (mag, real, imag), m, _ = b32
     m.batch_mode = "parity"
     ins = _cuda((mag, real, imag))

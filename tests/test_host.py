@@ -789,6 +789,38 @@ def test_column_split_kernels_keep_their_asm_invariants():
         assert r["sc1_loads"] > 0 and r["sc1_stores"] > 0, (name, r)
 
 
+def test_full_band_matrix_vector_kernel_weight_layout():
+    """csrc/lstm_fbv.hip (original FullSubNet, <= 4 utterances), restated on the CPU: thread (c, ks) of column slice cs holds gate c & 3
+    of unit 8 cs + (c >> 2) over k slice ks - 100 weights of layer 0 over [x (288, zero padded) | h0] and 128 of layer 1 over
+    [h0 | h1].  Emulating the kernel's sums on the packer's output (eight k slices per column, then the cell's four gates) reproduces
+    W_ih x + W_hh h for both layers, for num_freqs 257 and 161; the vector layout [x | h0 | h1] makes layer 1's k range contiguous."""
+    import ctypes as ct
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(11))
+    H, XP, K0, K1 = 512, 288, 100, 128
+    assert XP + H == 8 * K0 and 2 * H == 8 * K1
+    vp = lambda a: a.ctypes.data_as(ct.c_void_p)
+    for NIN in (257, 161):
+        wih0, whh0 = rng.standard_normal((4 * H, NIN)).astype(np.float32), rng.standard_normal((4 * H, H)).astype(np.float32)
+        wih1, whh1 = rng.standard_normal((4 * H, H)).astype(np.float32), rng.standard_normal((4 * H, H)).astype(np.float32)
+        out = np.zeros(H // 8 * (K0 + K1) * 256, dtype=np.float32)
+        assert lib.fsnp_debug_lstm_fbv_pack(H, NIN, vp(wih0), vp(whh0), vp(wih1), vp(whh1), vp(out), out.size) == 0, lib.fsnp_last_error()
+        assert lib.fsnp_debug_lstm_fbv_pack(H, NIN, vp(wih0), vp(whh0), vp(wih1), vp(whh1), vp(out), out.size - 4) == 2
+        pack = out.reshape(H // 8, (K0 + K1) // 4, 256, 4).astype(np.float64)
+        x, h0, h1 = (rng.standard_normal(n).astype(np.float32).astype(np.float64) for n in (NIN, H, H))
+        V = np.concatenate([x, np.zeros(XP - NIN), h0, h1])                    # the kernel's LDS row: [x | h0 | h1]
+        want0 = wih0.astype(np.float64) @ x + whh0.astype(np.float64) @ h0
+        want1 = wih1.astype(np.float64) @ h0 + whh1.astype(np.float64) @ h1
+        for cs in (0, 13, H // 8 - 1):
+            w = pack[cs].transpose(1, 0, 2).reshape(256, K0 + K1)              # [tid][j]
+            for c in range(32):
+                a0 = sum(w[ks * 32 + c, :K0] @ V[K0 * ks:K0 * ks + K0] for ks in range(8))
+                a1 = sum(w[ks * 32 + c, K0:] @ V[XP + K1 * ks:XP + K1 * ks + K1] for ks in range(8))
+                row = (c & 3) * H + 8 * cs + (c >> 2)
+                assert abs(a0 - want0[row]) < 1e-9 * (1 + abs(a0)) and abs(a1 - want1[row]) < 1e-9 * (1 + abs(a1))
+    assert lib.fsnp_debug_lstm_fbv_pack(384, 257, vp(wih0), vp(whh0), vp(wih1), vp(whh1), vp(out), out.size) == 2
+
+
 def test_wave_owned_column_split_index_maps_and_asm():
     """csrc/lstm_coopw.hip restated on the CPU.  (1) The packed stream: participant `part` of an NT-tile split multiplies 8-unit
     blocks part * NT + n of every k-group; column c of a block = gate c & 3 of unit c >> 2; the B operand of MFMA p of k-group g in

@@ -1,25 +1,18 @@
 #!/bin/bash
+# scratch: quick checks between evidence runs
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-{
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --tb=short -p no:cacheprovider -k "weight_update" 2>&1 | tail -3
-cd /tmp
-rm -rf $R/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --gpus 1 --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-alt --pipeline 0 > $R/gpurun_out/prof_b1.log 2>&1
-f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/kernel_stats_dev_b1.csv
-python - <<PY
-import csv
-rows=list(csv.DictReader(open("$R/gpurun_out/kernel_stats_dev_b1.csv")))
-for r in rows[:16]:
-    print("%-70s calls %5s avg %8.1f ns total %10.0f" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), float(r["TotalDurationNs"])))
-PY
-rm -rf $R/gpurun_out/prof
-cd $R
-for args in "--batch 1" "--batch 2"; do
-  timeout 400 python bench.py $args --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+ls -la _refstage 2>&1 | head -5
+ls _refstage/reference 2>&1 | head -3
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "side_stream or weight_update or golden or bf16_ih_forward_b32 or attention or cbam or subband_num or stages or c_abi or plain_c" 2>&1 | tail -8 | tee gpurun_out/dev_pytest.log
+for args in "--batch 1" "--batch 32" "--precision bf16_ih"; do
+  timeout 300 python bench.py $args --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
-r=json.loads(sys.stdin.read()); print(r['config']['workload'][:24], 'ms %.3f b2b %.3f dropin %.3f subband %.3f fullband %.3f alt %.3f' % (r['ms_per_step'], r['alt_ms_per_step'], r['dropin_ms_per_step'], r['roofline']['subband_stage_ms'], r['roofline']['fullband_ms'], r['roofline']['alt_fullband_ms']))"
+r=json.loads(sys.stdin.read()); print(r['config']['workload'][:40], r['ms_per_step'], r['alt_ms_per_step'], r.get('dropin_ms_per_step'), r['roofline']['fullband_ms'], r['roofline'].get('alt_fullband_ms'), [c['kernel'].split(' ')[0]+' x%d'%c['sequences'] for c in r['roofline']['subband_plan']])" | tee -a gpurun_out/dev_bench.log
 done
-} 2>&1 | tee gpurun_out/dev.log
+cd /tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --no-cpu-baseline --no-alt --batch 1 --steps 10 --warmup 2 --pipeline 0 > /dev/null 2>&1
+f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -22 "$f" | cut -c1-150 | tee $GRAFT_REPO_ROOT/gpurun_out/dev_stats_b1.csv
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof

@@ -8,6 +8,7 @@
 #   5. the whole GPU suite again (run B): two green runs on one HEAD
 # The pytest logs carry the commit and a digest of the kernel sources at start and end of each run.  Everything -> gpurun_out/.
 set -u
+REF=${1:-}          # (saved: the column-split timing loop below re-uses the positional parameters)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,7 +16,7 @@ digest() { cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fulls
 suite() {   # $1 = log name
   {
     echo "commit: ${FSNP_HEAD:-unknown}   csrc sha256[:16] at start: $(digest)   library stamp: $(cut -c1-16 fullsubnet_plus_amd/libfsnp_hip.so.stamp)   $(date -u +%FT%TZ)"
-    timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=8 2>&1 | tail -30
+    timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=25 2>&1 | tail -50
     echo "csrc sha256[:16] at end: $(digest)"
   } | tee gpurun_out/$1
 }
@@ -121,8 +122,8 @@ try:
 except Exception as e:
     print("bench_rccl_n1 ??", e)
 PY
-if [ $# -ge 1 ] && [ -d "$1" ]; then
-  timeout 900 python tools/cli_e2e.py "$1" 2>&1 | tail -15 | tee gpurun_out/cli_e2e_stdout.log
+if [ -n "$REF" ] && [ -d "$REF" ]; then
+  timeout 900 python tools/cli_e2e.py "$REF" 2>&1 | tail -15 | tee gpurun_out/cli_e2e_stdout.log
 fi
 suite pytest_gpu_runB.log
 head -16 gpurun_out/kernel_stats.csv | cut -c1-170

@@ -23,11 +23,11 @@ out = [f"# {TAG} - bench.py on one MI355X: every configuration measured at the e
        "`back to back` = `alt_ms_per_step` (forwards strictly serialised, `error_check=\"deferred\"`), `drop-in` = `dropin_ms_per_step` (the module's",
        "default `error_check=\"sync\"`: every forward waits for its launches - what editing the one TOML line gives).  Plans: built-in cost table.", "",
        "| configuration | frames/s | ms/step | back to back | drop-in | plan of the sub-band model |", "|---|---|---|---|---|---|",
-       "| **headline** `--gpus 1 --steps 20 --warmup 5`: batch 32 × 2 s, full mode | **%.0f** | **%.3f** | %.3f | %DROPIN% | %s; dominant kernel %.2f ms = %.3f of "
+       "| **headline** `--gpus 1 --steps 20 --warmup 5`: batch 32 × 2 s, full mode | **%.0f** | **%.3f** | %.3f | @DROPIN@ | %s; dominant kernel %.2f ms = %.3f of "
        "the fp32 MFMA peak; cpu_baseline (port, %d threads) %.0f frames/s; cIRM rel err vs oracle (%d utterances of the timed batch) %.1e |"
        % (h["value"], h["ms_per_step"], h["alt_ms_per_step"], hp, h["roofline"]["avg_launch_ms"], h["roofline"]["frac"],
           h["cpu_baseline"]["cores"], h["cpu_baseline"]["value"], len(h.get("cirm_checked_utterances", [])), h["cirm_rel_err"])]
-out[-1] = out[-1].replace("%DROPIN%", "%.3f" % h["dropin_ms_per_step"] if h.get("dropin_ms_per_step") else "-")
+out[-1] = out[-1].replace("@DROPIN@", "%.3f" % h["dropin_ms_per_step"] if h.get("dropin_ms_per_step") else "-")
 for m, a, v, ms, alt, dt, plan, dropin in rows:
     a = a.replace(" clips per GPU", "").replace(", random-init weights (seed 0)", "").replace(", num_neighbors=15", "")
     out.append("| %s: %s%s | %.0f | %.3f | %s | %s | %s |" % (m, a, "" if dt == "f32" else " **[" + dt + "]**", v, ms, "%.3f" % alt if alt else "-", "%.3f" % dropin if dropin else "-", plan))
