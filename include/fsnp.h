@@ -314,7 +314,7 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable);
  * audio_zen/model/base_model.py:339-355, EMA / weight averaging) changes no pointer and no version counter.  Register the n SOURCE
  * tensors (device pointers of fp32 data, numels[i] elements each; they must stay valid until the next fsnp_watch_weights / fsnp_destroy)
  * right after fsnp_commit_weights: every `every`-th forward then fingerprints them (35 MB for the default model) inside its prologue
- * launch - 8 us more on that launch, which zeroes the accumulators and describes the sub-band rows anyway - and flags the handle when they no longer match the pack - fsnp_poll_errors / fsnp_check_errors / the next call return 6
+ * launch - 9 us more on that launch, which zeroes the accumulators and describes the sub-band rows anyway - and flags the handle when they no longer match the pack - fsnp_poll_errors / fsnp_check_errors / the next call return 6
  * with an explanatory message (the forwards since the edit ran on the old weights: re-pack and register again).  n = 0 unregisters.
  *
  * fsnp_set_verify: the column-split recurrent kernels (small batches, remainder tiles) exchange h between workgroups through global

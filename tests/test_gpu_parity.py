@@ -1169,8 +1169,9 @@ def test_sync_error_policy_reruns_on_the_row_tile_kernel():
     m.poll_errors()
 
 
-@pytest.mark.parametrize("batch,kernel", [(1, "lstm2_coop_hp_kernel"), (2, "lstm2_coopw_kernel"), (8, "lstm2_coopw_kernel")])
-def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel):
+@pytest.mark.parametrize("batch,kernel,round4", [(1, "lstm2_coop_hp_kernel", False), (2, "lstm2_coopw_kernel", False), (8, "lstm2_coopw_kernel", False),
+                                                 (3, "lstm2_coop_kernel", True), (8, "lstm2_coopn_kernel", True)])
+def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel, round4):
     """the column-split kernels' hand-off can only detect a TIME-OUT; a stale or corrupted exchange image would give a
     silently wrong mask.  fsnp_set_verify (model.verify_every = N): every Nth forward whose plan holds a column-split launch runs
     those sequences again on the one-tile-per-CU kernel (no exchange) and compares on the device.  fsnp_debug_corrupt_exchange makes
@@ -1180,8 +1181,11 @@ def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel):
     sd = make_state_dict(0, "default")
     m = _model(DEFAULT_MODEL_ARGS, sd, "full")
     ins = _cuda(make_inputs(batch, 0.6, 40 + batch))
+    if round4:                                                           # the K split / the three-way split lead the plan again
+        m(*ins)
+        m.debug_set_costs(m.planner_costs_raw()[:21], 1)
     plain = m(*ins).cpu().numpy()
-    assert any(c["kernel"].startswith(kernel) for c in m.describe_plan(batch)), m.describe_plan(batch)
+    assert m.describe_plan(batch)[0]["kernel"].startswith(kernel), m.describe_plan(batch)
     m.verify_every = 1
     assert np.array_equal(m(*ins).cpu().numpy(), plain) and m.verify_count() == 1
     m.verify_every = 3                                                   # every third forward
