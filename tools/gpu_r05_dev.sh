@@ -1,23 +1,13 @@
 #!/bin/bash
-# scratch: prologue launch with and without the weight watch (B = 1 and B = 32)
+# scratch: the extended verification test, a verification soak over the default plans, the whole suite once more (run C)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-cat > /tmp/watch_cost.py <<'PY'
-import sys, torch
-from fullsubnet_plus_amd import FullSubNet_Plus
-from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_inputs, make_state_dict
-B, every = int(sys.argv[1]), int(sys.argv[2])
-m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS); m.load_state_dict(make_state_dict(0, "default")); m = m.cuda().eval(); m.batch_mode = "full"; m.error_check = "deferred"
-m.weight_watch_every = every
-ins = [t.cuda() for t in make_inputs(B, 2.0, 5)]
-for _ in range(12): m(*ins)
-torch.cuda.synchronize(); m.check_errors()
-PY
-cd /tmp
-for B in 1 32; do for every in 1 1000000; do
-  rm -rf /tmp/prof
-  PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof -o trace -- python /tmp/watch_cost.py $B $every > /dev/null 2>&1
-  f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
-  echo "B=$B weight_watch_every=$every: $(grep prologue_kernel $f | cut -d, -f2-4)" | tee -a $GRAFT_REPO_ROOT/gpurun_out/watch_cost.txt
-done; done
+digest() { cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h | sha256sum | cut -c1-16; }
+timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "exchange_verification" 2>&1 | tail -5 | tee gpurun_out/dev_pytest.log
+timeout 900 python tools/verify_soak.py 25 2>&1 | grep -v amdgpu.ids | tail -20
+{
+  echo "commit: ${FSNP_HEAD:-unknown}   csrc sha256[:16] at start: $(digest)   library stamp: $(cut -c1-16 fullsubnet_plus_amd/libfsnp_hip.so.stamp)   $(date -u +%FT%TZ)"
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=5 2>&1 | tail -20
+  echo "csrc sha256[:16] at end: $(digest)"
+} | tee gpurun_out/pytest_gpu_runC.log

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Exchange verification as a detector over many forwards: for each batch size run N forwards of fresh random inputs with
+verify_every = 4 - every fourth forward's sub-band stage is recomputed on the exchange-free row-tile kernel and compared on the device -
+and count verification passes and flags.  Usage: python tools/verify_soak.py [seconds_per_batch]   -> gpurun_out/verify_soak.txt"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fullsubnet_plus_amd import FullSubNet_Plus                                     # noqa: E402
+from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_inputs, make_state_dict   # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+lines = []
+for B, secs in ((1, 2.0), (2, 2.0), (3, 0.6), (5, 2.0), (8, 2.0), (12, 1.0), (21, 2.0), (32, 2.0), (3, 126.0)):
+    m = FullSubNet_Plus(**DEFAULT_MODEL_ARGS)
+    m.load_state_dict(make_state_dict(0, "default"))
+    m = m.cuda().eval()
+    m.batch_mode = "full"
+    m.error_check = "deferred"
+    m.verify_every = 4
+    sets = [[t.cuda() for t in make_inputs(B, secs, 1000 + 17 * B + i)] for i in range(4)]
+    plan = " + ".join(c["kernel"].split(" ")[0] + " x%d" % c["sequences"] for c in m.describe_plan(B))
+    n, flags, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        for ins in sets:
+            m(*ins)
+            n += 1
+        torch.cuda.synchronize()
+        try:
+            m.check_errors()
+        except RuntimeError as e:
+            flags += 1
+            lines.append("  FLAG at forward ~%d: %s" % (n, str(e)[:300]))
+    line = "B=%d x %.1f s: %d forwards, %d verified against the row-tile kernel, %d flags   [%s]" % (B, secs, n, m.verify_count(), flags, plan)
+    print(line, flush=True)
+    lines.append(line)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "verify_soak.txt"), "w") as f:
+    f.write("\n".join(lines) + "\n")
