@@ -345,8 +345,8 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but t
  * 0 = the general tcn_gemm_kernel everywhere (also FSNP_GEMM_DMA=0 at fsnp_create time).  Both meet the same tolerance;
  * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it).  Small batches (at most 6 workgroups per CU
  * on 32-row tiles: B <= 16 at 2 s clips) run the same GEMMs on tcn_gemm_sk_kernel - 32 x 64 tiles whose four waves split K, no
- * workgroup barrier in the k-loop (FSNP_GEMM_SPLITK=<workgroups per CU>, 0 = never) and the sconv GEMMs of larger problems
- * on the 64-row kernel (FSNP_GEMM_BM64=0: never); mode 2 = as 1 but never the split-K kernel; mode 3 = the 128-row DMA kernel only. */
+ * workgroup barrier in the k-loop - and the sconv GEMMs of larger problems on the 64-row kernel; mode 2 = as 1 but never the
+ * split-K kernel; mode 3 = the 128-row DMA kernel only (the environment switches that used to select these were removed in ABI 9). */
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
 /* Test hook: sets the device error word as a timed-out inter-workgroup wait would (the next fsnp_forward /
  * fsnp_check_errors on the handle must then fail, once). */
@@ -359,8 +359,7 @@ int fsnp_debug_inject_error(fsnp_handle* h);
 int fsnp_debug_set_chaos(fsnp_handle* h, int32_t seed);
 
 /* Tuning hook: waves per workgroup of the fused LSTM kernel: 12 (three per SIMD), 4 (one per SIMD) or
- * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4); also settable with the
- * environment variable FSNP_LSTM_WAVES at fsnp_create time. */
+ * 0 = automatic (default: 12 when the tile plan carries VALU rows, else 4). */
 int fsnp_debug_set_lstm_waves(fsnp_handle* h, int32_t waves);
 
 /* Test hook: pretend the device has `num_cus` compute units when planning the LSTM tiles (a tile =
