@@ -628,20 +628,34 @@ static bool plan_has_exchange(const SbPlan& plan) {
 static int verify_pass(fsnp_handle* h, const SbPlan& plan, const Dims& d, int mode, int batch_offset, int global_batch, const LstmArgs& a,
                        const SubbandBuffers& sbuf, size_t out_elems, hipStream_t s) {
     const bool cumulative = h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAPLACE || h->cfg.norm_type == FSNP_NORM_CUMULATIVE_LAYER;
-    // the exchange-free plan of exactly the column-split chunks' sequences
+    // the exchange-free plan of exactly the column-split chunks' sequences; consecutive chunks (B = 8: three launches over rows
+    // [0, 2056)) are re-run as ONE range - one round of half tiles instead of one per launch
     SbPlan vp;
-    for (const SbChunk& c : plan.chunks) {
-        if (!(c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9)) continue;
-        PlannerCtx pc = pctx(h);
-        pc.lstm_coop = 0;
-        const SbPlan one = plan_sb(pc, c.nrows);
+    PlannerCtx pc = pctx(h);
+    pc.lstm_coop = 0;
+    pc.half_tiles_without_coop = true;
+    pc.ih_bf16 = 0;                          // (the re-run is fp32 whatever fsnp_set_precision says: below)
+    bool bad = false;
+    int run0 = 0, run_n = 0;
+    auto flush = [&]() {
+        if (run_n == 0) return;
+        const SbPlan one = plan_sb(pc, run_n);
         for (SbChunk k : one.chunks) {
-            if (k.kind != 0 && k.kind != 4) { set_error("fsnp_set_verify: no exchange-free kernel for this model"); return 2; }
-            k.row0 += c.row0; k.slot0 = vp.total_slots; k.coop_tile0 = 0;
+            if (k.kind != 0 && k.kind != 4) { bad = true; return; }
+            k.row0 += run0; k.slot0 = vp.total_slots; k.coop_tile0 = 0;
             vp.total_slots += k.num_tiles * k.rps;
             vp.chunks.push_back(k);
         }
+        run_n = 0;
+    };
+    for (const SbChunk& c : plan.chunks) {
+        const bool exch = c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9;
+        if (exch && run_n > 0 && c.row0 == run0 + run_n) { run_n += c.nrows; continue; }
+        flush();
+        if (exch) { run0 = c.row0; run_n = c.nrows; }
     }
+    flush();
+    if (bad) { set_error("fsnp_set_verify: no exchange-free kernel for this model"); return 2; }
     if (vp.chunks.empty()) return 0;
     const size_t out_b = align_up(out_elems * 4, 256), rows_b = align_up((size_t)vp.total_slots * sizeof(RowDesc), 256);
     const size_t md_b = cumulative ? align_up((size_t)vp.total_slots * d.Tp * sizeof(NormMD), 256) : 0;
@@ -663,7 +677,12 @@ static int verify_pass(fsnp_handle* h, const SbPlan& plan, const Dims& d, int mo
     }
     LstmArgs va = a;
     va.rows = vrows; va.md_row = vmd; va.out = reinterpret_cast<float*>(vb);
+    // the column-split kernels are fp32 in every precision mode, so their check is too: under fsnp_set_precision(h, 1) the row-tile /
+    // half-tile kernels would otherwise run their bf16 ih-GEMM here and differ from a CORRECT exchange by ~1e-3 - a false alarm
+    const int keep_bf16 = h->lw.ih_bf16;
+    h->lw.ih_bf16 = 0;
     launch_sb_lstm(h, vp, va, nullptr, nullptr, nullptr, s);
+    h->lw.ih_bf16 = keep_bf16;
     const long n = (long)vp.total_slots * h->cfg.output_size * d.T;
     hipLaunchKernelGGL(verify_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.out, reinterpret_cast<const float*>(vb), vrows,
                        vp.total_slots, d.T, h->cfg.output_size, a.out_stride_o, h->d_err);

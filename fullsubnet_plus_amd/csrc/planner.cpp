@@ -187,7 +187,14 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
     const SbChunk whole = rowtile_chunk(h, 0, num_rows);
     // bf16-ih mode (configs[4]) only changes the row-tile kernel: sequences that run on a column-split kernel (small
     // batches, remainder tiles) stay fp32 - more accurate and, there, faster
-    if (!coop_on) { push(whole); return p; }
+    if (!coop_on) {
+        // (the exchange-free re-run of fsnp_set_verify: up to one round of 16-row half tiles costs half a round of 32-row tiles; plain
+        //  FSNP_LSTM_COOP=0 handles keep the row-tile kernel, whose plans their users and tests know)
+        const SbChunk all16{4, 0, num_rows, cdiv(num_rows, 16), 0, 16, 0, 0, 0, 0, 0};
+        if (h.half_tiles_without_coop && h.lstm16_ok && est_step_us(h, all16) < est_step_us(h, whole)) push(all16);
+        else push(whole);
+        return p;
+    }
     // candidates: everything column-split; one launch of the row-tile kernel (VALU rows / extra rounds as needed); full
     // rounds of the row-tile kernel + the remainder column-split (must be `composite_gain` cheaper than the single launch)
     const int full = h.num_cus * 32, q = num_rows / full, rem = num_rows - q * full;

@@ -47,6 +47,7 @@ struct PlannerCtx {
     int ih_bf16 = 0, lstm_coop = 1, coop_occ = 1;
     int occ_ksplit[4] = {1, 1, 1, 1}, occ_coopn[2] = {1, 1};
     int coop_hp = 0, coop_w = 0, pipeline = 0;
+    bool half_tiles_without_coop = false;   // lstm_coop == 0 plans may still use the (exchange-free) half-tile kernel: fsnp_set_verify's re-run
     double composite_gain = 0.97;
     CostTable cost{};
 };

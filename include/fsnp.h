@@ -319,9 +319,10 @@ int fsnp_set_pipeline(fsnp_handle* h, int32_t enable);
  *
  * fsnp_set_verify: the column-split recurrent kernels (small batches, remainder tiles) exchange h between workgroups through global
  * memory; their hand-off can only detect a TIME-OUT (code 5).  With every = N > 0, every Nth forward whose plan holds such a launch runs
- * the same sequences AGAIN on the one-tile-per-CU kernel (no exchange at all) into a scratch mask and compares on the device
+ * the same sequences AGAIN on a kernel without any exchange (up to 4096 sequences: one round of 16-row half tiles, ~103 us per step;
+ * more: the one-tile-per-CU kernel; always fp32, like the kernels it checks) into a scratch mask and compares on the device
  * (|a - b| <= 1e-4 + 1e-3 |b|); a mismatch flags the handle with code 7 and the first differing (utterance, bin, frame).  Cost: one
- * one-tile-per-CU pass (~208 us per step and round of 256 row tiles) per N forwards - at N = 64 and 2 s clips +0.42 ms per forward.
+ * such round per N forwards - at N = 64 and 2 s clips +0.21 ... +0.26 ms per forward.
  * fsnp_verify_count = verification passes run so far.  0 = off (default; FSNP_VERIFY_EVERY=N at fsnp_create time sets it). */
 int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_t* numels, int32_t n, int32_t every, void* hip_stream);
 int fsnp_set_verify(fsnp_handle* h, int32_t every);

@@ -1210,6 +1210,17 @@ def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel, round
     assert rel_err(fixed, plain) < 1e-5                                  # re-run on the one-tile-per-CU kernel
     m.verify_every = 0
     assert np.array_equal(m(*ins).cpu().numpy(), plain)
+    if not round4:
+        # bf16-ih mode (configs[4]) leaves the column-split kernels in fp32: their check must stay fp32 as well (no false alarm), and
+        # the re-run of <= 4096 sequences is one round of HALF tiles (half the price of a row-tile round)
+        m.set_precision("bf16_ih")
+        m.verify_every = 1
+        m.error_check = "deferred"
+        before = m.verify_count()
+        got = m(*ins)
+        m.check_errors()
+        assert m.verify_count() == before + 1 and np.array_equal(got.cpu().numpy(), plain)
+        m.set_precision("fp32")
 
 
 def test_two_handles_overlapped_on_two_streams():
