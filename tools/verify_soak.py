@@ -37,7 +37,7 @@ for B, secs in ((1, 2.0), (2, 2.0), (3, 0.6), (5, 2.0), (8, 2.0), (12, 1.0), (21
         except RuntimeError as e:
             flags += 1
             lines.append("  FLAG at forward ~%d: %s" % (n, str(e)[:300]))
-    line = "B=%d x %.1f s: %d forwards, %d verified against the row-tile kernel, %d flags   [%s]" % (B, secs, n, m.verify_count(), flags, plan)
+    line = "B=%d x %.1f s: %d forwards, %d verified against the exchange-free kernel, %d flags   [%s]" % (B, secs, n, m.verify_count(), flags, plan)
     print(line, flush=True)
     lines.append(line)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
