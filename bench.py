@@ -62,6 +62,16 @@ def parse():
                          "K forwards are complete (fsnp_flush + synchronize) inside the timed region.  0 = every forward runs "
                          "strictly back to back.  The other mode is timed too and reported as `alt_ms_per_step`")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the other loop mode (profiling runs)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="every timed loop (K steps, barrier + synchronise on both sides) is run this many times; the line reports the "
+                         "MEDIAN run (`ms_per_step`, `value`, `roofline`) and all of them (`ms_per_step_runs`): one 0.6 s region "
+                         "cannot tell a clock ramp or a slow box from a regression (VERDICT r05)")
+    ap.add_argument("--probe-ms", type=float, default=50.0,
+                    help="length of the fp32-MFMA peak probe (fsnp_debug_box_probe) run before and after the timed loops; 0 = off")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: ALSO time BASELINE.json configs[2] as worded - ONE global batch of batch x N utterances lives on rank 0; "
+                         "a step = scatter the STFT shards + forward + gather the masks to rank 0 (reported as `strong`, next to the "
+                         "weak-scaling number, which stays the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -106,6 +116,81 @@ def cpu_baseline(sd, inputs, budget_s, norm, fullsubnet=False):
     return {"value": done * T / dt, "unit": "frames/s", "cores": best_threads, "kind": "port",
             "sample": f"{done} x 1-utterance forwards of the {T}-frame clips (oracle/fsnp_torch.py, "
                       f"torch {torch.__version__} CPU, {best_threads} of {ncpu} host threads), {dt:.1f} s"}, outs
+
+
+def pci_address(dev):
+    """"0000:05:00.0" of a torch device (None when this torch build does not expose it): selects the GPU's sysfs directory."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return "{:04x}:{:02x}:{:02x}.0".format(p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:                                            # noqa: BLE001 - best effort
+        return None
+
+
+def strong_scaling_loop(args, model, dist, dev, rank, world, B, sync_all):
+    """BASELINE.json configs[2] as worded: ONE global batch of B x world utterances, resident on rank 0.  A step =
+    scatter the complex STFT shards (what the reference inferencer holds after torch.stft, inferencer.py:142) -> forward on every
+    rank (fsnp_forward_complex consumes the buffer in place) -> gather the masks on rank 0.  The batch split needs no other
+    collective.  RCCL implements scatter / gather as grouped send / recv over xGMI; on gloo (tests) the shards go through host memory."""
+    from fullsubnet_plus_amd.synthetic import make_wave
+    n_fft, hop = 2 * (model.num_freqs - 1), model.num_freqs - 1
+    via_host = args.dist_backend != "nccl"
+    GB = B * world
+    T = None
+    chunks = None
+    if rank == 0:
+        wav = torch.from_numpy(make_wave(GB, args.seconds, 4242)).to(dev)
+        spec = torch.stft(wav, n_fft, hop, n_fft, window=torch.hann_window(n_fft, device=dev), return_complex=True)   # [GB, F, T], memory [GB][T][F]
+        T = spec.shape[-1]
+        flat = torch.view_as_real(spec.transpose(1, 2).contiguous())       # [GB, T, F, 2] contiguous
+        chunks = [c.cpu() if via_host else c.contiguous() for c in flat.chunk(world, dim=0)]
+    tt = torch.tensor([T or 0], dtype=torch.int64, device="cpu" if via_host else dev)
+    dist.broadcast(tt, 0)
+    T = int(tt.item())
+    cdev = "cpu" if via_host else dev
+    mine = torch.empty((B, T, model.num_freqs, 2), dtype=torch.float32, device=cdev)
+    masks = [torch.empty((B, model.output_size, model.num_freqs, T), dtype=torch.float32, device=cdev) for _ in range(world)] if rank == 0 else None
+    model.set_pipeline(False, dev)
+    t_sc = t_fw = t_ga = 0.0
+
+    def step(timed):
+        nonlocal t_sc, t_fw, t_ga
+        a = time.perf_counter()
+        dist.scatter(mine, chunks if rank == 0 else None, src=0)
+        x = mine.to(dev) if via_host else mine
+        torch.cuda.synchronize(dev)
+        b = time.perf_counter()
+        o = model.forward_complex(torch.view_as_complex(x).transpose(1, 2))           # [B, F, T] view with torch.stft's strides
+        torch.cuda.synchronize(dev)
+        c = time.perf_counter()
+        oc = o.cpu() if via_host else o.contiguous()
+        dist.gather(oc, masks, dst=0)
+        torch.cuda.synchronize(dev)
+        d = time.perf_counter()
+        if timed:
+            t_sc += b - a; t_fw += c - b; t_ga += d - c
+        return o
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            step(False)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        sync_all()
+        dt = time.perf_counter() - t0
+    model.poll_errors()
+    every = [None] * world
+    dist.all_gather_object(every, (dt, t_sc, t_fw, t_ga))
+    slow = max(range(world), key=lambda r: every[r][0])
+    dt = every[slow][0]
+    return {"what": "configs[2] as worded: ONE global batch on rank 0; step = scatter STFT shards + forward + gather masks to rank 0",
+            "global_batch": GB, "ms_per_step": dt / args.steps * 1e3, "value": GB * T * args.steps / dt, "unit": "frames/s",
+            "scaling": "strong in the data placement (one source rank), weak in the work per GPU (batch x N)",
+            "scatter_ms": every[0][1] / args.steps * 1e3, "forward_ms_slowest_rank": max(e[2] for e in every) / args.steps * 1e3,
+            "gather_ms": every[0][3] / args.steps * 1e3, "via_host_memory": via_host,
+            "bytes_scattered_per_step": GB * T * model.num_freqs * 8, "bytes_gathered_per_step": GB * model.output_size * model.num_freqs * T * 4}
 
 
 def self_launch(args):
@@ -223,22 +308,49 @@ def main():
             model.poll_errors()                                  # a column-split launch that gave up would have flagged the handle
             return dt, tm, o
 
+        from fullsubnet_plus_amd import box as box_mod
+        stream_ptr = torch.cuda.current_stream(dev).cuda_stream
+        sysfs_dir = box_mod.sysfs_device(pci_address(dev))
+        idle_state = box_mod.read_sysfs(sysfs_dir)
+        # what this box's matrix pipes hold, right before the timed loops (the first forward above has woken the clocks)
+        probe_before = box_mod.probe(args.probe_ms, stream_ptr) if args.probe_ms > 0 else None
+        sampler = box_mod.Sampler(sysfs_dir) if sysfs_dir else None
+        if sampler:
+            sampler.start()
+
+        def timed_runs(pipeline):
+            """args.repeats x timed_loop -> (elapsed of the MEDIAN run, its timing, its last output, [ms per step of every run], [dominant-kernel ms of every run])"""
+            runs = [timed_loop(pipeline) for _ in range(max(args.repeats, 1))]
+            order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+            med = runs[order[len(order) // 2]]
+            return (med[0], med[1], runs[-1][2], [r[0] / args.steps * 1e3 for r in runs],
+                    [r[1]["lstm_first_chunk_ms"] / max(r[1]["count"], 1) for r in runs])
+
         pipelined = bool(args.pipeline) and not args.wave
-        alt_elapsed, alt_timing, _ = timed_loop(not pipelined) if not (args.wave or args.no_alt) else (None, None, None)
+        alt_elapsed, alt_timing, _, alt_runs, _ = timed_runs(not pipelined) if not (args.wave or args.no_alt) else (None, None, None, None, None)
         # the drop-in default: what a maintainer who edits the one TOML line gets - error_check="sync" (every forward waits for its
         # own launches and polls the error word before it returns), no pipelined loop
-        dropin_elapsed = None
+        dropin_elapsed, dropin_runs = None, None
         if not (args.wave or args.no_alt) and world == 1:
             model.error_check = "sync"
-            dropin_elapsed, _, _ = timed_loop(False)
+            dropin_elapsed, _, _, dropin_runs, _ = timed_runs(False)
             model.error_check = "deferred"
-        elapsed, timing, out = timed_loop(pipelined)
+        elapsed, timing, out, main_runs, launch_runs = timed_runs(pipelined)
+        launch_clock = model.launch_clock()                     # the clocks of the LAST dominant-kernel launch (None: no such launch)
+        sampled = sampler.stop() if sampler else {"samples": 0, "note": "no readable /sys/class/drm/card*/device for this GPU"}
+        probe_after = box_mod.probe(args.probe_ms, stream_ptr) if args.probe_ms > 0 else None
+
+        strong = None
+        if args.strong and dist is not None and not args.wave and not fsn:
+            strong = strong_scaling_loop(args, model, dist, dev, rank, world, B, sync_all)
 
     rank_ms = None
     if dist is not None:
         cnt = max(timing["count"], 1)
         mine = torch.tensor([elapsed, timing["lstm_ms"] / cnt, timing["lstm_first_chunk_ms"] / cnt, timing["fullband_ms"] / cnt,
-                             timing["forward_ms"] / cnt], dtype=torch.float64, device=dev)
+                             timing["forward_ms"] / cnt, probe_before["mfma_tflops"] if probe_before else 0.0,
+                             probe_after["mfma_tflops"] if probe_after else 0.0, probe_after["clock_mhz"] if probe_after else 0.0],
+                            dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         rank_ms = [float(t[0].item()) / args.steps * 1e3 for t in every]
@@ -247,6 +359,8 @@ def main():
         # ... and the roofline block below describes THAT rank's kernels (the N > 1 line carries the slowest rank's roofline)
         timing = {"count": 1, "lstm_ms": float(every[slow][1]), "lstm_first_chunk_ms": float(every[slow][2]),
                   "fullband_ms": float(every[slow][3]), "forward_ms": float(every[slow][4])}
+        rank_probe = [{"rank": r, "mfma_tflops_before": float(every[r][5]), "mfma_tflops_after": float(every[r][6]),
+                       "clock_mhz_after": float(every[r][7]), "ms_per_step": rank_ms[r]} for r in range(world)]
         # batch-split plumbing: gather every rank's masks once (outside the timed region)
         g0 = time.perf_counter()
         gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=dev)
@@ -254,7 +368,7 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - g0) * 1e3
     else:
-        gather_ms = None
+        gather_ms, rank_probe = None, None
 
     frames_total = world * B * T * args.steps
     value = frames_total / elapsed
@@ -272,6 +386,8 @@ def main():
     stage_achieved = stage_flops / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
 
     lstm_kernel_name = plan[0]["kernel"]
+    probes = [p for p in (probe_before, probe_after) if p]
+    box_peak = min(p["mfma_tflops"] for p in probes) if probes else None
     traffic = None   # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes
     pmc_path = os.path.join(ROOT, "profiles", "lstm_pmc.json")
     if os.path.exists(pmc_path) and B == 32 and abs(args.seconds - 2.0) < 1e-9 and args.mode == "full":
@@ -283,6 +399,8 @@ def main():
                   (" waveform -> waveform (HIP STFT + forward + cIRM + iSTFT)" if args.wave else " forward"),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # every timed loop runs --repeats times (each: K steps between barrier + synchronise); the headline is the MEDIAN run
+        "ms_per_step_runs": main_runs, "alt_ms_per_step_runs": alt_runs, "dropin_ms_per_step_runs": dropin_runs,
         "alt_ms_per_step": None if alt_elapsed is None else alt_elapsed / args.steps * 1e3,
         # the drop-in default (error_check="sync", no pipelined loop): one TOML line edited, nothing else
         "dropin_ms_per_step": None if dropin_elapsed is None else dropin_elapsed / args.steps * 1e3,
@@ -306,7 +424,12 @@ def main():
                      "traffic": traffic,
                      "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of every round by "
                                        "tools/gpu_r05_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
-                     "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms,
+                     # the same rate against what THIS box's matrix pipes held in a pure-MFMA probe right before / after the loops
+                     # (box.mfma_peak_tflops: the lower of the two) - a slow box shows as frac < frac_of_box_peak, a slow kernel in both
+                     "frac_of_box_peak": (achieved / box_peak) if box_peak else None,
+                     "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms, "avg_launch_ms_runs": launch_runs,
+                     # workgroup 0 of the last dominant launch: its wall time by the 100 MHz clock and the rate of s_memtime over it
+                     "last_launch_clock": launch_clock,
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
                      # the same stage in the OTHER loop (in the serving loop it runs beside the previous forward's remainder
@@ -314,13 +437,25 @@ def main():
                      "alt_fullband_ms": None if alt_timing is None else alt_timing["fullband_ms"] / max(alt_timing["count"], 1),
                      "forward_ms": timing["forward_ms"] / max(timing["count"], 1)},
     }
+    result["box"] = {
+        "mfma_peak_tflops": box_peak, "spec_peak_tflops": PEAK_FP32_MFMA_TFLOPS,
+        "probe": "fsnp_debug_box_probe: v_mfma_f32_32x32x2_f32 only, one wave per SIMD on every CU, %g ms, random operands; run right "
+                 "before and right after the timed loops" % args.probe_ms,
+        "probe_before": probe_before, "probe_after": probe_after,
+        "idle_before": idle_state, "during_timed_loops": sampled,
+        "hostname": socket.gethostname(), "gpu": torch.cuda.get_device_name(dev),
+    }
+    if rank_probe is not None:
+        result["box"]["per_rank"] = rank_probe
+    if strong is not None:
+        result["strong"] = strong
     if gather_ms is not None:
         result["gather_ms"] = gather_ms
         result["dist"] = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""),
                           "world_size_seen": dist.get_world_size(), "same_device": bool(args.same_device),
                           "gathered_shape": list(gathered.shape),
                           "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}, "roofline_of_rank": slow}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:           # (rank 0 only; at N > 1 the other ranks wait in destroy_process_group)
         base, ref_outs = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
         ref_path = os.path.join(ROOT, "profiles", "r05_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
         if not os.path.exists(ref_path):
@@ -341,8 +476,11 @@ def main():
             result["cirm_checked_utterances"] = sorted(errs)
             result["cirm_worst_utterance"] = max(errs, key=lambda i: errs[i][0] / errs[i][1])
     if rank == 0:
+        from fullsubnet_plus_amd import box as box_mod2
+        result["box"]["rocm_smi_after"] = box_mod2.smi_snapshot()
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()                       # (rank 0 ran the CPU baseline meanwhile)
         dist.destroy_process_group()
 
 

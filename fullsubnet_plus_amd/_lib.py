@@ -1,4 +1,4 @@
-"""ctypes binding of include/fsnp.h (cffi is not installed in this image; ctypes is stdlib)."""
+"""ctypes binding of include/fsnp.h + include/fsnp_debug.h (cffi is not installed in this image; ctypes is stdlib)."""
 import ctypes
 import os
 
@@ -26,8 +26,9 @@ SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1, "TCN": 2}
 MODE_FULL, MODE_PARITY = 0, 1
 NUM_COSTS = 25           # FSNP_NUM_COSTS: values of the planner's flat cost table (fsnp_get_costs)
 MODEL_FULLSUBNET_PLUS, MODEL_FULLSUBNET = 0, 1
+BOX_PROBE_VALUES = 9     # FSNP_BOX_PROBE_VALUES (include/fsnp_debug.h)
 
-# every symbol include/fsnp.h declares: name -> (restype, argtypes)
+# every symbol include/fsnp.h and include/fsnp_debug.h declare: name -> (restype, argtypes)
 SYMBOLS = {
     "fsnp_create": (c_i32, [ctypes.POINTER(FsnpConfig), ctypes.POINTER(c_vp)]),
     "fsnp_destroy": (None, [c_vp]),
@@ -83,11 +84,13 @@ SYMBOLS = {
     "fsnp_debug_lstm_coop_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coopw_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_fbv_pack": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_debug_box_probe": (c_i32, [ctypes.c_double, ctypes.POINTER(ctypes.c_double * BOX_PROBE_VALUES), c_vp]),
+    "fsnp_debug_launch_clock": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 4)]),
     "fsnp_last_error": (ctypes.c_char_p, []),
     "fsnp_version": (ctypes.c_char_p, []),
 }
 
-ABI_VERSION = 9          # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
+ABI_VERSION = 10         # FSNP_ABI_VERSION of the include/fsnp.h these signatures were written against
 
 _lib = None
 

@@ -38,27 +38,45 @@ using namespace fsnp;
 namespace fsnp {
 
 // Decodes and clears the host-mapped error word that finished launches set (fsnp_handle.h: kErr*).  0 = clean.
+// The word is TAKEN with one atomic exchange (a bit the device ORs in between a read and a separate clearing store would be lost:
+// ADVICE r05) and every condition that was set is named in the message; the return code is the gravest one (5 > 7 > 6).
 int take_device_errors(fsnp_handle* h, const char* where) {
-    volatile unsigned* e = reinterpret_cast<volatile unsigned*>(h->d_err);
-    const unsigned bits = e[0];
+    unsigned* e = reinterpret_cast<unsigned*>(h->d_err);
+    if (__atomic_load_n(e, __ATOMIC_ACQUIRE) == 0) return 0;
+    const unsigned bits = __atomic_exchange_n(e, 0u, __ATOMIC_ACQ_REL);
     if (bits == 0) return 0;
-    const unsigned key = e[4];
-    e[0] = 0; e[4] = 0xFFFFFFFFu;
+    std::string msg = std::string(where) + ":";
+    int rc = 0;
     if (bits & kErrTimeout) {
-        set_error("%s: an inter-workgroup wait timed out in a column-split LSTM kernel (its workgroups were not co-resident - is the GPU "
-                  "shared with another process?); the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids these kernels", where);
-        return 5;
+        msg += " an inter-workgroup wait timed out in a column-split LSTM kernel (its workgroups were not co-resident - is the GPU "
+               "shared with another process?); the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids these kernels.";
+        rc = 5;
     }
     if (bits & kErrVerify) {
-        set_error("%s: exchange verification failed (fsnp_set_verify): the column-split kernels and the one-tile-per-CU kernel disagree, "
-                  "first at utterance %u, bin %u, frame %u; the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids the "
-                  "column-split kernels", where, key >> 24, (key >> 14) & 1023u, key & 16383u);
-        return 7;
+        // where the two kernels first disagreed: a 64-bit key in DEVICE memory (utterance << 44 | bin << 24 | frame; atomic min), read
+        // back here - on the error path only - once the comparing kernel has finished
+        unsigned long long key = ~0ull;
+        if (h->verify_key) {
+            fsnp::DeviceGuard guard(h->device);
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(&key, h->verify_key, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); key = ~0ull; }
+        }
+        char at[160];
+        if (key != ~0ull) snprintf(at, sizeof(at), ", first at utterance %llu, bin %llu, frame %llu", key >> 44, (key >> 24) & 0xFFFFFull, key & 0xFFFFFFull);
+        else at[0] = 0;
+        msg += std::string(rc ? " ALSO:" : "") + " exchange verification failed (fsnp_set_verify): the column-split kernels and the exchange-free "
+               "kernel disagree" + at + "; the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids the column-split kernels.";
+        if (!rc) rc = 7;
     }
-    set_error("%s: the watched source tensors no longer match the packed weights (a parameter was modified in place through .data "
-              "after packing): forwards since that edit ran on the OLD weights - re-pack (fsnp_set_weight / fsnp_commit_weights / "
-              "fsnp_watch_weights; Python: model.refresh_weights())", where);
-    return 6;
+    if (bits & kErrStaleWeights) {
+        msg += std::string(rc ? " ALSO:" : "") + " the watched source tensors no longer match the packed weights (a parameter was modified in "
+               "place through .data after packing): forwards since that edit ran on the OLD weights - re-pack (fsnp_set_weight / "
+               "fsnp_commit_weights / fsnp_watch_weights; Python: model.refresh_weights()).";
+        if (!rc) rc = 6;
+    }
+    if (!rc) { msg += " unknown device error bits"; rc = 4; }
+    set_error("%s", msg.c_str());
+    return rc;
 }
 
 // what the planner needs to know of a handle
@@ -232,7 +250,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
         if (c.kind == 0) {
             if (h->gru) launch_gru(h->lw, ca, s);
-            else launch_lstm(h->lw, ca, s);
+            else { ca.clk = reinterpret_cast<unsigned long long*>(h->d_err) + 8; launch_lstm(h->lw, ca, s); }
             continue;
         }
         if (c.kind == 4) { launch_lstm16(h->lw, ca, s); continue; }
@@ -606,7 +624,8 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
 // exchange at all) into a scratch mask and compared on the device.  The kernels sum K in different orders, so "equal" is a tolerance:
 // |a - b| <= 1e-4 + 1e-3 |b| (kernel-to-kernel differences are ~1e-6; one corrupted exchange element moves the mask by 1e-2 and more).
 __global__ __launch_bounds__(256) void verify_compare_kernel(const float* __restrict__ out, const float* __restrict__ ref, const RowDesc* __restrict__ rows,
-                                                             int num_slots, int T, int OC, long stride_o, unsigned* err_host) {
+                                                             int num_slots, int T, int OC, long stride_o, unsigned* err_host,
+                                                             unsigned long long* first_key) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)num_slots * OC * T) return;
     const int t = (int)(i % T), o = (int)((i / T) % OC), slot = (int)(i / ((long)OC * T));
@@ -615,8 +634,10 @@ __global__ __launch_bounds__(256) void verify_compare_kernel(const float* __rest
     const size_t at = (size_t)rd.out_off + (size_t)o * stride_o + t;
     const float a = out[at], b = ref[at];
     if (!(fabsf(a - b) <= 1e-4f + 1e-3f * fabsf(b))) {
-        const unsigned key = ((unsigned)(rd.b & 255) << 24) | ((unsigned)(rd.f & 1023) << 14) | (unsigned)(t & 16383);
-        __hip_atomic_fetch_min(err_host + 4, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // 20 bits of utterance, 20 of bin, 24 of frame: nothing the entry points accept wraps (the 8 / 10 / 14-bit key did)
+        const unsigned long long key = ((unsigned long long)(unsigned)rd.b << 44) | ((unsigned long long)((unsigned)rd.f & 0xFFFFFu) << 24) |
+                                       (unsigned long long)((unsigned)t & 0xFFFFFFu);
+        __hip_atomic_fetch_min(first_key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_or(err_host, kErrVerify, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -684,8 +705,10 @@ static int verify_pass(fsnp_handle* h, const SbPlan& plan, const Dims& d, int mo
     launch_sb_lstm(h, vp, va, nullptr, nullptr, nullptr, s);
     h->lw.ih_bf16 = keep_bf16;
     const long n = (long)vp.total_slots * h->cfg.output_size * d.T;
+    if (!h->verify_key) FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->verify_key), 8));
+    FSNP_HIP_CHECK(hipMemsetAsync(h->verify_key, 0xFF, 8, s));
     hipLaunchKernelGGL(verify_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.out, reinterpret_cast<const float*>(vb), vrows,
-                       vp.total_slots, d.T, h->cfg.output_size, a.out_stride_o, h->d_err);
+                       vp.total_slots, d.T, h->cfg.output_size, a.out_stride_o, h->d_err, h->verify_key);
     FSNP_HIP_CHECK(hipGetLastError());
     h->verify_runs += 1;
     return 0;
@@ -825,7 +848,6 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         return 4;
     }
     memset(h->d_err, 0, 256);
-    h->d_err[4] = 0xFFFFFFFFu;                     // smallest (utterance, bin, frame) key of a failed verification (atomic min)
     const char* dbg = getenv("FSNP_DEBUG_STAGES");
     h->debug = dbg && dbg[0] == '1';
     *out = h;
@@ -844,6 +866,7 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->d_weights) (void)hipFree(h->d_weights);
     drop_weight_watch(h);
     if (h->verify_out) (void)hipFree(h->verify_out);
+    if (h->verify_key) (void)hipFree(h->verify_key);
     if (h->d_err) (void)hipHostFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
@@ -988,7 +1011,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int chp = (int)align_up(d.CH, 4);           // row stride of the h1 sequence (a float4 multiple; pad columns written as zeros)
         fa.seq_stride = chp;
         if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
-        else if (h->fb_valu && lstm_fbv_available(h->fbw, batch)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); });   // B <= 4: VALU
+        else if (h->fb_valu && lstm_fbv_available(h->fbw, batch, h->num_cus_real)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); });   // B <= 4: VALU
         else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
         launch_linear_act(fptr(w.y1), chp, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
@@ -1352,6 +1375,17 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
     return fsnp_check_errors(h);
 }
 
+int fsnp_debug_launch_clock(fsnp_handle* h, double out[4]) {
+    if (!h || !out) { set_error("fsnp_debug_launch_clock: null argument"); return 1; }
+    const volatile unsigned long long* c = reinterpret_cast<const volatile unsigned long long*>(h->d_err) + 8;
+    const unsigned long long t0 = c[0], r0 = c[1], t1 = c[2], r1 = c[3];
+    if (r0 == 0 || r1 <= r0 || t1 <= t0) { set_error("fsnp_debug_launch_clock: no completed launch of the one-tile-per-CU LSTM kernel on this handle"); return 2; }
+    out[0] = (double)(t1 - t0); out[1] = (double)(r1 - r0);
+    out[2] = (double)(r1 - r0) * 1e-5;                          // 100 MHz ticks -> ms
+    out[3] = (double)(t1 - t0) / (double)(r1 - r0) * 100.0;     // s_memtime ticks per microsecond
+    return 0;
+}
+
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || ih_bf16 < 0 || ih_bf16 > 1) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM, BASELINE.json configs[4])"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
@@ -1491,7 +1525,8 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode) {
     h->lstm_coop = mode != 0;
     h->coop_skew = mode != 2;
     h->coop_hp = mode == 4 ? 1 : mode == 1 ? h->coop_hp_cfg : 0;
-    h->fb_valu = mode != 2;        // (FullSubNet: mode 2 also keeps the full-band LSTM on the K-split kernel, whatever the batch)
+    h->fb_valu = mode == 1 || mode == 4;   // (FullSubNet: modes 0 and 2 keep the full-band LSTM on the K-split kernel, whatever the batch - mode 0 is
+                                           // what the sync error policy retries with after a time-out, so it must not come back to the same exchange)
     h->cost.calibrated = h->calibrate ? 0 : h->cost.calibrated;    // the K-split costs depend on the schedule: measure again
     if (!h->cost.calibrated) h->cost = initial_costs(h->H, h->gru != 0, h->sb_tcn != 0);
     return 0;

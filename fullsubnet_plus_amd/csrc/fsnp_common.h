@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/fsnp.h"
+#include "../../include/fsnp_debug.h"
 
 namespace fsnp {
 
@@ -214,6 +215,8 @@ struct LstmArgs {
                                // h0 of row 0 at step coop_corrupt - 1 with 1.0 added (its own state stays right): a corrupted exchange image
     int coop_chaos;            // test hook (fsnp_debug_set_chaos): != 0 = seed of pseudo-random, workgroup-uniform delays at the phase boundaries
                                // of the column-split kernels, so that the workgroups of a launch drift apart instead of running in lockstep
+    unsigned long long* clk;   // one-tile-per-CU LSTM kernel (lstm.hip) only, optional: workgroup 0 writes {s_memtime, s_memrealtime} when it starts
+                               // into clk[0..1] and when it ends into clk[2..3] (host-mapped: fsnp_debug_launch_clock - which clock did the launch hold?)
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };
@@ -253,7 +256,7 @@ void lstm_coopw_pack_weights(int H, int NIN, int KX, const float* wih0, const fl
 // lstm_fbv.hip: the full-band LSTM(num_freqs -> 512 x 2) of the original FullSubNet for 1 ... 4 utterances as matrix-VECTOR products
 // on the VALU (weights resident, H / 8 workgroups, serial schedule with one hand-off per step); h1 sequence out
 void launch_lstm_fbv(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
-bool lstm_fbv_available(const LstmWeights& w, int batch);
+bool lstm_fbv_available(const LstmWeights& w, int batch, int num_cus);
 size_t lstm_fbv_pack_floats(int H);
 void lstm_fbv_pack_weights(int H, int NIN, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 // lstm_generic.hip: runtime-sized fp32-FMA kernel for the sizes no tuned kernel is instantiated for (any hidden size / input width);

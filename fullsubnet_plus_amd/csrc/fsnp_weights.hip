@@ -161,7 +161,11 @@ int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_
     // baseline kernel now and then: a false "stale weights" flag, profiles/r05_pytest_gpu_runA.log)
     FSNP_HIP_CHECK(hipMemsetAsync(h->watch_acc, 0, (8 + kWatchBlocks) * 8, static_cast<hipStream_t>(hip_stream)));
     h->watch_nseg = (int)segs.size();
-    return launch_weight_watch(h, static_cast<hipStream_t>(hip_stream), true);
+    if (const int rc = launch_weight_watch(h, static_cast<hipStream_t>(hip_stream), true)) return rc;
+    // the baseline belongs to the handle's shared state like a forward's workspace: a later forward on ANOTHER (non-blocking) stream
+    // must not start its watch blocks (same ticket word, same baseline slot) before this kernel has finished (a spurious
+    // code 6 when the watch was registered on the default stream and the forward ran on a torch side stream)
+    return mark_forward_done(h, static_cast<hipStream_t>(hip_stream));
 }
 
 int fsnp_num_weights(const fsnp_handle* h) { return h ? (int)h->specs.size() : 0; }

@@ -267,6 +267,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     const int slot0 = blockIdx.x * RT;
     const int Tp = a.Tp;
 
+    // which clock does this launch hold?  workgroup 0 stamps the shader-side counter and the 100 MHz wall clock on entry and on exit
+    // (straight to host-mapped memory: nothing stays live across the time loop); bench.py reports the ratio (fsnp_debug_launch_clock)
+    if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk[1] = __builtin_amdgcn_s_memrealtime();
+        a.clk[0] = __builtin_amdgcn_s_memtime();
+    }
+
     for (int i = tid; i < (KGX + 2 * KGH) * (64 + 2 * EX); i += NTHR) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < OUT * KGH * 2; i += NTHR) {
         const int o = i / (KGH * 2), kg = (i >> 1) % KGH, kh = i & 1;
@@ -485,6 +492,10 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #undef FSNP_STAMP
     __syncthreads();
     fc_store(Tp - 1);
+    if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk[2] = __builtin_amdgcn_s_memtime();
+        a.clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------

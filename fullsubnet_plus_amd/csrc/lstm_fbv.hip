@@ -202,8 +202,11 @@ void lstm_fbv_pack_weights(int H, int NIN, const float* wih0, const float* whh0,
         }
 }
 
-bool lstm_fbv_available(const LstmWeights& w, int batch) {
-    return !w.gru && w.H == 512 && w.NIN <= kFbvXP && batch >= 1 && batch <= 4 && w.wpack_fbv != nullptr;
+// The H / 8 = 64 workgroups hand h over to each other every step, so all of them must be resident at once; with ~230 weight registers
+// per thread ONE workgroup fits a CU: a device (or partition) with fewer CUs than workgroups would sit in the exchange until its 2 s
+// time-out - the caller then keeps the K-split kernel, whose unit count is chosen from the CU count.
+bool lstm_fbv_available(const LstmWeights& w, int batch, int num_cus) {
+    return !w.gru && w.H == 512 && w.NIN <= kFbvXP && batch >= 1 && batch <= 4 && w.wpack_fbv != nullptr && num_cus >= w.H / 8;
 }
 
 // H / 8 workgroups, all co-resident; a.num_rows <= 4 sequences; a.coop_hx: >= 4 x 4 x H floats, zeroed; a.coop_bar: one counter

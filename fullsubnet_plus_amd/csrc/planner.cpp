@@ -33,8 +33,8 @@ CostTable default_costs() {
 }
 // flat layout (include/fsnp.h, fsnp_get_costs): [0..7] K split full launch x {one, two per CU} at 8 / 16 / 32 / 64 units, [8..11] three-way
 // split 1 / 2 row tiles per group x {one, two per CU}, [12] one tile per CU, [13] relative extra per VALU row, [14..17] K split with ONE row
-// tile, [18] half tile per CU, [19..20] half-tile ping-pong one tile / full launch, [21..23] wave-owned split full launch at 32 / 64 / 96
-// units, [24..26] the same with ONE row tile
+// tile, [18] half tile per CU, [19..20] half-tile ping-pong one tile / full launch, [21..22] wave-owned split at 32 / 64 units per
+// workgroup, a full launch, [23..24] the same with ONE row tile (kNumCosts = 25; the 96-unit instantiation was never built)
 void costs_to_array(const CostTable& t, double* out) {
     for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }

@@ -621,6 +621,14 @@ class _HipModel(nn.Module):
                    "fsnp_get_timing")
         return {"lstm_ms": ms[0], "fullband_ms": ms[1], "forward_ms": ms[2], "lstm_first_chunk_ms": ms[3], "count": int(cnt[0])}
 
+    def launch_clock(self):
+        """-> {"wall_ms", "s_memtime_ticks", "s_memtime_mhz"} of the LAST launch of the one-tile-per-CU LSTM kernel on this handle, as its
+        workgroup 0 stamped them (fsnp_debug_launch_clock; synchronise first), or None if there was no such launch."""
+        out = (ctypes.c_double * 4)()
+        if _lib.load().fsnp_debug_launch_clock(self._handle, ctypes.byref(out)) != 0:
+            return None
+        return {"wall_ms": out[2], "s_memtime_ticks": out[0], "s_memtime_mhz": out[3]}
+
     def describe_plan(self, batch, parity=False):
         """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups", "deferred_when_pipelined"}, ...]: how the
         sub-band sequences of a `batch`-utterance forward are cut into kernel launches, the arithmetic each launch runs in under the

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "fsnp.h"
+#include "fsnp_debug.h"   /* (includes fsnp.h; the host-only planner hook below lives in the debug header) */
 
 int main(void) {
     fsnp_config cfg;

@@ -986,6 +986,77 @@ def test_weight_watch_registered_on_a_side_stream_raises_no_false_alarm():
     m.check_errors()
 
 
+def test_weight_watch_registered_on_one_stream_forward_on_another():
+    """fsnp_watch_weights queued its baseline fingerprint on the caller's stream without recording the handle's
+    cross-stream event, so a forward on ANOTHER non-blocking stream could start its watch blocks (same ticket word, same baseline
+    slot) under the running baseline kernel - a spurious code 6.  The registration now ends with mark_forward_done: 24 registrations
+    on the default stream behind queued work, each followed at once by a forward on a side stream that never waited for the default
+    stream by itself."""
+    g = Golden("b3_t20_harsh")
+    m = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    ref = m(*ins).cpu().numpy()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    busy = torch.empty(64 << 20, device="cuda")
+    m.error_check = "deferred"
+    for i in range(24):
+        for _ in range(4):
+            busy.add_(1.0)                                  # the default stream is busy when the baseline kernel is queued on it
+        m.refresh_weights()
+        m.set_verify(0)                                     # _ensure_handle on the DEFAULT stream: re-pack + watch registration
+        with torch.cuda.stream(side):
+            out = m(*ins)
+            m.check_errors()                                # raises on a false "weights modified"
+            assert np.array_equal(out.cpu().numpy(), ref), i
+    torch.cuda.synchronize()
+
+
+def test_box_probe_and_launch_clock():
+    """bench.py's `box` object: the pure-MFMA probe reports a plausible fp32 MFMA rate for an MI355X (the data sheet's 157.3 TFLOP/s is
+    2.4 GHz x 65,536 FLOP per cycle; a box under a power cap holds less) and a shader clock consistent with it; the dominant kernel's
+    workgroup 0 stamps the launch it ran in."""
+    from fullsubnet_plus_amd import box
+    p = box.probe(20.0)
+    assert p["compute_units"] >= 64 and 0.5 < p["frac_of_spec_peak"] <= 1.02, p
+    assert 1200 < p["clock_mhz_slowest_cu"] <= p["clock_mhz"] <= p["clock_mhz_fastest_cu"] < 2600, p
+    # the rate over the whole launch (hipEvents) can only be below the in-kernel rate; both describe the same clock
+    assert p["mfma_tflops"] <= p["mfma_tflops_in_kernel"] * 1.005 and p["mfma_tflops"] > 0.9 * p["mfma_tflops_in_kernel"], p
+    assert abs(p["mfma_tflops_in_kernel"] - p["clock_mhz"] * 1e6 * 65536 * p["compute_units"] / 256 / 1e12) < 1e-6 * p["mfma_tflops"]
+    g = Golden("b4_t16_default")
+    m = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    m(*ins)
+    assert m.launch_clock() is None or m.launch_clock()["wall_ms"] > 0    # B = 4: column-split plan, no one-tile-per-CU launch yet
+    m.debug_set_lstm_coop(0)
+    m(*ins)
+    torch.cuda.synchronize()
+    c = m.launch_clock()
+    assert c is not None and 0.01 < c["wall_ms"] < 100 and c["s_memtime_ticks"] > 0 and c["s_memtime_mhz"] > 50, c
+
+
+def test_error_word_reports_every_condition_that_was_set():
+    """the error word is taken with ONE atomic exchange and every bit that was set is named (a verify or stale-weights bit
+    that coincides with a time-out used to be dropped)."""
+    g = Golden("b3_t20_harsh")
+    m = _model(g.args, g.state_dict(), "full")
+    ins = _cuda(g.inputs())
+    m.error_check = "deferred"
+    ref = m(*ins).cpu().numpy()
+    m.sb_model.fc_output_layer.bias.data.add_(0.5)           # -> the weight watch flags the next forward (code 6) ...
+    m(*ins)
+    torch.cuda.synchronize()
+    m.debug_inject_error()                                   # ... and a (pretended) time-out lands in the same word (code 5)
+    with pytest.raises(RuntimeError, match=r"(?s)timed out.*ALSO:.*watched source tensors") as ei:
+        m.poll_errors()
+    assert ei.value.code == 5
+    m.poll_errors()                                          # taken: clean now
+    m.sb_model.fc_output_layer.bias.data.sub_(0.5)
+    m.refresh_weights()
+    assert np.array_equal(m(*ins).cpu().numpy(), ref)
+    m.check_errors()
+
+
 def _sleep_cycles_for(seconds):
     """torch.cuda._sleep counts device clock ticks: calibrate them against the wall clock once."""
     torch.cuda.synchronize()
