@@ -430,6 +430,10 @@ def main():
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms, "avg_launch_ms_runs": launch_runs,
                      # workgroup 0 of the last dominant launch: its wall time by the 100 MHz clock and the rate of s_memtime over it
                      "last_launch_clock": launch_clock,
+                     # ... and the rate against the peak AT THAT CLOCK (65,536 FLOP per shader cycle on 256 CUs): the kernel needs a
+                     # fixed number of cycles per launch, its milliseconds follow the clock the box holds
+                     "frac_at_held_clock": (lstm_flops / (launch_clock["wall_ms"] * 1e-3) / (65536.0 * launch_clock["s_memtime_mhz"] * 1e6)
+                                            if launch_clock and plan[0]["kernel"].startswith("lstm2_fc_kernel") else None),
                      "subband_plan": plan, "subband_stage_ms": stage_ms, "subband_stage_tflops": stage_achieved,
                      "fullband_ms": timing["fullband_ms"] / max(timing["count"], 1),
                      # the same stage in the OTHER loop (in the serving loop it runs beside the previous forward's remainder
@@ -443,7 +447,7 @@ def main():
                  "before and right after the timed loops" % args.probe_ms,
         "probe_before": probe_before, "probe_after": probe_after,
         "idle_before": idle_state, "during_timed_loops": sampled,
-        "hostname": socket.gethostname(), "gpu": torch.cuda.get_device_name(dev),
+        "hostname": socket.gethostname(), "gpu": torch.cuda.get_device_name(dev), "gpu_unique_id": box_mod.gpu_unique_id(sysfs_dir),
     }
     if rank_probe is not None:
         result["box"]["per_rank"] = rank_probe

@@ -88,6 +88,11 @@ def read_sysfs(dev_dir):
     return out
 
 
+def gpu_unique_id(dev_dir):
+    """The GPU's serial (sysfs unique_id): tells the boxes of a pool apart where every container's hostname is the same."""
+    return _read(os.path.join(dev_dir, "unique_id")) if dev_dir else None
+
+
 class Sampler(threading.Thread):
     """Samples sclk / socket power from sysfs every `period` seconds between start() and stop()."""
 
