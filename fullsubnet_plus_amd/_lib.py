@@ -45,6 +45,8 @@ SYMBOLS = {
     "fsnp_enhance_wave": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "fsnp_apply_cirm": (c_i32, [c_vp, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, ctypes.POINTER(c_i64 * 3), c_i32, c_i32,
                                 c_i32, c_vp]),
+    "fsnp_norm": (c_i32, [c_i32, c_vp, ctypes.POINTER(c_i64 * 4), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "fsnp_unfold": (c_i32, [c_vp, ctypes.POINTER(c_i64 * 4), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "fsnp_read_stage": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i64]),
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),
@@ -83,6 +85,7 @@ SYMBOLS = {
     "fsnp_debug_lstm_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coop_pack": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_coopw_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    "fsnp_debug_lstm_hpw_pack": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_lstm_fbv_pack": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_box_probe": (c_i32, [ctypes.c_double, ctypes.POINTER(ctypes.c_double * BOX_PROBE_VALUES), c_vp]),
     "fsnp_debug_launch_clock": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 4)]),

@@ -155,31 +155,7 @@ __global__ __launch_bounds__(64) void fe_frame_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) { frame[row * 2] = s; frame[row * 2 + 1] = q; }
 }
 
-// EPSILON of audio_zen/constant.py:8 == np.finfo(np.float32).eps
-#define FSNP_EPS 1.1920928955078125e-07f
-
-// Turn running (sum, sumsq, count) into (m, d) for the four norm types (base_model.py:210-316).
-__device__ __forceinline__ NormMD norm_md(int norm_type, double sum, double sq, double count) {
-    NormMD r;
-    const double mean = sum / count;
-    if (norm_type == FSNP_NORM_OFFLINE_LAPLACE) {
-        r.m = 0.0f;
-        r.d = (float)mean + 1e-5f;
-    } else if (norm_type == FSNP_NORM_CUMULATIVE_LAPLACE) {
-        r.m = 0.0f;
-        r.d = (float)mean + FSNP_EPS;
-    } else if (norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
-        double var = (sq - count * mean * mean) / (count - 1.0);   // torch.std: unbiased
-        if (var < 0) var = 0;
-        r.m = (float)mean;
-        r.d = (float)sqrt(var) + 1e-5f;
-    } else {  // cumulative layer norm: var = (pow - 2*mean*sum)/count + mean^2 ; std = sqrt(var + EPS)
-        double var = (sq - 2.0 * mean * sum) / count + mean * mean;
-        r.m = (float)mean;
-        r.d = (float)sqrt(var + (double)FSNP_EPS);
-    }
-    return r;
-}
+// (norm_md - running (sum, sumsq, count) -> (m, d) for the four norm types - lives in fsnp_common.h: stages.hip uses it too)
 
 // one workgroup per (branch, utt): chunked prefix scan over frames
 __global__ __launch_bounds__(256) void fe_scan_kernel(const double* __restrict__ frame, NormMD* __restrict__ md,

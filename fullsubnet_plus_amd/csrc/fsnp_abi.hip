@@ -277,7 +277,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             ca.coop_xcd = xcd_local && h->num_cus_real % 8 == 0 && xcd_local_blocks_per_xcd(S, T, cpx) <= cpx ? cpx : 0;
         }
         launch_coop_chained(h->device, s, [&] {
-            if (c.kind == 8) launch_lstm_hp(h->lw, ca, s);
+            if (c.kind == 8) { if (h->lw.hp_wave && lstm_hpw_available(h->lw)) launch_lstm_hpw(h->lw, ca, s); else launch_lstm_hp(h->lw, ca, s); }
             else if (c.kind == 9) launch_lstm_coopw(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
@@ -831,6 +831,8 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         const char* he = getenv("FSNP_COOP_HP");
         h->coop_hp = he && he[0] == '0' ? 0 : 1;
         h->coop_hp_cfg = h->coop_hp;
+        const char* hw = getenv("FSNP_HP_WAVE");           // 0 = kind-8 launches on lstm_hp.hip (round 3) instead of lstm_hpw.hip (round 6)
+        h->hp_wave = hw && hw[0] == '0' ? 0 : 1;
         h->hp_ok = !generic_sb && cfg->sequence_model == FSNP_SEQ_LSTM && (cfg->sb_hidden == 384 || cfg->sb_hidden == 256);
     }
     {
@@ -1481,7 +1483,8 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
         (int)h->committed, h->ih_bf16, h->pipeline, (int)h->timing, h->ws_bytes, h->ws_slots);
     add("effective settings (environment variable as read at fsnp_create = value in force):\n");
     add("  FSNP_LSTM_COOP=%s -> column-split kernels %s\n", env("FSNP_LSTM_COOP"), h->lstm_coop ? "planned (auto)" : "never");
-    add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
+    add("  FSNP_COOP_HP=%s -> half-tile ping-pong kernel (lstm_hp.hip / lstm_hpw.hip) %s\n", env("FSNP_COOP_HP"), !h->hp_ok ? "not built for this model" : h->coop_hp ? "planned" : "never");
+    add("  FSNP_HP_WAVE=%s -> its launches run on %s\n", env("FSNP_HP_WAVE"), h->hp_wave && lstm_hpw_available(h->lw) ? "lstm_hpw.hip (wave-owned units, round 6)" : "lstm_hp.hip (gate-split waves, round 3)");
     add("  FSNP_COOP_W=%s -> wave-owned column split (lstm_coopw.hip) %s\n", env("FSNP_COOP_W"), !h->coopw_ok ? "not built for this model" : h->coop_w ? "planned" : "never");
     add("  FSNP_COOP_SKEW=%s -> K-split schedule %s\n", env("FSNP_COOP_SKEW"), h->coop_skew ? "layer-skewed" : "serial");
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
@@ -1570,6 +1573,18 @@ int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, in
         return 2;
     }
     lstm_coop_pack_weights(hidden, input_size, kx, units, wih0, whh0, wih1, whh1, out);
+    return 0;
+}
+
+int fsnp_debug_lstm_hpw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
+                             const float* whh1, float* out, int64_t out_floats) {
+    if (!wih0 || !whh0 || !wih1 || !whh1 || !out) { set_error("fsnp_debug_lstm_hpw_pack: null argument"); return 1; }
+    if (hidden % 16 != 0 || kx % 4 != 0 || kx > 64 || input_size > kx) { set_error("fsnp_debug_lstm_hpw_pack: bad sizes"); return 2; }
+    if (out_floats != (int64_t)lstm_hpw_pack_floats(hidden, kx)) {
+        set_error("fsnp_debug_lstm_hpw_pack: need %lld floats", (long long)lstm_hpw_pack_floats(hidden, kx));
+        return 2;
+    }
+    lstm_hpw_pack_weights(hidden, input_size, kx, wih0, whh0, wih1, whh1, out);
     return 0;
 }
 

@@ -2,6 +2,7 @@
 // gfx950 (MI355X / CDNA4) only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/fsnp.h"
@@ -26,6 +27,33 @@ struct Dims {
 
 // One (m_t, d_t) pair: normalised = (x - m) / d.
 struct NormMD { float m, d; };
+
+// EPSILON of audio_zen/constant.py:8 == np.finfo(np.float32).eps
+#define FSNP_EPS 1.1920928955078125e-07f
+
+// Turn running (sum, sumsq, count) into (m, d) for the four norm types (base_model.py:210-316).
+__host__ __device__ __forceinline__ NormMD norm_md(int norm_type, double sum, double sq, double count) {
+    NormMD r;
+    const double mean = sum / count;
+    if (norm_type == FSNP_NORM_OFFLINE_LAPLACE) {
+        r.m = 0.0f;
+        r.d = (float)mean + 1e-5f;
+    } else if (norm_type == FSNP_NORM_CUMULATIVE_LAPLACE) {
+        r.m = 0.0f;
+        r.d = (float)mean + FSNP_EPS;
+    } else if (norm_type == FSNP_NORM_OFFLINE_GAUSSIAN) {
+        double var = (sq - count * mean * mean) / (count - 1.0);   // torch.std: unbiased
+        if (var < 0) var = 0;
+        r.m = (float)mean;
+        r.d = (float)sqrt(var) + 1e-5f;
+    } else {  // cumulative layer norm: var = (pow - 2*mean*sum)/count + mean^2 ; std = sqrt(var + EPS)
+        double var = (sq - 2.0 * mean * sum) / count + mean * mean;
+        r.m = (float)mean;
+        r.d = (float)sqrt(var + (double)FSNP_EPS);
+    }
+    return r;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // frontend.hip : strided input -> raw, norm statistics, TSSE gate, att = norm(x) * gate
@@ -119,6 +147,11 @@ void stft_build_matrices(int n_fft, float* fwd /*[N2 pad 384][n_fft]*/, float* i
                          float* window /*[n_fft]*/);
 
 // ---------------------------------------------------------------------------------------------
+// stages.hip : BaseModel's public helpers as stage-level entry points (fsnp_norm, fsnp_unfold)
+int launch_norm_stage(int norm_type, const float* in, const int64_t strides[4], float* out, int B, int C, int F, int T, hipStream_t s);
+void launch_unfold_stage(const float* in, const int64_t strides[4], float* out, int B, int C, int F, int T, int num_neighbor, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
 // subband.hip : statistics of the (never materialised) sub-band input tensor
 struct SubbandBuffers {
     const float* att_mag;  // [B][Tp][FP]
@@ -163,6 +196,8 @@ struct LstmWeights {
     const float* wpack16_bf;    // its bf16-ih stream: layer-1 W_ih as bf16 k-steps of 32 (configs[4]); nullptr = not packed
     const float* wpack_gru;     // one-tile-per-CU GRU kernel (lstm_gru.hip): [wave][k-group][3 live tiles x ST][lane][4]
     const float* wpack_hp;      // half-tile ping-pong kernel (lstm_hp.hip): [column slice of 16 units][gate][k-group of 16][lane][4]
+    const float* wpack_hpw;     // the same launch shape with wave-owned units (lstm_hpw.hip, round 6): [participant = 4 cs + wave][fragment][lane][4]; nullptr = not packed
+    int hp_wave;                // 1 = planner kind 8 launches run on lstm_hpw.hip (default), 0 = on lstm_hp.hip (FSNP_HP_WAVE=0)
     const float* wpack_fbv;     // full-band LSTM of FullSubNet for <= 4 utterances on the VALU (lstm_fbv.hip): [slice][fragment][thread][4]; nullptr = not packed
     const float* wpack_coopw;   // wave-owned column split (lstm_coopw.hip): [k-group][8-unit block, gate-interleaved columns][lane][4]; nullptr = not packed
     const float* wgen;          // runtime-sized kernel (lstm_generic.hip): transposed [layer][k][4H], layer 0 k = [x | h0], layer 1 = [h0 | h1]
@@ -244,6 +279,12 @@ size_t lstm_coop_exchange_bytes(int H, int row_tiles);
 // every row tile worked on as two half tiles of 16 sequences in turn (the hand-off of one half hidden behind the other)
 void launch_lstm_hp(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
 bool lstm_hp_available(const LstmWeights& w);
+// lstm_hpw.hip: the same launch shape, exchange region and counters; a WAVE owns 4 units x 4 gates over the whole K (transposed MFMA:
+// lane-local cells), operands streamed L2 -> registers, no workgroup barrier in the time loop
+void launch_lstm_hpw(const LstmWeights& w, const LstmArgs& a, hipStream_t s);
+bool lstm_hpw_available(const LstmWeights& w);
+size_t lstm_hpw_pack_floats(int H, int KX);
+void lstm_hpw_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 size_t lstm_hp_pack_floats(int H, int KX);
 void lstm_hp_pack_weights(int H, int NIN, int KX, const float* wih0, const float* whh0, const float* wih1, const float* whh1, float* out);
 // lstm_coopw.hip: a wave owns 8 NT hidden units over the full K, S = H / (32 NT) workgroups per row tile (a.coop_units = 32 NT in

@@ -93,6 +93,7 @@ struct fsnp_handle {
                                  // input width no tuned kernel is instantiated for
     bool generic_fb = false;     // FullSubNet: the same for the full-band recurrent model (fb_model_hidden_size != 512 or > 264 bins)
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
+    int hp_wave = 1;             // kind-8 launches run on the wave-owned variant (lstm_hpw.hip); FSNP_HP_WAVE=0: lstm_hp.hip
     int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0: never; fsnp_debug_set_lstm_coop(h, 4): even then)
     int fb_valu = 1;             // FullSubNet: the full-band LSTM of <= 4 utterances runs on the VALU kernel (lstm_fbv.hip); fsnp_debug_set_gemm_dma-like
                                  // test switch: fsnp_debug_set_lstm_coop(h, 2) turns it off together with the other round-3+ schedules

@@ -393,10 +393,12 @@ int fsnp_commit_weights(fsnp_handle* h) {
         lstm_coop_pack_weights(H, h->NIN, h->KX, units, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
                                blob.data() + o_wpack_coop[ui]);
     }
-    size_t o_wpack_hp = 0;
+    size_t o_wpack_hp = 0, o_wpack_hpw = 0;
     if (h->hp_ok) {
         o_wpack_hp = alloc(lstm_hp_pack_floats(H, h->KX));
         lstm_hp_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_hp);
+        o_wpack_hpw = alloc(lstm_hpw_pack_floats(H, h->KX));
+        lstm_hpw_pack_weights(H, h->NIN, h->KX, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack_hpw);
     }
     size_t o_wpack_coopw = 0;
     if (h->coopw_ok) {
@@ -468,6 +470,8 @@ int fsnp_commit_weights(fsnp_handle* h) {
     h->lw.wpack = d + o_wpack; h->lw.wpack12 = d + o_wpack12; for (int ui = 0; ui < 4; ++ui) h->lw.wpack_coop[ui] = d + o_wpack_coop[ui];
     h->lw.wpack_coopn = d + o_wpack_coopn;
     h->lw.wpack_hp = d + o_wpack_hp;
+    h->lw.wpack_hpw = h->hp_ok ? d + o_wpack_hpw : nullptr;
+    h->lw.hp_wave = h->hp_wave;
     h->lw.wpack_coopw = h->coopw_ok ? d + o_wpack_coopw : nullptr;
     h->lw.wpack_gru = d + o_wpack_gru;
     h->lw.wpack16 = d + o_wpack16;

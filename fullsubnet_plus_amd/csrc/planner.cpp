@@ -23,7 +23,10 @@ CostTable default_costs() {
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = ks[i]; t.ksplit[i][1] = 3.0 * ks[i]; t.ksplit1[i] = k1[i]; }
     for (int i = 0; i < 2; ++i) { t.coopn[i][0] = cn[i]; t.coopn[i][1] = 2.2 * cn[i]; }
     t.rowtile = 206.0; t.rowtile_ex = 0.11; t.rowtile16 = 103.0;
-    t.hp[0] = 12.3; t.hp[1] = 12.9;      // half-tile ping-pong (lstm_hp.hip): one row tile / a full launch of 10
+    // half-tile ping-pong launches: one row tile / a full launch of 10.  Round 6: they run on the wave-owned variant (lstm_hpw.hip):
+    // 10.9 ... 11.7 us per step in 128-step runs (profiles/r06_hpw_times.txt), 9.6 / 10.1 in fsnp_measure_costs' short runs on zeros;
+    // lstm_hp.hip (FSNP_HP_WAVE=0; H = 384 with more than 40 input features): 12.3 / 12.9
+    t.hp[0] = 10.4; t.hp[1] = 11.0;
     // round 5: wave-owned column split (lstm_coopw.hip) at 32 / 64 units per workgroup: one row tile / a full launch of 21 / 42
     // (profiles/r05_column_split.md; a 96-unit instantiation - 64 tiles x 4 workgroups - measured 63.3 us: no better than a 42-tile
     // launch at 64 units + a 21-tile launch at 32, and it spilled registers: not built)

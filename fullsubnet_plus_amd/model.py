@@ -179,6 +179,52 @@ class _HipModel(nn.Module):
         self._pipeline = False
         self._hip = _HipState()
 
+    # ------------------------------------------------------------------ BaseModel's public helpers (module protocol)
+    @staticmethod
+    def _stage_input(input):
+        assert input.dim() == 4, f"The dim of input is {input.dim()}. It should be four dim."
+        if not input.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; move the tensor to 'cuda'. There is deliberately no CPU fallback.")
+        x = input if input.dtype == torch.float32 else input.float()
+        return x, (ctypes.c_int64 * 4)(*x.stride()), torch.cuda.current_stream(x.device).cuda_stream
+
+    @staticmethod
+    def unfold(input, num_neighbor):
+        """BaseModel.unfold (audio_zen/model/base_model.py:15-47): [B, C, F, T] -> [B, F, C, 2 num_neighbor + 1, T], the overlapped sub-band
+        units along the frequency axis (reflect padded); num_neighbor < 1: [B, F, C, 1, T].  HIP kernel (fsnp_unfold) on CUDA tensors of
+        any strides.  (The forward never calls it: the recurrent kernels gather the sub-band input on the fly.)"""
+        x, st, stream = _HipModel._stage_input(input)
+        B, C, F, T = x.shape
+        ns = 2 * int(num_neighbor) + 1 if num_neighbor >= 1 else 1
+        out = torch.empty((B, F, C, ns, T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsnp_unfold(x.data_ptr(), ctypes.byref(st), out.data_ptr(), B, C, F, T, int(num_neighbor), ctypes.c_void_p(stream)),
+                       "fsnp_unfold")
+        return out
+
+    def norm_wrapper(self, norm_type: str):
+        """BaseModel.norm_wrapper (base_model.py:318-330): -> a callable [B, C, F, T] -> [B, C, F, T] running the named normalisation as HIP
+        kernels (fsnp_norm); unknown names raise NotImplementedError like the reference."""
+        if norm_type not in _lib.NORM_TYPES:
+            raise NotImplementedError("You must set up a type of Norm. "
+                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
+        code = _lib.NORM_TYPES[norm_type]
+
+        def norm(input):
+            x, st, stream = _HipModel._stage_input(input)
+            B, C, F, T = x.shape
+            out = torch.empty((B, C, F, T), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().fsnp_norm(code, x.data_ptr(), ctypes.byref(st), out.data_ptr(), B, C, F, T, ctypes.c_void_p(stream)), "fsnp_norm")
+            return out
+        norm.__name__ = norm_type
+        return norm
+
+    @property
+    def norm(self):
+        """`self.norm` of the reference models (fullsubnet_plus.py:115, fullsubnet.py:61): norm_wrapper(self.norm_type)."""
+        return self.norm_wrapper(self.norm_type)
+
     def _weights_key(self):
         # (storage pointer, version) of every parameter: changes on load_state_dict, .to(), in-place updates.  The parameter
         # LIST is cached - walking the module tree (340 parameters) was 0.56 ms per forward, a quarter of a B = 1 step - and

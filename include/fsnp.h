@@ -19,7 +19,7 @@
  * All device work is enqueued on the caller's HIP stream; no device synchronisation
  * happens inside fsnp_forward.
  *
- * This header is the surface a maintainer of the reference binds (27 entry points).  Planner introspection, per-kernel timing,
+ * This header is the surface a maintainer of the reference binds (29 entry points).  Planner introspection, per-kernel timing,
  * stage read-back, calibration probes and every test / tuning hook live in fsnp_debug.h (same library, same ABI version).
  */
 #ifndef FSNP_H
@@ -192,6 +192,20 @@ int fsnp_apply_cirm(const float* mask, const float* noisy, const int64_t strides
  *   out : DEVICE fp32 [N, output_size, T] */
 int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, int32_t steps,
                   void* hip_stream);
+
+/* Stage-level entry points, second kind: the PUBLIC HELPERS every reference model object carries next to forward() - `self.norm`
+ * (fullsubnet_plus.py:115, fullsubnet.py:61) = BaseModel.norm_wrapper(norm_type) (audio_zen/model/base_model.py:318-330) and
+ * BaseModel.unfold (base_model.py:15-47) - on arbitrary device tensors.  No handle (they are static functions of the reference).
+ *   fsnp_norm   : in DEVICE fp32 [B,C,F,T] with ELEMENT strides[4] (batch, channel, freq, time) -> out contiguous [B,C,F,T];
+ *                 norm_type = FSNP_NORM_*: offline norms take the statistics over (C,F,T) of an utterance (base_model.py:211-226,
+ *                 261-275), cumulative norms a prefix over the frames of every (b, c) row (base_model.py:228-258, 278-316).
+ *   fsnp_unfold : in as above -> out contiguous [B, F, C, 2 num_neighbor + 1, T]: the sub-band units along the frequency axis,
+ *                 reflect padded (functional.pad(mode="reflect") + functional.unfold); num_neighbor < 1: [B, F, C, 1, T].
+ * Stream-ordered (scratch from hipMallocAsync on hip_stream), no synchronisation. */
+int fsnp_norm(int32_t norm_type, const float* in, const int64_t strides[4], float* out, int32_t batch, int32_t channels, int32_t freqs,
+              int32_t frames, void* hip_stream);
+int fsnp_unfold(const float* in, const int64_t strides[4], float* out, int32_t batch, int32_t channels, int32_t freqs, int32_t frames,
+                int32_t num_neighbor, void* hip_stream);
 
 /* For bug reports: a text dump of the handle's configuration and of EVERY effective FSNP_* setting (the environment variables
  * are read at fsnp_create; the value in force is printed next to each).  Writes at most cap bytes (NUL-terminated) into buf

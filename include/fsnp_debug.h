@@ -152,6 +152,13 @@ int fsnp_debug_lstm_coop_pack(int32_t hidden, int32_t input_size, int32_t kx, in
 int fsnp_debug_lstm_coopw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
                                const float* whh1, float* out, int64_t out_floats);
 
+/* Same for the wave-owned variant of the half-tile ping-pong kernel (csrc/lstm_hpw.hip): [participant = 4 cs + wave][fragment: x k-groups
+ * of 16 | W_hh0 | W_hh1 | W_ih1][lane][4] - the A operand of v_mfma_f32_16x16x4_f32 number j of a k-group g is
+ * W[gate * H + unit][k = 16 g + 4 j + (lane >> 4)], M row lane & 15 = 4 jj + gate, unit = 16 cs + wave + 4 jj;
+ * (hidden / 16) * 4 * ((kx + 15) / 16 + 3 * hidden / 16) * 256 floats. */
+int fsnp_debug_lstm_hpw_pack(int32_t hidden, int32_t input_size, int32_t kx, const float* wih0, const float* whh0, const float* wih1,
+                             const float* whh1, float* out, int64_t out_floats);
+
 /* Same for the matrix-vector full-band kernel of the original FullSubNet (csrc/lstm_fbv.hip; hidden 512, <= 288 inputs):
  * [column slice of 8 units][fragment j4 < 57][thread (c = tid & 31: gate c & 3 of unit c >> 2; ks = tid >> 5: k slice)][4] -
  * fragments 0 .. 24 = layer 0 over [x (288, zero padded) | h0], k = 100 ks + 4 j4 + e; fragments 25 .. 56 = layer 1 over [h0 | h1],

@@ -986,6 +986,32 @@ def test_weight_watch_registered_on_a_side_stream_raises_no_false_alarm():
     m.check_errors()
 
 
+@pytest.mark.parametrize("norm_type", ["offline_laplace_norm", "cumulative_laplace_norm", "offline_gaussian_norm", "cumulative_layer_norm"])
+def test_norm_and_unfold_stage_entry_points_vs_oracle(norm_type):
+    """fsnp_norm / fsnp_unfold (csrc/stages.hip) = `model.norm` / `model.unfold` of the reference's module protocol (base_model.py:15-47,
+    210-330) on arbitrary [B, C, F, T] tensors: contiguous and torch.stft-style strided inputs, one and several channels (the sub-band
+    input is normalised with C = 1 and F = 34 features), against the oracle's restatement of the reference functions.  The laplace norms
+    divide by a mean: positive inputs (magnitudes), as in the model."""
+    m = FullSubNet_Plus(**{**DEFAULT_MODEL_ARGS, "norm_type": norm_type}).cuda().eval()
+    rng = np.random.Generator(np.random.PCG64(31))
+    for shape in [(3, 1, 257, 20), (2, 3, 34, 61), (1, 2, 5, 300)]:
+        x = torch.from_numpy(np.abs(rng.standard_normal(shape)).astype(np.float32) + 0.1)
+        want = fsnp_torch.NORMS[norm_type](x).numpy()
+        got = m.norm(x.cuda()).cpu().numpy()
+        assert got.shape == want.shape and rel_err(got, want) < 2e-5, (shape, rel_err(got, want))
+        xs = x.permute(0, 3, 2, 1).contiguous().permute(0, 3, 2, 1)          # same values, memory order [B][T][F][C]
+        assert not xs.is_contiguous()
+        assert np.array_equal(m.norm(xs.cuda()).cpu().numpy(), got)
+        assert np.array_equal(m.norm_wrapper(norm_type)(x.cuda()).cpu().numpy(), got)
+    for shape, nb in [((2, 1, 257, 12), 15), ((2, 3, 40, 7), 1), ((1, 2, 9, 5), 0), ((2, 1, 33, 4), 8)]:
+        x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        want = fsnp_torch.unfold(x, nb).numpy()
+        got = m.unfold(x.cuda(), nb).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (shape, nb)
+        xs = x.permute(0, 3, 2, 1).contiguous().permute(0, 3, 2, 1)
+        assert np.array_equal(FullSubNet_Plus.unfold(xs.cuda(), nb).cpu().numpy(), want)
+
+
 def test_weight_watch_registered_on_one_stream_forward_on_another():
     """fsnp_watch_weights queued its baseline fingerprint on the caller's stream without recording the handle's
     cross-stream event, so a forward on ANOTHER non-blocking stream could start its watch blocks (same ticket word, same baseline

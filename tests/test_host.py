@@ -634,6 +634,91 @@ def test_half_tile_ping_pong_index_arithmetic():
             assert voff == csp * 128 + 4 * (o * 16 + cs) and voff // 128 == csp and (voff % 128) // 4 == o * 16 + cs   # stage[512 + o * 16 + row]
 
 
+def test_wave_owned_half_tile_kernel_data_flow_on_the_cpu():
+    """csrc/lstm_hpw.hip restated with numpy on the weights its packer really produces (fsnp_debug_lstm_hpw_pack): the TRANSPOSED product
+    (weights = A operand of v_mfma_f32_16x16x4_f32, h / x = B operand) leaves gate i of cell (sequence lane & 15, unit 16 cs + w + 4 (lane >> 4))
+    in accumulator register i of that lane - for every participant, both layers, K = [x | h0] and [h1 | h0]; the lane's result lands at
+    hp_a16(sequence, unit) of the exchange image = participant * 256 + sequence * 16 + (lane >> 4) * 4 bytes (one contiguous 256-byte row per
+    wave); the Linear partials are found where the summing wave looks for them."""
+    lib = _lib.load()
+    H, NIN, KX = 64, 34, 40                       # (the index arithmetic does not depend on H; 64 keeps the emulation small)
+    GX, GH = (KX + 15) // 16, H // 16
+    NF = GX + 3 * GH
+    rng = np.random.default_rng(5)
+    wih0 = rng.standard_normal((4 * H, NIN)).astype(np.float32)
+    whh0, wih1, whh1 = (rng.standard_normal((4 * H, H)).astype(np.float32) for _ in range(3))
+    n = (H // 16) * 4 * NF * 256
+    out = np.zeros(n, np.float32)
+    assert lib.fsnp_debug_lstm_hpw_pack(H, NIN, KX, wih0.ctypes.data, whh0.ctypes.data, wih1.ctypes.data, whh1.ctypes.data, out.ctypes.data, n) == 0
+    pack = out.reshape(H // 16 * 4, NF, 64, 4)                        # [participant][fragment][lane][j]
+    x = rng.standard_normal((16, KX)).astype(np.float32); x[:, NIN:] = 7.0     # features >= NIN: garbage that must meet zero weights
+    h0 = rng.standard_normal((16, H)).astype(np.float32)
+    h1 = rng.standard_normal((16, H)).astype(np.float32)
+    a16 = lambda row, k: ((((k >> 4) * 4) + (k & 3)) * 16 + row) * 4 + ((k >> 2) & 3)
+    img0, img1 = np.zeros(16 * H, np.float32), np.zeros(16 * H, np.float32)
+    for r in range(16):
+        for k in range(H):
+            img0[a16(r, k)] = h0[r, k]; img1[a16(r, k)] = h1[r, k]
+    lanes = np.arange(64)
+
+    def mfma(acc, a_lane, b_lane):               # D[m][n] += sum_kk A[m][kk] B[kk][n]; A from lane kk * 16 + m, B from lane kk * 16 + n
+        A = a_lane.reshape(4, 16).T              # [m][kk]
+        B = b_lane.reshape(4, 16)                # [kk][n]
+        return acc + A.astype(np.float64) @ B.astype(np.float64)
+
+    want0 = np.concatenate([x[:, :NIN], h0], 1).astype(np.float64) @ np.concatenate([wih0, whh0], 1).astype(np.float64).T      # [seq][4H]
+    want1 = np.concatenate([h1, h0], 1).astype(np.float64) @ np.concatenate([whh1, wih1], 1).astype(np.float64).T
+    for part in range(H // 16 * 4):
+        cs, wv = part >> 2, part & 3
+        d0, d1 = np.zeros((16, 16)), np.zeros((16, 16))
+        for i in range(KX // 4):                 # x k-groups: the lane's fragment component i & 3 of group i >> 2 = x[seq][4 i + (lane >> 4)]
+            xb = x[lanes & 15, 4 * i + (lanes >> 4)]
+            d0 = mfma(d0, pack[part, i >> 2, :, i & 3], xb)
+        for g in range(GH):
+            p = img1.reshape(GH, 64, 4)[g]       # one 16-byte load per lane: float4 index g * 64 + lane
+            q = img0.reshape(GH, 64, 4)[g]
+            for j in range(4):
+                d1 = mfma(d1, pack[part, GX + GH + g, :, j], p[:, j])
+                d0 = mfma(d0, pack[part, GX + g, :, j], q[:, j])
+                d1 = mfma(d1, pack[part, GX + 2 * GH + g, :, j], q[:, j])
+        for lane in range(64):
+            seq, jj = lane & 15, lane >> 4
+            unit = 16 * cs + wv + 4 * jj
+            for gate in range(4):                # accumulator register i of lane L = D[m = 4 (L >> 4) + i][n = L & 15]
+                assert abs(d0[4 * jj + gate, seq] - want0[seq, gate * H + unit]) < 1e-3
+                assert abs(d1[4 * jj + gate, seq] - want1[seq, gate * H + unit]) < 1e-3
+            assert a16(seq, unit) * 4 == part * 256 + seq * 16 + jj * 4
+    P = 4 * 24
+    for cs in range(16):                         # summing wave of row cs: lane + 64 j reads the float2 of participant p at p * 128 + cs * 8
+        for p_ in range(P):
+            assert (p_ * 32 + cs * 2) * 4 == p_ * 128 + cs * 8
+    for part in range(P):                        # a wave's partial: lanes < 16 (sequence = lane) store float2 at (part * 32 + seq * 2) * 4
+        assert {(part * 32 + seq * 2) * 4 for seq in range(16)} == {part * 128 + 8 * r for r in range(16)}
+
+
+def test_models_carry_the_reference_base_model_helpers():
+    """SURVEY.md 8(b) "module protocol": the reference model objects expose `norm` (fullsubnet_plus.py:115, fullsubnet.py:61), `norm_wrapper`
+    (base_model.py:318-330) and `unfold` (base_model.py:15-47) next to forward().  The HIP classes carry them too (fsnp_norm / fsnp_unfold
+    kernels); like forward() they refuse CPU tensors - there is no CPU fallback - and unknown norm names raise the reference's error."""
+    for m in (FullSubNet_Plus(**DEFAULT_MODEL_ARGS), FullSubNet(**FULLSUBNET_MODEL_ARGS)):
+        assert callable(m.norm) and m.norm.__name__ == m.norm_type
+        assert callable(m.norm_wrapper("cumulative_layer_norm")) and callable(m.unfold) and callable(type(m).unfold)
+        with pytest.raises(NotImplementedError, match="You must set up a type of Norm"):
+            m.norm_wrapper("forgetting_norm")
+        x = torch.zeros(2, 1, 9, 5)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.norm(x)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.unfold(x, 2)
+        with pytest.raises(AssertionError, match="four dim"):
+            m.unfold(x[0], 2)
+    lib = _lib.load()
+    st = (ctypes.c_int64 * 4)(1, 1, 1, 1)
+    assert lib.fsnp_norm(9, 1, ctypes.byref(st), 1, 1, 1, 1, 1, None) == 2 and b"norm_type" in lib.fsnp_last_error()
+    assert lib.fsnp_unfold(1, ctypes.byref(st), 1, 1, 1, 4, 1, 4, None) == 2 and b"reflect" in lib.fsnp_last_error()
+    assert lib.fsnp_norm(0, None, ctypes.byref(st), 1, 1, 1, 1, 1, None) == 1
+
+
 def test_splitk_gemm_has_no_barrier_in_its_k_loop():
     """tcn_gemm_sk_kernel (csrc/tcn.hip, small batches): a wave multiplies ITS k-tiles out of a private double buffer - 16 MFMAs per
     k-tile, 6 + 6 DMA pieces, no scratch, no workgroup barrier between the first and the last MFMA."""
@@ -1012,7 +1097,9 @@ def test_subband_plan_choices_match_the_design():
     assert sum(c["rows"] for c in g) == 65792 and all(c["kind"] == 1 for c in g[12:])   # the short rest K split
     g = _plan(8224, gru=1)                                                          # GRU, B = 32: 257 tiles = 170 + 85 + 2
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
-    assert seq(3084) == [9, 9, 9] and kinds(3400) == [(4, 3400)]                    # B = 12: 97 tiles = 42 + 42 + 13 on the wave-owned split (half tiles from ~103 tiles)
+    # B = 12: 97 tiles = 42 + 42 on the wave-owned split + 10 on the half-tile ping-pong launch + 3 K split (round 6: with lstm_hpw.hip's
+    # 11 us per step that beats a third wave-owned launch of 13 tiles - measured 13.19 against 13.54 ms per forward); half tiles from ~103 tiles
+    assert seq(3084) == [9, 9, 8, 1] and kinds(3400) == [(4, 3400)]
     p = _plan(3084, gru=1)                                                          # (GRU: 97 tiles = one per group + the rest K split)
     assert p[0]["kind"] == 2 and p[0]["rpg"] == 1 and p[0]["tiles"] == 85 and all(c["kind"] == 1 for c in p[1:]) and sum(c["rows"] for c in p) == 3084
     assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2

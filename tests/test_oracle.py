@@ -120,3 +120,24 @@ def test_committed_golden_is_what_the_generator_produces():
     fcase = next(c for c in make_golden.FSN_CASES if c["name"] == "fsn_b1_t20_gaussian")
     fpayload, _ = make_golden.run_case_fsn(fcase, ref_loader.load_reference_fullsubnet())
     assert rel_err(fpayload["out"], Golden("fsn_b1_t20_gaussian").arrays["out"]) < 1e-6
+
+
+def test_helper_restatements_match_the_reference_base_model():
+    """oracle/fsnp_torch.py NORMS / unfold - the checkers of `model.norm` / `model.unfold` (fsnp_norm, fsnp_unfold) - against the reference's
+    own BaseModel static functions (audio_zen/model/base_model.py:15-47, 210-316), on the shapes the GPU test uses."""
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted")
+    import numpy as np
+    import torch
+    ref_loader.load_reference()
+    from audio_zen.model.base_model import BaseModel  # type: ignore
+    rng = np.random.Generator(np.random.PCG64(31))
+    for shape in [(3, 1, 257, 20), (2, 3, 34, 61), (1, 2, 5, 300)]:
+        x = torch.from_numpy(np.abs(rng.standard_normal(shape)).astype(np.float32) + 0.1)
+        for name, fn in fsnp_torch.NORMS.items():
+            want = getattr(BaseModel, name)(x)
+            got = fn(x)
+            assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), name
+    for shape, nb in [((2, 1, 257, 12), 15), ((2, 3, 40, 7), 1), ((1, 2, 9, 5), 0), ((2, 1, 33, 4), 8)]:
+        x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        assert torch.equal(fsnp_torch.unfold(x, nb), BaseModel.unfold(x, nb))

@@ -14,6 +14,22 @@ from fullsubnet_plus_amd import FullSubNet_Plus, _lib  # noqa: E402
 from fullsubnet_plus_amd.synthetic import DEFAULT_MODEL_ARGS, make_state_dict  # noqa: E402
 
 
+def main_hpw(s, n, steps):
+    """csrc/lstm_hpw.hip (round 6, the default of planner kind 8; FSNP_HP_WAVE=0 selects lstm_hp.hip): wave 0 of workgroup 0 - which also
+    sums the Linear partials of output row 0."""
+    names = ["x k-groups (10 MFMAs) + s_waitcnt vmcnt(0) (previous stores, first operands) + arrival", "Linear of the previous step (summing waves only)",
+             "-", "pass over h: 288 MFMAs, 36 operand loads, 12 x loads, counter poll", "counter check (+ wait) + prefill of the other half's operands",
+             "cells + 2 h stores + Linear partial (2 x 2 cross-lane adds, 1 store)", "x normalise", "-"]
+    d = np.diff(s[:, :9], axis=1) * 0.01
+    res = {"kernel": "lstm2_coop_hpw_kernel", "sequences": n, "steps": steps, "us_per_half_phase": float((s[1:, 0] - s[:-1, 0]).mean() * 0.01),
+           "counter_seen_complete_at_the_poll_fraction": float(s[:, 15].mean())}
+    for i, nm in enumerate(names):
+        if nm != "-":
+            res[f"{i}: {nm}"] = round(float(d[:, i].mean()), 3)
+    res["gap to the next phase"] = round(float((s[1:, 0] - s[:-1, 8]).mean() * 0.01), 3)
+    print(json.dumps(res, indent=1))
+
+
 def main_hp(s, n, steps):
     names = ["drain own DMA + barrier 1 (operands in LDS)", "pass: first quarter", "pass: deferred arrival (store drain + atomic)", "pass: rest (+ fetch of the other half)",
              "pre-activations -> LDS, barrier 2 (= waiting for the slowest wave)", "cell phase", "barrier 3", "publish (+ wait / late fetch)"]
@@ -63,7 +79,8 @@ def main():
     for _ in range(2):
         _lib.check(lib.fsnp_debug_pp_profile(m._handle, x.data_ptr(), out.data_ptr(), n, steps, r, stamps.ctypes.data, stamps.size), "profile")
     if hp:
-        return main_hp(stamps.reshape(steps * 2, 16).astype(np.int64)[8:], n, steps)
+        wave_owned = os.environ.get("FSNP_HP_WAVE", "1") != "0"
+        return (main_hpw if wave_owned else main_hp)(stamps.reshape(steps * 2, 16).astype(np.int64)[8:], n, steps)
     s = stamps.reshape(steps * rr, 8).astype(np.int64)[4 * rr:]          # skip warm-up steps; 10 ns ticks
     names = ["MFMA pass", "barrier 1 (+flags)", "early fetch + partial tiles -> LDS, barrier 2", "cell phase", "barrier 3", "publish (+ wait / late fetch)"]
     d = np.diff(s[:, :7], axis=1) * 0.01
