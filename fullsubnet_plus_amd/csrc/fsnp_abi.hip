@@ -1392,7 +1392,7 @@ int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || ih_bf16 < 0 || ih_bf16 > 1) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM, BASELINE.json configs[4])"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
     if (ih_bf16 && h->H != 384) { set_error("fsnp_set_precision: the bf16 variants exist for sb_model_hidden_size = 384 only"); return 2; }
-    if (ih_bf16 && h->KX != 40) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 40 features only"); return 2; }
+    if (ih_bf16 && (h->KX != 40 || h->NIN >= h->KX)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for sub-band inputs of <= 39 features only (its layer-0 bias rides in a spare input column)"); return 2; }
     h->ih_bf16 = ih_bf16;
     h->lw.ih_bf16 = ih_bf16 == 1 ? 1 : 0;       // (launch_lstm's own switch: the bf16-ih variant of lstm.hip)
     return 0;

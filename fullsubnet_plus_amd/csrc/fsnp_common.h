@@ -321,7 +321,7 @@ size_t lstm_pack_floats(int H, int KX, int NW);  // size of wpack in floats
 // host-side packer: W_ih0 [4H][NIN], W_hh0 [4H][H], W_ih1 [4H][H], W_hh1 [4H][H] -> wpack
 size_t lstm_pack_floats_bf16ih(int H, int KX, int NW);
 void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
-                              const float* whh1, float* wpack);
+                              const float* whh1, const float* bias0, float* wpack);
 void lstm_pack_weights(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
                        const float* whh1, float* wpack);
 

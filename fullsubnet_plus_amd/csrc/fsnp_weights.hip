@@ -363,10 +363,10 @@ int fsnp_commit_weights(fsnp_handle* h) {
             o_wpack12 = alloc(lstm_pack_floats(H, h->KX, 12));
             lstm_pack_weights(H, h->NIN, h->KX, 12, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), blob.data() + o_wpack12);
         }
-        for (int i = 0; i < 2 && h->KX == 40 && H == 384; ++i) {      // the bf16-ih variant is built for the default input width only
+        for (int i = 0; i < 2 && h->KX == 40 && H == 384 && h->NIN < h->KX; ++i) {      // the bf16-ih variant is built for the default input width only (and needs a spare input column: its layer-0 bias rides there)
             const int nw = i == 0 ? 4 : 12;
             o_wpack_bf[i] = alloc(lstm_pack_floats_bf16ih(H, h->KX, nw));
-            lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(),
+            lstm_pack_weights_bf16ih(H, h->NIN, h->KX, nw, sbw.wih0.data(), sbw.whh0.data(), sbw.wih1.data(), sbw.whh1.data(), sbw.bias.data(),
                                      blob.data() + o_wpack_bf[i]);
         }
     }

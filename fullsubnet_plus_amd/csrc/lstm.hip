@@ -137,7 +137,8 @@ __host__ __device__ __forceinline__ int a_frag_index_bf16(int row, int k) {
     return (((k >> 4) * 64) + (((k >> 3) & 1) * 32) + row) * 8 + (k & 7);
 }
 
-template <int ST, int UW>
+// HBLO: 2-byte elements between the hi and the lo bf16 image of h0_t (Hb != nullptr only)
+template <int ST, int UW, int HBLO = 0>
 __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x2 (&c)[ST][8], float* __restrict__ Hs, int wave,
                                           int lane, unsigned short* __restrict__ Hb = nullptr) {
 #pragma unroll
@@ -158,7 +159,14 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x2 (&c)[ST][
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);     // (r even: r + 1 is the next row)
             Hs[kbase + row * 4] = h.x;
             Hs[kbase + (row + 1) * 4] = h.y;
-            if (Hb) { Hb[a_frag_index_bf16(row, k)] = bf16_bits(h.x); Hb[a_frag_index_bf16(row + 1, k)] = bf16_bits(h.y); }
+            if (Hb) {           // bf16 A image of h0_t as hi + lo (round 6): h = hi + lo to ~16 mantissa bits, two MFMAs per weight fragment
+                const unsigned short hx = bf16_bits(h.x), hy = bf16_bits(h.y);
+                Hb[a_frag_index_bf16(row, k)] = hx; Hb[a_frag_index_bf16(row + 1, k)] = hy;
+                if constexpr (HBLO > 0) {
+                    Hb[HBLO + a_frag_index_bf16(row, k)] = bf16_bits(h.x - __uint_as_float((unsigned)hx << 16));
+                    Hb[HBLO + a_frag_index_bf16(row + 1, k)] = bf16_bits(h.y - __uint_as_float((unsigned)hy << 16));
+                }
+            }
         }
     }
 }
@@ -167,13 +175,15 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[4 * ST], f32x2 (&c)[ST][
 // step (fp32 accumulate into the same tiles), operands = bf16 A image of h0_t in LDS and bf16 weight fragments that
 // travel through the same 16-byte-per-lane register pipeline as the fp32 groups.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-template <int NT, int EX>
+// ALO: float4 units between the hi and the lo bf16 A image (round 6): every weight fragment multiplies both - the activation's own
+// quantisation error (half of the mode's error budget, profiles/r06_bf16_error.md) leaves the product, the weights stay bf16
+template <int NT, int EX, int ALO>
 __device__ __forceinline__ void mfma_groups_bf16(f32x16 (&acc)[NT], float (&accx)[EX > 0 ? EX : 1][NT], float4 (&b)[NT],
                                                  const float4* __restrict__ A, const float4* __restrict__ AE, int nsteps,
                                                  const WStream& ws, int& gnext, int groups_total, int lane) {
-    float4 a = A[0];
+    float4 a = A[0], al = A[ALO];                 // (ALO == 0 - VALU-row tiles - : hi only)
     for (int g = 0; g < nsteps; ++g) {
-        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64];
+        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64], aln = A[ALO + (g + 1 < nsteps ? g + 1 : g) * 64];
         // VALU rows: this lane's 8 weights of tile n are k = 16 g + 8 (lane>>5) + j, i.e. fp32 k-group 2g + (lane>>5)
         // of the E image (kh = 0: j even, kh = 1: j odd)
         float4 he[EX > 0 ? EX : 1][2];
@@ -202,15 +212,19 @@ __device__ __forceinline__ void mfma_groups_bf16(f32x16 (&acc)[NT], float (&accx
             }
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[n]),
                                                              acc[n], 0, 0, 0);
+            if constexpr (ALO > 0)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b[n]),
+                                                                 acc[n], 0, 0, 0);
             b[n] = wload<NT>(ws, gnext, n);
             __builtin_amdgcn_sched_barrier(0);
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
-        a = an;
+        a = an; al = aln;
     }
 }
 
 // Extra rows: combine the two half-wave partial sums, add the bias, update c, write h into the E-image.
+// (bias == nullptr: the bias rode in the product - bf16-ih variant, layer 0: folded into the weight column of a constant-1 input)
 template <int ST, int UW, int EX, int NT>
 __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][NT], float (&cx)[EX > 0 ? EX : 1][ST],
                                                 const float* __restrict__ bias, float* __restrict__ He, int wave,
@@ -223,7 +237,7 @@ __device__ __forceinline__ void lstm_cell_extra(float (&accx)[EX > 0 ? EX : 1][N
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v = accx[e][q * ST + s];
-                g4[q] = v + __shfl_xor(v, 32) + bias[(q * ST + s) * 32];
+                g4[q] = v + __shfl_xor(v, 32) + (bias ? bias[(q * ST + s) * 32] : 0.0f);
             }
             const float cn = fast_sigmoid(g4[1]) * cx[e][s] + fast_sigmoid(g4[0]) * fast_tanh(g4[2]);
             cx[e][s] = cn;
@@ -258,8 +272,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
     float4* HE1s = HE0s + KGH * 2 * EX;                  // [KGH][2][EX]
     float4* Wfc4 = HE1s + KGH * 2 * EX;                  // [OUT][KGH][2]
     RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc4 + OUT * KGH * 2);  // [RT]
-    float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [2][NW][NT][32]
-    float4* H0b = reinterpret_cast<float4*>(Bs + 2 * NW * NT * 32);      // BF: [KSB][64] bf16 A image of h0_t
+    // BF (bf16-ih variant): the layer-0 bias is FOLDED into the product - input slot k = NIN (one of the zero-padded columns of the x
+    // image) holds the constant 1, the weight column k = NIN holds b_ih0 + b_hh0 (lstm_pack_weights_bf16ih) - so the table holds layer 1
+    // only: the 6 KB that frees are what the second (lo) bf16 image of h0_t needs to fit a CU's 160 KB next to the fp32 images
+    constexpr int BL = BF ? 1 : 2;                                       // bias layers in LDS
+    constexpr bool HILO = BF && EX == 0;                                 // h0_t as bf16 hi + lo (VALU-row tiles: hi only, the E images take the room)
+    float* Bs = reinterpret_cast<float*>(rows_s + RT);                   // [BL][NW][NT][32]
+    float4* H0b = reinterpret_cast<float4*>(Bs + BL * NW * NT * 32);     // BF: [hi | lo][KSB][64] bf16 A images of h0_t (h = hi + lo)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -281,11 +300,15 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         Wfc4[i] = make_float4(wr[0], wr[2], wr[4], wr[6]);
     }
     if (tid < RT) rows_s[tid] = a.rows[slot0 + tid];
-    for (int i = tid; i < 2 * NW * NT * 32; i += NTHR) {
-        const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) % NW, layer = i / (32 * NT * NW);
+    for (int i = tid; i < BL * NW * NT * 32; i += NTHR) {
+        const int col = i & 31, n = (i >> 5) % NT, wv = (i / (32 * NT)) % NW, layer = BF ? 1 : i / (32 * NT * NW);
         Bs[i] = w.bias[layer * 4 * HID + (n / ST) * HID + wv * UW + (n % ST) * 32 + col];
     }
     __syncthreads();
+    if constexpr (BF) {                   // the constant-1 input column (main rows and extra rows); never written again: its owner has no element
+        if (tid < 32) reinterpret_cast<float*>(Xs)[a_frag_index(tid, w.NIN)] = 1.0f;
+        if (EX > 0 && tid < EX) reinterpret_cast<float*>(XEs)[e_frag_index<EXA>(tid, w.NIN)] = 1.0f;
+    }
 
     // ---- gather plan.  main rows: row = tid & 31, features j = (tid >> 5) + 8 i.
     //      extra rows: thread tid < EX*KX owns (e = tid / KX, j = tid % KX).
@@ -314,14 +337,16 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int j = (tid >> 5) + JSTEP * i;
-            goff[i] = j < KX ? plan(rd, j) : -2;          // -2: this thread has no element i
+            goff[i] = (j < KX && !(BF && j == w.NIN)) ? plan(rd, j) : -2;          // -2: this thread has no element i (BF: the constant-1 column)
             xdst[i] = a_frag_index(grow, j < KX ? j : 0);
         }
         row_md(rd, slot0 + grow, md, md_row);
     }
     int goffx = -1, xdstx = 0;
     NormMD mdx = {0.0f, 1.0f}; const NormMD* mdx_row = nullptr;
-    if (EX > 0 && tid < EX * KX) {
+    bool havex = EX > 0 && tid < EX * KX;
+    if (BF && havex && tid % KX == w.NIN) havex = false;       // the constant-1 column of the extra rows
+    if (havex) {
         const int e = tid / KX, j = tid % KX;
         const RowDesc rd = rows_s[32 + e];
         goffx = plan(rd, j);
@@ -336,7 +361,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (gbase[goff[i]] - m0.m) / m0.d : 0.0f;
-        if (EX > 0 && tid < EX * KX) {
+        if (havex) {
             const NormMD mx = mdx_row ? mdx_row[0] : mdx;
             XEf[xdstx] = goffx >= 0 ? (gbase[goffx] - mx.m) / mx.d : 0.0f;
         }
@@ -344,8 +369,8 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 
     // ---- register state -----------------------------------------------------------------------------
     // biases sit in LDS in (layer, wave, tile, column) order: Bs[((layer*NW + wave)*NT + n)*32 + col]
-    const float* __restrict__ bias_l0 = Bs + ((0 * NW + wave) * NT) * 32 + (lane & 31);
-    const float* __restrict__ bias_l1 = Bs + ((1 * NW + wave) * NT) * 32 + (lane & 31);
+    const float* __restrict__ bias_l0 = BF ? nullptr : Bs + ((0 * NW + wave) * NT) * 32 + (lane & 31);
+    const float* __restrict__ bias_l1 = Bs + (((BL - 1) * NW + wave) * NT) * 32 + (lane & 31);
     f32x2 c0[ST][8], c1[ST][8];          // cell state as register PAIRS (rows r, r + 1): operands of the packed cell update
     float cx0[EXA][ST], cx1[EXA][ST];
 #pragma unroll
@@ -439,7 +464,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
             if (md_row) mdn = md_row[t + 1];
 #pragma unroll
             for (int i = 0; i < NG; ++i) xr[i] = goff[i] >= 0 ? gbase[goff[i] + (t + 1) * gstep] : 0.0f;
-            if (EX > 0 && tid < EX * KX) {
+            if (havex) {
                 if (mdx_row) mdxn = mdx_row[t + 1];
                 xrx = goffx >= 0 ? gbase[goffx + (t + 1) * gstep] : 0.0f;
             }
@@ -451,7 +476,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = bias_l0[n * 32];
+            for (int r = 0; r < 16; ++r) acc[n][r] = BF ? 0.0f : bias_l0[n * 32];
 #pragma unroll
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
@@ -459,13 +484,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
         FSNP_STAMP(1);
         __syncthreads();
         FSNP_STAMP(2);
-        lstm_cell<ST, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
-        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);
+        lstm_cell<ST, UW, HILO ? KSB * 64 * 8 : 0>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
+        if (EX > 0) lstm_cell_extra<ST, UW, EX, NT>(accx, cx0, bias_l0, reinterpret_cast<float*>(HE0s), wave, lane);      // (BF: bias_l0 == nullptr)
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < NG; ++i)
                 if (goff[i] != -2) Xf[xdst[i]] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
-            if (EX > 0 && tid < EX * KX) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
+            if (havex) XEf[xdstx] = goffx >= 0 ? (xrx - mdxn.m) / mdxn.d : 0.0f;
         }
         if (t > 0) fc_store(t - 1);
         FSNP_STAMP(3);
@@ -480,7 +505,7 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
             for (int e = 0; e < EXA; ++e) accx[e][n] = 0.0f;
         }
         run_groups(acc, accx, H1s + lane, AEh1, KGH);
-        if constexpr (BF) mfma_groups_bf16<NT, EX>(acc, accx, breg, H0b + lane, HE0s, KSB, ws, gnext, KGT, lane);
+        if constexpr (BF) mfma_groups_bf16<NT, EX, HILO ? KSB * 64 : 0>(acc, accx, breg, H0b + lane, HE0s, KSB, ws, gnext, KGT, lane);
         else run_groups(acc, accx, H0s + lane, AEh0, KGH);
         FSNP_STAMP(5);
         __syncthreads();
@@ -546,8 +571,9 @@ static unsigned short host_bf16(float v) {
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// bias0 = b_ih0 + b_hh0 [4H]: packed as the weight column of input slot k = NIN, which the kernel feeds with the constant 1 (NIN < KX)
 void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0, const float* whh0, const float* wih1,
-                              const float* whh1, float* wpack) {
+                              const float* whh1, const float* bias0, float* wpack) {
     const int UW = H / NW, ST = UW / 32, NT = 4 * ST;
     const int KGX = KX / 8, KGH = H / 8, KG0 = KGX + KGH, KSB = H / 16, KGT = KG0 + KGH + KSB;
     for (int wv = 0; wv < NW; ++wv)
@@ -562,7 +588,7 @@ void lstm_pack_weights_bf16ih(int H, int NIN, int KX, int NW, const float* wih0,
                             float v = 0.0f;
                             if (g < KG0) {
                                 const int k = 8 * g + 2 * p + (lane >> 5);
-                                if (k < KX) { if (k < NIN) v = wih0[(size_t)wrow * NIN + k]; }
+                                if (k < KX) { if (k < NIN) v = wih0[(size_t)wrow * NIN + k]; else if (k == NIN) v = bias0[wrow]; }
                                 else v = whh0[(size_t)wrow * H + (k - KX)];
                             } else {
                                 const int k = 8 * (g - KG0) + 2 * p + (lane >> 5);
@@ -583,7 +609,7 @@ static void launch_lstm_ex(const LstmWeights& w, const LstmArgs& a, hipStream_t 
     constexpr int OUT = 2;
     constexpr int KGX = KX / 8, KGH = HID / 8, NT = 4 * (HID / NW / 32);
     const size_t smem = (size_t)(KGX + 2 * KGH) * (64 + 2 * EX) * 16 + (size_t)OUT * KGH * 2 * 16 +
-                        (32 + EX) * sizeof(RowDesc) + (size_t)2 * NW * NT * 32 * 4 + (BF ? (size_t)(HID / 16) * 64 * 16 : 0);
+                        (32 + EX) * sizeof(RowDesc) + (size_t)(BF ? 1 : 2) * NW * NT * 32 * 4 + (BF ? (size_t)(EX == 0 ? 2 : 1) * (HID / 16) * 64 * 16 : 0);
     LstmWeights wv = w;
     wv.wpack = BF ? (NW == 12 ? w.wpack_bf[1] : w.wpack_bf[0]) : (NW == 12 ? w.wpack12 : w.wpack);
     if constexpr (KX == 40 && HID == 384) {          // the phase-profile variant exists for the default sizes only

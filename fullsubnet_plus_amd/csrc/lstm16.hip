@@ -78,28 +78,31 @@ __device__ __forceinline__ unsigned short bf16_bits16(float v) {
 __host__ __device__ __forceinline__ int a16_index_bf16(int row, int k) {
     return (((k >> 5) * 64) + (((k >> 3) & 3) * 16) + row) * 8 + (k & 7);
 }
-template <int NT>
+// (round 6: the bf16 A image of h0_t is a hi + lo PAIR, ALO float4 apart - every weight fragment multiplies both: lstm.hip mfma_groups_bf16)
+template <int NT, int ALO>
 __device__ __forceinline__ void groups16_bf16(f32x4 (&acc)[NT], float4 (&b)[NT], const float4* __restrict__ A, int nsteps, const S16& ws,
                                               int& gnext, int groups_total) {
-    float4 a = A[0];
+    float4 a = A[0], al = A[ALO];
     for (int g = 0; g < nsteps; ++g) {
-        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64];
+        const float4 an = A[(g + 1 < nsteps ? g + 1 : g) * 64], aln = A[ALO + (g + 1 < nsteps ? g + 1 : g) * 64];
 #pragma unroll
         for (int n = 0; n < NT; n += 2) {
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b[n]), acc[n], 0, 0, 0);
             acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b[n + 1]), acc[n + 1], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, al), __builtin_bit_cast(bf16x8_16, b[n]), acc[n], 0, 0, 0);
+            acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, al), __builtin_bit_cast(bf16x8_16, b[n + 1]), acc[n + 1], 0, 0, 0);
             b[n] = w16load<NT>(ws, gnext, n);
             b[n + 1] = w16load<NT>(ws, gnext, n + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         gnext = (gnext + 1 == groups_total) ? 0 : gnext + 1;
-        a = an;
+        a = an; al = aln;
     }
 }
 
 // lane-local cell update: accumulator register r of tile (gate, s) <-> row 4 (lane >> 4) + r, unit wave UW + 16 s + (lane & 15)
 // (Hb != nullptr: h is also written, rounded to bf16, into the A image of the bf16 ih-GEMM segment)
-template <int SB, int UW>
+template <int SB, int UW, int HBLO = 0>
 __device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], float* __restrict__ Hs, int wave, int lane,
                                        unsigned short* __restrict__ Hb = nullptr) {
 #pragma unroll
@@ -115,7 +118,13 @@ __device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], flo
             c[s][r] = cc.x; c[s][r + 1] = cc.y;
             Hs[a16_index(4 * (lane >> 4) + r, k)] = h.x;
             Hs[a16_index(4 * (lane >> 4) + r + 1, k)] = h.y;
-            if (Hb) { Hb[a16_index_bf16(4 * (lane >> 4) + r, k)] = bf16_bits16(h.x); Hb[a16_index_bf16(4 * (lane >> 4) + r + 1, k)] = bf16_bits16(h.y); }
+            if (Hb) {           // hi + lo: h = hi + lo to ~16 mantissa bits (HBLO 2-byte elements apart)
+                const unsigned short hx = bf16_bits16(h.x), hy = bf16_bits16(h.y);
+                const int ix = a16_index_bf16(4 * (lane >> 4) + r, k), iy = a16_index_bf16(4 * (lane >> 4) + r + 1, k);
+                Hb[ix] = hx; Hb[iy] = hy;
+                Hb[HBLO + ix] = bf16_bits16(h.x - __uint_as_float((unsigned)hx << 16));
+                Hb[HBLO + iy] = bf16_bits16(h.y - __uint_as_float((unsigned)hy << 16));
+            }
         }
     }
 }
@@ -141,7 +150,7 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
     float* Wfc = reinterpret_cast<float*>(H1s + KGH * 64);               // [OUT][HID]
     RowDesc* rows_s = reinterpret_cast<RowDesc*>(Wfc + OUT * HID);       // [16]
     float* Bs = reinterpret_cast<float*>(rows_s + 16);                   // [2][NW][NT][16]
-    float4* H0b = reinterpret_cast<float4*>(Bs + 2 * NW * NT * 16);      // BF: [KSB][64] bf16 A image of h0_t
+    float4* H0b = reinterpret_cast<float4*>(Bs + 2 * NW * NT * 16);      // BF: [hi | lo][KSB][64] bf16 A images of h0_t
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -256,7 +265,7 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
         groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
-        cell16<SB, UW>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
+        cell16<SB, UW, KSB * 64 * 8>(acc, c0, reinterpret_cast<float*>(H0s), wave, lane, BF ? reinterpret_cast<unsigned short*>(H0b) : nullptr);
         if (have_next) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) Xf[xdst[i]] = goff[i] >= 0 ? (xr[i] - mdn.m) / mdn.d : 0.0f;
@@ -274,7 +283,7 @@ void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
         groups16<NT>(acc, breg, H1s + lane, KGH, ws, gnext, KGT);
 #pragma unroll
         for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[n]));
-        if constexpr (BF) groups16_bf16<NT>(acc, breg, H0b + lane, KSB, ws, gnext, KGT);
+        if constexpr (BF) groups16_bf16<NT, KSB * 64>(acc, breg, H0b + lane, KSB, ws, gnext, KGT);
         else groups16<NT>(acc, breg, H0s + lane, KGH, ws, gnext, KGT);
         __syncthreads();
         cell16<SB, UW>(acc, c1, reinterpret_cast<float*>(H1s), wave, lane);
@@ -365,7 +374,7 @@ static void launch_lstm16_bf(const LstmWeights& w, const LstmArgs& a, hipStream_
     constexpr int HID = 384, KX = 40, OUT = 2;
     constexpr int KGX = (KX + 15) / 16, KGH = HID / 16, NT = 4 * (HID / 4 / 16);
     const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * HID * 4 + 16 * sizeof(RowDesc) + (size_t)2 * 4 * NT * 16 * 4 +
-                        (BF ? (size_t)(HID / 32) * 64 * 16 : 0);
+                        (BF ? (size_t)2 * (HID / 32) * 64 * 16 : 0);
     auto kern = lstm2_fc16_kernel<HID, KX, OUT, BF>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });

@@ -216,9 +216,11 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap);
  * the sub-band LSTM (W_ih_l1 x h0_t, 32 % of the LSTM FLOPs) runs on v_mfma_f32_32x32x16_bf16 with bf16 operands
  * and fp32 accumulation; the recurrent GEMMs, layer 0, the cell and everything else stay fp32.  Only the one-tile-per-CU
  * kernel has this variant: sequences scheduled on the column-split kernels (small batches, the remainder tile of a
- * composite plan) are computed in fp32.  Tolerance of this
- * mode vs the fp32 reference: 2.5e-3 rel on the recurrent model, 6e-3 on the whole forward at B = 32 (measured 1.2e-3 /
- * 4.9e-3; tests/test_gpu_parity.py::test_bf16_ih_variant, ::test_bf16_ih_forward_b32).  Sub-band inputs of <= 40 features only. */
+ * composite plan) are computed in fp32.  h0_t enters the product as a bf16 hi + lo pair (round 6: two MFMAs per weight fragment), so
+ * the weights' rounding is the only bf16 error left.  Tolerance of this mode vs the fp32 reference: 2.5e-3 rel on the recurrent model,
+ * 4e-3 on the whole forward at B = 32 (measured 1.2e-3 / 2.75e-3 over four weight seeds and 2 s / 10 s clips, no growth with the clip
+ * length: profiles/r06_bf16_error.md; tests/test_gpu_parity.py::test_bf16_ih_variant, ::test_bf16_ih_forward_b32,
+ * ::test_bf16_ih_forward_seeds_and_long_clips).  Sub-band inputs of <= 39 features only (the layer-0 bias rides in a spare input column). */
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16);
 /* Synchronises the device and reports asynchronous kernel-side failures of earlier calls (today: a timed-out
  * inter-workgroup wait in a column-split LSTM kernel, whose workgroups must all be co-resident).  0 = none.

@@ -25,10 +25,16 @@ def _run(cmd, timeout=600):
 
 def test_bench_plain_gpus2_self_launches_two_ranks():
     res = _run([sys.executable, "bench.py", "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "2",
-                "--warmup", "1", "--batch", "4", "--no-cpu-baseline"])
+                "--warmup", "1", "--batch", "4", "--cpu-budget-s", "2", "--strong"])
     assert res.returncode == 0, res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
+    # round 6: the N > 1 line carries the CPU baseline (rank 0), the box object with one probe per rank, the median-of-three runs and
+    # the strong-scaling leg (one global batch of 8 on rank 0: scatter + forward + gather)
+    assert r["cpu_baseline"]["value"] > 0 and r["cirm_rel_err"] < 1e-3
+    assert len(r["ms_per_step_runs"]) == 3 and min(r["ms_per_step_runs"]) <= r["ms_per_step"] <= max(r["ms_per_step_runs"])
+    assert len(r["box"]["per_rank"]) == 2 and r["box"]["mfma_peak_tflops"] > 50
+    assert r["strong"]["global_batch"] == 8 and r["strong"]["value"] > 0
     assert r["n_gpus"] == 2 and r["dist"]["world_size_seen"] == 2
     assert r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
     assert r["dist"]["per_rank_ms_per_step"]["max"] >= r["dist"]["per_rank_ms_per_step"]["min"] > 0
@@ -43,9 +49,16 @@ def test_bench_eight_ranks_on_one_device():
     the N = 8 plumbing: self-launch, rendezvous, per-rank inputs, barrier-bracketed timing, max over ranks, the mask gather, and the
     roofline block of the slowest rank."""
     res = _run([sys.executable, "bench.py", "--gpus", "8", "--same-device", "--dist-backend", "gloo", "--steps", "2",
-                "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-alt"], timeout=900)
+                "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-alt", "--strong", "--repeats", "1", "--probe-ms", "5"], timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    # round 6: the same launch also times BASELINE.json configs[2] as worded - ONE global batch on rank 0, scatter + forward + gather - next
+    # to the weak-scaling headline, and every rank reports what its box held (here: eight probes of the one device)
+    st = r["strong"]
+    assert st["global_batch"] == 16 and st["ms_per_step"] > 0 and st["value"] > 0 and st["via_host_memory"] is True
+    assert st["scatter_ms"] > 0 and st["gather_ms"] > 0 and st["forward_ms_slowest_rank"] > 0
+    assert st["bytes_scattered_per_step"] == 16 * r["config"]["frames_per_clip"] * 257 * 8
+    assert len(r["box"]["per_rank"]) == 8 and all(p["mfma_tflops_after"] > 0 for p in r["box"]["per_rank"])
     assert r["n_gpus"] == 8 and r["dist"]["world_size_seen"] == 8 and r["config"]["global_batch"] == 16
     assert r["dist"]["gathered_shape"][0] == 16 and 0 <= r["dist"]["roofline_of_rank"] < 8
     assert r["dist"]["per_rank_ms_per_step"]["max"] >= r["dist"]["per_rank_ms_per_step"]["min"] > 0

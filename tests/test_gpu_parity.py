@@ -547,9 +547,38 @@ def test_bf16_ih_variant(n, cus):
     assert 1e-6 < err < 2.5e-3, err          # must differ from fp32 (the mode is really on) and stay inside the stated bound
 
 
+BF16_FORWARD_TOL = 4e-3     # whole forward under bf16_ih vs fp32 (profiles/r06_bf16_error.md: worst of six seed / clip-length rows 2.75e-3)
+
+
+@pytest.mark.parametrize("wseed,iseed,seconds", [(1, 101, 2.0), (2, 102, 2.0), (3, 103, 2.0), (0, 100, 10.0), (1, 101, 10.0)])
+def test_bf16_ih_forward_seeds_and_long_clips(wseed, iseed, seconds):
+    """configs[4], owning the tolerance: the bound is asserted on FOUR weight seeds (with test_bf16_ih_forward_b32's seed 0)
+    and on 10 s clips - the error must not grow with the clip length (the forget gates damp earlier steps' quantisation noise).  Round 5's
+    arithmetic (h0_t as ONE bf16 image) measured 2.4e-3 ... 6.07e-3 over these rows, i.e. above its own 6e-3 bound on one seed; with h0_t as
+    bf16 hi + lo (round 6) the worst row is 2.75e-3.  Every utterance against the fp32 HIP forward, utterances 0 / 15 / 31 against the fp32
+    oracle."""
+    sd = make_state_dict(wseed, "default")
+    mag, real, imag = make_inputs(32, seconds, iseed)
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    ins = _cuda((mag, real, imag))
+    ref = m(*ins).cpu().numpy()
+    m.set_precision("bf16_ih")
+    got = m(*ins).cpu().numpy()
+    per_utt = [rel_err(got[b:b + 1], ref[b:b + 1]) for b in range(32)]
+    T = ref.shape[-1]
+    halves = [rel_err(got[..., :T // 2], ref[..., :T // 2]), rel_err(got[..., T // 2:], ref[..., T // 2:])]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    spots = {b: rel_err(got[b:b + 1], fsnp_torch.forward_full(sd, mag[b:b + 1], real[b:b + 1], imag[b:b + 1]).numpy()) for b in (0, 15, 31)}
+    _record(f"bf16_ih_forward_w{wseed}_{seconds:g}s", rel_vs_fp32_hip_max=max(per_utt), worst_utt=int(np.argmax(per_utt)), first_half=halves[0],
+            second_half=halves[1], rel_vs_oracle=spots)
+    assert 1e-6 < max(per_utt) < BF16_FORWARD_TOL, per_utt
+    assert max(spots.values()) < BF16_FORWARD_TOL, spots
+    assert halves[1] < 1.5 * halves[0] + 1e-4, halves                 # no accumulation along the clip
+
+
 def test_bf16_ih_forward_b32():
     """BASELINE configs[4] at its per-GPU shape (batch 32 x 2 s), tolerance re-stated against the fp32 ORACLE (and its fp64
-    run) on every utterance: bound 6e-3 rel (measured 4.9e-3 against the fp32 HIP path in round 2)."""
+    run) on every utterance: bound 4e-3 rel (round 6: h0_t as bf16 hi + lo - measured 2.75e-3; round 5: 5.8e-3 of 6e-3)."""
     sd = make_state_dict(0, "default")
     mag, real, imag = make_inputs(32, 2.0, 100)
     m = _model(DEFAULT_MODEL_ARGS, sd, "full")
@@ -569,8 +598,8 @@ def test_bf16_ih_forward_b32():
             e64[b] = rel_err(got[b:b + 1], want64)
     _record("bf16_ih_forward_b32", rel_vs_fp32_hip=err, rel_vs_oracle_max=max(e32.values()), rel_vs_oracle_worst_utt=max(e32, key=e32.get),
             rel_vs_fp64_max=max(e64.values()), plan=[c["kernel"] + f" x{c['sequences']}" for c in m.describe_plan(32)])
-    assert 1e-6 < err < 6e-3, err            # must differ from fp32 (the mode is really on)
-    assert max(e32.values()) < 6e-3 and max(e64.values()) < 6e-3, (e32, e64)
+    assert 1e-6 < err < BF16_FORWARD_TOL, err            # must differ from fp32 (the mode is really on)
+    assert max(e32.values()) < BF16_FORWARD_TOL and max(e64.values()) < BF16_FORWARD_TOL, (e32, e64)
     # the plan keeps the chip-filling chunk on the one-tile-per-CU kernel (whose bf16 round is 0.75 of its fp32 round): a planner that
     # prices it at the fp32 cost trades it for half-tile + column-split launches (27.6 instead of 20.9 ms: profiles/r05_bench_configs.md)
     plan = m.describe_plan(32)
@@ -606,7 +635,7 @@ def test_bf16_ih_on_the_half_tile_kernel(n):
 
 def test_bf16_ih_forward_parity_mode_b32_and_b16():
     """... and through the whole forward: the reference's literal batched call at B = 32 (drop_band: 4096 sequences = 256 half tiles) and
-    B = 16 in full mode (4112 = 4096 + 16) against the fp32 ORACLE on every utterance, bound 6e-3 as at the chip-filling batch;
+    B = 16 in full mode (4112 = 4096 + 16) against the fp32 ORACLE on every utterance, bound 4e-3 as at the chip-filling batch;
     describe_plan reports the half-tile chunk as bf16 and the 16-sequence column-split chunk as fp32."""
     sd = make_state_dict(0, "default")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -623,7 +652,7 @@ def test_bf16_ih_forward_parity_mode_b32_and_b16():
         want = (fsnp_torch.forward(sd, mag, real, imag) if mode == "parity" else fsnp_torch.forward_full(sd, mag, real, imag)).numpy()
         e_ref, e_bf = rel_err(ref, want), rel_err(got, want)
         _record(f"bf16_ih_forward_{mode}_b{B}", rel_fp32=e_ref, rel_bf16=e_bf, plan=[c["kernel"] + f" x{c['sequences']} [{c['precision']}]" for c in plan])
-        assert e_ref < TOL and 1e-6 < rel_err(got, ref) and e_bf < 6e-3, (e_ref, e_bf)
+        assert e_ref < TOL and 1e-6 < rel_err(got, ref) and e_bf < BF16_FORWARD_TOL, (e_ref, e_bf)
 
 
 def test_batch2_raises_like_reference():

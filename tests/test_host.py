@@ -302,8 +302,9 @@ def test_lstm_hot_loops_have_no_scratch_or_drain():
         assert len(loops) == 3 or (key.endswith("_BF1") and len(loops) == 2), (key, loops)
         for i, l in enumerate(loops):
             assert l["scratch"] == 0, (key, l)
-            if key.endswith("_BF1") and i == 2:       # bf16 segment: one MFMA and one refill per tile and k-step
-                assert l["gload"] == l["mfma"], (key, l)
+            if key.endswith("_BF1") and i == 2:       # bf16 segment: one refill per tile and k-step and TWO MFMAs (hi and lo image of h0, round 6);
+                hilo = "_EX0_" in key                 # tiles with VALU rows keep the hi image only (their E images take the LDS the lo image needs)
+                assert (2 if hilo else 1) * l["gload"] == l["mfma"], (key, l)
                 continue
             assert l["mfma"] % 16 == 0 and l["gload"] * 4 == l["mfma"], (key, l)
             if "_NW4_" in key and ("_EX0_" in key or "_EX1_" in key):   # the production fp32 kernels
@@ -751,11 +752,11 @@ def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
     assert len(res) >= 1
     for key, loops in res.items():
         assert len(loops) >= 3, (key, loops)
-        bf = "ELb1EEEv" in key                       # the bf16 ih-GEMM instantiation (round 4): its last loop is 24 bf16 MFMAs per k-step of 32
-        for l in loops:
-            assert l["gload"] == 24 and (l["mfma"] == 96 or (bf and l["mfma"] == 24)), (key, l)
+        bf = "ELb1EEEv" in key                       # the bf16 ih-GEMM instantiation (round 4): its last loop is 2 x 24 bf16 MFMAs per k-step of 32
+        for l in loops:                              # (round 6: every weight fragment multiplies the hi AND the lo bf16 image of h0)
+            assert l["gload"] == 24 and (l["mfma"] == 96 or (bf and l["mfma"] == 48)), (key, l)
             assert l["scratch"] == 0 and l["drain"] == 0 and l["acc_moves"] == 0, (key, l)
-        assert sum(1 for l in loops if l["mfma"] == 24) == (1 if bf else 0), (key, loops)
+        assert sum(1 for l in loops if l["mfma"] == 48) == (1 if bf else 0), (key, loops)
 
 
 # ---------------------------------------------------------------- cooperative kernel weight stream (csrc/lstm_coop.hip)
