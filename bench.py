@@ -72,6 +72,9 @@ def parse():
                     help="N > 1: ALSO time BASELINE.json configs[2] as worded - ONE global batch of batch x N utterances lives on rank 0; "
                          "a step = scatter the STFT shards + forward + gather the masks to rank 0 (reported as `strong`, next to the "
                          "weak-scaling number, which stays the headline)")
+    ap.add_argument("--verify-sample", type=int, default=None,
+                    help="fsnp_set_verify_sample for every loop (default: the module's policy - 16 in the drop-in loop's error_check='sync', off "
+                         "in the deferred loops); 0 = off everywhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -259,6 +262,7 @@ def main():
     model = model.to(dev).eval()
     model.batch_mode = args.mode
     model.error_check = "deferred"       # no host wait per forward; poll_errors() below, after the final synchronisation
+    model.verify_sample_every = args.verify_sample
 
     B = args.batch
     cpu_in = make_inputs(B, args.seconds, 1000 + rank)           # synthetic, per-rank seed

@@ -72,7 +72,9 @@ SYMBOLS = {
     "fsnp_flush": (c_i32, [c_vp, c_vp]),
     "fsnp_watch_weights": (c_i32, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), c_i32, c_i32, c_vp]),
     "fsnp_set_verify": (c_i32, [c_vp, c_i32]),
+    "fsnp_set_verify_sample": (c_i32, [c_vp, c_i32]),
     "fsnp_verify_count": (c_i64, [c_vp]),
+    "fsnp_debug_verify_sample_stats": (c_i32, [c_vp, ctypes.POINTER(c_i64 * 3)]),
     "fsnp_debug_corrupt_exchange": (c_i32, [c_vp, c_i32]),
     "fsnp_abi_version": (c_i32, []),
     "fsnp_config_size": (c_i32, []),

@@ -56,16 +56,21 @@ int take_device_errors(fsnp_handle* h, const char* where) {
         // where the two kernels first disagreed: a 64-bit key in DEVICE memory (utterance << 44 | bin << 24 | frame; atomic min), read
         // back here - on the error path only - once the comparing kernel has finished
         unsigned long long key = ~0ull;
-        if (h->verify_key) {
+        if (h->verify_key || h->verify_key_sampled) {
             fsnp::DeviceGuard guard(h->device);
             (void)hipDeviceSynchronize();
-            if (hipMemcpy(&key, h->verify_key, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); key = ~0ull; }
+            for (unsigned long long* src : {h->verify_key, h->verify_key_sampled}) {
+                unsigned long long k = ~0ull;
+                if (src && hipMemcpy(&k, src, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); k = ~0ull; }
+                if (k < key) key = k;
+            }
         }
         char at[160];
         if (key != ~0ull) snprintf(at, sizeof(at), ", first at utterance %llu, bin %llu, frame %llu", key >> 44, (key >> 24) & 0xFFFFFull, key & 0xFFFFFFull);
         else at[0] = 0;
         msg += std::string(rc ? " ALSO:" : "") + " exchange verification failed (fsnp_set_verify): the column-split kernels and the exchange-free "
-               "kernel disagree" + at + "; the result of that forward is invalid.  FSNP_LSTM_COOP=0 avoids the column-split kernels.";
+               "kernel disagree" + at + "; the result of that forward is invalid (a sampled check - fsnp_set_verify_sample - reports a forward "
+               "of up to a few calls ago).  FSNP_LSTM_COOP=0 avoids the column-split kernels.";
         if (!rc) rc = 7;
     }
     if (bits & kErrStaleWeights) {
@@ -714,6 +719,118 @@ static int verify_pass(fsnp_handle* h, const SbPlan& plan, const Dims& d, int mo
     return 0;
 }
 
+// ---- fsnp_set_verify_sample: ONE row tile of a column-split launch, recomputed off the critical path.
+// The sampled tile's normalised input and the mask values its launch wrote are SNAPSHOT on the launch's own stream (two tiny kernels);
+// the recomputation - the exchange-free half-tile kernel on the snapshot, two workgroups, as long as a whole round: ~13 ms at 2 s clips -
+// and the comparison run on a stream of their own and touch nothing but private buffers, so the caller may free / overwrite the mask and
+// later forwards may rebuild the workspace meanwhile.  A mismatch flags the handle (code 7) whenever it is found: the report names the
+// sampled forward's (utterance, bin, frame), the call that notices it is a later one.
+__global__ __launch_bounds__(256) void vs_copy_kernel(const float* __restrict__ out, const RowDesc* __restrict__ rows, RowDesc* __restrict__ rows_copy,
+                                                      float* __restrict__ snap, int num_slots, int T, int OC, long stride_o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < num_slots) rows_copy[i] = rows[i];
+    if (i >= num_slots * OC * T) return;
+    const int t = i % T, o = (i / T) % OC, slot = i / (OC * T);
+    const RowDesc rd = rows[slot];
+    snap[i] = rd.valid ? out[(size_t)rd.out_off + (size_t)o * stride_o + t] : 0.0f;
+}
+__global__ __launch_bounds__(256) void vs_compare_kernel(const float* __restrict__ snap, const float* __restrict__ ref, const RowDesc* __restrict__ rows,
+                                                         int num_slots, int T, int OC, unsigned* err_host, unsigned long long* first_key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_slots * OC * T) return;
+    const int t = i % T, slot = i / (OC * T);
+    const RowDesc rd = rows[slot];
+    if (!rd.valid) return;
+    const float a = snap[i], b = ref[i];                        // ref: the dense run's [slot][o][t]
+    if (!(fabsf(a - b) <= 1e-4f + 1e-3f * fabsf(b))) {
+        const unsigned long long key = ((unsigned long long)(unsigned)rd.b << 44) | ((unsigned long long)((unsigned)rd.f & 0xFFFFFu) << 24) |
+                                       (unsigned long long)((unsigned)t & 0xFFFFFFu);
+        __hip_atomic_fetch_min(first_key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(err_host, kErrVerify, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// a plan that can be sampled: column-split launches only, each leaving a CU free ON EVERY XCD.  The recomputation's two workgroups own
+// their CUs for ~13 ms (one each on two XCDs), and the dispatcher deals a launch's workgroups to the XCDs by index, not by room: B = 8's
+// 252-workgroup launches put 32 on some XCDs - the 32nd waited for the sample to end and the launch (all of whose workgroups must be
+// resident) with it: +7.7 ms per sampled forward (profiles/r06_verify_sample.md).  Such plans (B = 3, B = 8) are not sampled.
+static bool plan_can_be_sampled(const fsnp_handle* h, const SbPlan& plan) {
+    if (plan.chunks.empty() || !h->lstm16_ok || h->num_cus_real % 8 != 0) return false;
+    const int cpx = h->num_cus_real / 8;
+    for (const SbChunk& c : plan.chunks) {
+        const bool exch = c.kind == 1 || c.kind == 2 || c.kind == 8 || c.kind == 9;
+        if (!exch || c.rps != 32) return false;
+        const int S = c.kind == 8 ? h->H / 16 : (c.kind == 1 || c.kind == 9) ? h->H / c.units : h->H / 128;
+        const int T = c.kind == 2 ? c.groups : c.num_tiles;
+        const int local = xcd_local_blocks_per_xcd(S, T, cpx);
+        const int per_xcd = local <= cpx ? local : cdiv(T * S, 8);       // (launch_sb_lstm: XCD-local placement where it fits, else round robin)
+        if (per_xcd > cpx - 1) return false;
+    }
+    return true;
+}
+// `st` = the stream the plan's launches were enqueued on (the caller's, or the side stream in the pipelined loop)
+static int verify_sample(fsnp_handle* h, const SbPlan& plan, const Dims& d, const LstmArgs& a, const SubbandBuffers& sbuf, hipStream_t st) {
+    if (h->vs_busy) {
+        const hipError_t q = hipEventQuery(h->ev_vs_done);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); h->vs_skipped += 1; return 0; }      // the previous sample is still being recomputed
+        h->vs_busy = false;
+    }
+    const long long n = h->vs_runs;
+    const SbChunk& c = plan.chunks[(size_t)(n % (long long)plan.chunks.size())];
+    const int tile = (int)((n / (long long)plan.chunks.size()) % c.num_tiles), nslots = 32;
+    const int OC = h->cfg.output_size, T = d.T, Tp = d.Tp, NIN = h->NIN;
+    const size_t x_b = align_up((size_t)nslots * Tp * NIN * 4, 256), o_b = align_up((size_t)nslots * OC * T * 4, 256);
+    const size_t r_b = align_up((size_t)nslots * sizeof(RowDesc), 256);
+    const size_t need = x_b + 2 * o_b + 2 * r_b + 256;
+    if (!h->vs_stream) {
+        FSNP_HIP_CHECK(hipStreamCreateWithFlags(&h->vs_stream, hipStreamNonBlocking));
+        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_vs_snap, hipEventDisableTiming));
+        FSNP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_vs_done, hipEventDisableTiming));
+    }
+    if (need > h->vs_bytes) {                 // (no sample in flight here: the buffer is idle)
+        if (h->vs_buf) FSNP_HIP_CHECK(hipFreeAsync(h->vs_buf, st));
+        h->vs_buf = nullptr; h->vs_bytes = 0;
+        FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&h->vs_buf), need, st));
+        h->vs_bytes = need;
+    }
+    float* vx = reinterpret_cast<float*>(h->vs_buf);
+    float* vsnap = reinterpret_cast<float*>(h->vs_buf + x_b);
+    float* vref = reinterpret_cast<float*>(h->vs_buf + x_b + o_b);
+    RowDesc* vrows_src = reinterpret_cast<RowDesc*>(h->vs_buf + x_b + 2 * o_b);
+    RowDesc* vrows = reinterpret_cast<RowDesc*>(h->vs_buf + x_b + 2 * o_b + r_b);
+    unsigned long long* vkey = reinterpret_cast<unsigned long long*>(h->vs_buf + x_b + 2 * o_b + 2 * r_b);
+    const size_t slot0 = (size_t)c.slot0 + (size_t)tile * c.rps;
+    // ---- snapshot, behind the launches it samples
+    SbGatherArgs ga{};
+    ga.att_mag = a.att_mag; ga.fb_rel = a.fb_rel; ga.fb_branch_stride = a.fb_branch_stride;
+    ga.rows = a.rows + slot0; ga.md_utt = a.md_utt; ga.md_row = a.md_row ? a.md_row + slot0 * Tp : nullptr;
+    ga.x = vx; ga.xstride = NIN;
+    ga.num_slots = nslots; ga.Tp = Tp; ga.FP = d.FP; ga.F = d.F; ga.NSBN = h->cfg.sb_num_neighbors; ga.NIN = NIN; ga.NFBN = h->cfg.fb_num_neighbors;
+    launch_sb_gather(ga, st);
+    const int nout = nslots * OC * T;
+    hipLaunchKernelGGL(vs_copy_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, a.out, a.rows + slot0, vrows_src, vsnap, nslots, T, OC, a.out_stride_o);
+    FSNP_HIP_CHECK(hipMemsetAsync(vkey, 0xFF, 8, st));
+    FSNP_HIP_CHECK(hipEventRecord(h->ev_vs_snap, st));
+    // ---- recomputation and comparison, on their own stream
+    hipStream_t vs = h->vs_stream;
+    FSNP_HIP_CHECK(hipStreamWaitEvent(vs, h->ev_vs_snap, 0));
+    hipLaunchKernelGGL(build_rows_kernel, dim3(1), dim3(256), 0, vs, vrows, nslots, 2, 16, 1, T, 0, 0, 1, 1, 0, 2, OC);
+    LstmArgs va{};
+    va.rows = vrows; va.dense = vx; va.dense_stride = NIN; va.out = vref; va.out_stride_o = T;
+    va.num_rows = nslots; va.num_tiles = 2; va.Tp = Tp; va.LA = d.LA; va.FP = 0; va.F = 1; va.NSBN = 0; va.act = h->cfg.sb_act;
+    va.coop_own_cu = 1;                      // its two workgroups share the chip with the following forwards: they own their CUs (lstm16.hip: OWN)
+    const int keep_bf16 = h->lw.ih_bf16;     // the column-split kernels are fp32 in every precision mode: so is their check
+    h->lw.ih_bf16 = 0;
+    launch_lstm16(h->lw, va, vs);
+    h->lw.ih_bf16 = keep_bf16;
+    hipLaunchKernelGGL(vs_compare_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, vs, vsnap, vref, vrows_src, nslots, T, OC, h->d_err, vkey);
+    FSNP_HIP_CHECK(hipGetLastError());
+    FSNP_HIP_CHECK(hipEventRecord(h->ev_vs_done, vs));
+    h->vs_busy = true;
+    h->vs_runs += 1;
+    h->verify_key_sampled = vkey;
+    return 0;
+}
+
 }  // namespace fsnp
 
 extern "C" {
@@ -869,6 +986,10 @@ void fsnp_destroy(fsnp_handle* h) {
     drop_weight_watch(h);
     if (h->verify_out) (void)hipFree(h->verify_out);
     if (h->verify_key) (void)hipFree(h->verify_key);
+    if (h->vs_buf) (void)hipFree(h->vs_buf);
+    if (h->vs_stream) (void)hipStreamDestroy(h->vs_stream);
+    if (h->ev_vs_snap) (void)hipEventDestroy(h->ev_vs_snap);
+    if (h->ev_vs_done) (void)hipEventDestroy(h->ev_vs_done);
     if (h->d_err) (void)hipHostFree(h->d_err);
     for (auto& r : h->timing_recs)
         for (auto& e : r.e) (void)hipEventDestroy(e);
@@ -1067,6 +1188,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
     bool defer_all = false;
     // fsnp_set_verify: every Nth forward with a column-split launch is checked against the exchange-free kernel (nothing deferred then)
     const bool verify_now = h->verify_every > 0 && plan_has_exchange(plan) && (h->verify_calls++ % h->verify_every) == 0;
+    // fsnp_set_verify_sample: every Nth forward of a plan made of column-split launches only, one row tile is recomputed off the critical path
+    const bool sample_now = !verify_now && h->vs_every > 0 && plan_can_be_sampled(h, plan) && (h->vs_calls++ % h->vs_every) == 0;
     a.coop_corrupt = h->corrupt_exchange; h->corrupt_exchange = 0;
     if (verify_now) {
         launch_sb_lstm(h, plan, a, fptr(w.coop_hx), bar, abort_word, s, h->timing ? rec.e[3] : nullptr);
@@ -1099,6 +1222,10 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         if (h->timing) FSNP_HIP_CHECK(hipEventRecord(rec.e[2], h->side_stream));
         FSNP_HIP_CHECK(hipEventRecord(h->ev_side[slot], h->side_stream));
         h->side_used[slot] = true;
+    }
+    if (sample_now) {        // (a plan of column-split launches only runs on ONE stream: the side stream when the pipelined loop defers it, else s)
+        if (const int vr = verify_sample(h, plan, d, a, sbuf, defer_all ? h->side_stream : s)) return vr;
+        if (defer_all) FSNP_HIP_CHECK(hipEventRecord(h->ev_side[slot], h->side_stream));       // the snapshot reads this workspace half too
     }
     FSNP_HIP_CHECK(hipGetLastError());
     h->last_ws = w; h->last_dims = d; h->have_last = true; h->last_base = base;
@@ -1413,7 +1540,20 @@ int fsnp_set_verify(fsnp_handle* h, int32_t every) {
     return 0;
 }
 
+int fsnp_set_verify_sample(fsnp_handle* h, int32_t every) {
+    if (!h || every < 0) { set_error("fsnp_set_verify_sample: every must be >= 0 (0 = off)"); return 1; }
+    if (every == h->vs_every) return 0;            // (idempotent: a binding may state its setting in front of every forward)
+    h->vs_every = every; h->vs_calls = 0;
+    return 0;
+}
+
 int64_t fsnp_verify_count(const fsnp_handle* h) { return h ? (int64_t)h->verify_runs : -1; }
+
+int fsnp_debug_verify_sample_stats(const fsnp_handle* h, int64_t out[3]) {
+    if (!h || !out) { set_error("fsnp_debug_verify_sample_stats: null argument"); return 1; }
+    out[0] = h->vs_runs; out[1] = h->vs_skipped; out[2] = h->vs_calls;
+    return 0;
+}
 
 int fsnp_debug_corrupt_exchange(fsnp_handle* h, int32_t step) {
     if (!h || step < 0) { set_error("fsnp_debug_corrupt_exchange: step must be >= 0 (0 = off)"); return 1; }

@@ -112,8 +112,18 @@ struct fsnp_handle {
     int verify_every = 0;
     long long verify_calls = 0, verify_runs = 0;
     float* verify_out = nullptr;             // scratch mask of the verification pass (stream-ordered allocation)
+    unsigned long long* verify_key_sampled = nullptr;   // the same key of the sampled check (inside vs_buf)
     unsigned long long* verify_key = nullptr; // device: smallest (utterance << 44 | bin << 24 | frame) at which a verification pass disagreed
     size_t verify_bytes = 0;
+    // fsnp_set_verify_sample (round 6): every Nth forward whose plan is column-split launches only, ONE row tile of one of them (they come
+    // up in turn) is recomputed on the exchange-free half-tile kernel from a snapshot, on a stream of its own, beside the forwards that follow
+    int vs_every = 0;
+    long long vs_calls = 0, vs_runs = 0, vs_skipped = 0;
+    hipStream_t vs_stream = nullptr;
+    hipEvent_t ev_vs_snap = nullptr, ev_vs_done = nullptr;
+    bool vs_busy = false;                    // ev_vs_done has been recorded and not yet seen complete
+    unsigned char* vs_buf = nullptr;         // snapshot + reference buffers (private: nothing a later forward or the caller touches)
+    size_t vs_bytes = 0;
     int corrupt_exchange = 0;                // fsnp_debug_corrupt_exchange: flip one word of the next column-split launch's exchange (test hook)
     int lstm_waves = 0;   // 0 = auto: 12 waves when the tile plan uses VALU rows, else 4
 

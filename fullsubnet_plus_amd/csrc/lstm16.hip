@@ -131,9 +131,15 @@ __device__ __forceinline__ void cell16(f32x4 (&acc)[4 * SB], f32x4 (&c)[SB], flo
 
 }  // namespace
 
-template <int HID, int KX, int OUT, bool BF>
+// OWN (the sampled exchange verification's two-workgroup launch beside other forwards, fsnp_set_verify_sample): the kernel CLAIMS the whole
+// register file of its SIMDs.  Its waves stream fp32 MFMAs back to back, and a wave of another kernel that shares such a SIMD is starved
+// (measured ~10 x): with ~300 registers allocated, the small full-band kernels of the following forwards DID land beside it
+// and every launch of theirs waited for those stragglers (tcn_dwconv_kernel 7.7 -> 110 us, prologue 16 -> 400 us while a sample ran:
+// profiles/r06_verify_sample.md).  Touching v255 / a255 makes the kernel descriptor ask for all 512 registers: nothing else fits the CU.
+template <int HID, int KX, int OUT, bool BF, bool OWN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void lstm2_fc16_kernel(LstmWeights w, LstmArgs a) {
+    if constexpr (OWN) asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, v255" ::: "v255", "a255");
     static_assert(OUT == 2, "FC lane mapping assumes output_size == 2");
     constexpr int NW = 4, UW = HID / NW, SB = UW / 16, NT = 4 * SB;      // 96 units, 6 blocks of 16, 24 tiles per wave
     static_assert(UW % 16 == 0 && HID % 128 == 0, "tile shapes");
@@ -375,11 +381,20 @@ static void launch_lstm16_bf(const LstmWeights& w, const LstmArgs& a, hipStream_
     constexpr int KGX = (KX + 15) / 16, KGH = HID / 16, NT = 4 * (HID / 4 / 16);
     const size_t smem = (size_t)(KGX + 2 * KGH) * 64 * 16 + (size_t)OUT * HID * 4 + 16 * sizeof(RowDesc) + (size_t)2 * 4 * NT * 16 * 4 +
                         (BF ? (size_t)2 * (HID / 32) * 64 * 16 : 0);
+    LstmWeights wv = w;
+    wv.wpack = BF ? w.wpack16_bf : w.wpack16;
+    if constexpr (!BF) {
+        if (a.coop_own_cu != 0) {          // a launch that shares the chip with other kernels: own the CUs it runs on (see OWN above)
+            auto ko = lstm2_fc16_kernel<HID, KX, OUT, false, true>;
+            static PerDeviceOnce own_once;
+            own_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+            hipLaunchKernelGGL(ko, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
+            return;
+        }
+    }
     auto kern = lstm2_fc16_kernel<HID, KX, OUT, BF>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
-    LstmWeights wv = w;
-    wv.wpack = BF ? w.wpack16_bf : w.wpack16;
     hipLaunchKernelGGL(kern, dim3(a.num_tiles), dim3(256), smem, s, wv, a);
 }
 // one 16-row tile per workgroup, any number of tiles (rounds of num_CUs run back to back); w.ih_bf16: the bf16 ih-GEMM variant

@@ -176,6 +176,10 @@ class _HipModel(nn.Module):
         self.error_check = "sync"
         # fsnp_watch_weights: every Nth forward starts with one fingerprint kernel over the parameters' storage (1 = every forward)
         self.weight_watch_every = 1
+        # fsnp_set_verify_sample: every Nth forward of a small batch (a plan of column-split launches only) has one row tile recomputed on
+        # an exchange-free kernel beside the following forwards.  None = the policy's default: 16 under error_check="sync", off under
+        # "deferred" (throughput loops decide for themselves); an int = that value whatever the policy
+        self.verify_sample_every = None
         self._pipeline = False
         self._hip = _HipState()
 
@@ -295,6 +299,7 @@ class _HipModel(nn.Module):
                 cfg = self._config()
                 _lib.check(lib.fsnp_create(ctypes.byref(cfg), ctypes.byref(hp)), "fsnp_create")
             st.handle, st.device, st.packed_key = hp, device, None
+            self.__dict__.pop("_vs_applied", None)
             if self.__dict__.get("_verify_every"):
                 _lib.check(lib.fsnp_set_verify(hp, int(self.__dict__["_verify_every"])), "fsnp_set_verify")
         key = self._weights_key()
@@ -363,6 +368,11 @@ class _HipModel(nn.Module):
         for t in ins:
             assert t.device == device
         lib = self._ensure_handle(device)
+        vs = self.verify_sample_every
+        vs = (16 if self.error_check == "sync" else 0) if vs is None else int(vs)
+        if vs != self.__dict__.get("_vs_applied"):
+            if lib.fsnp_set_verify_sample(self._handle, vs) == 0:
+                self.__dict__["_vs_applied"] = vs
         out_f = num_freqs // self.num_groups_in_drop_band if parity else num_freqs
         standalone = global_batch is None
         out = torch.empty((gb if parity else batch_size, self.output_size, out_f, num_frames), dtype=torch.float32, device=device)
@@ -466,6 +476,12 @@ class _HipModel(nn.Module):
     def verify_count(self):
         """-> verification passes run so far (fsnp_verify_count)."""
         return int(_lib.load().fsnp_verify_count(self._handle))
+
+    def verify_sample_stats(self):
+        """-> {"samples", "skipped", "eligible_forwards"} of the sampled exchange verification (fsnp_set_verify_sample)."""
+        out = (ctypes.c_int64 * 3)()
+        _lib.check(_lib.load().fsnp_debug_verify_sample_stats(self._handle, ctypes.byref(out)), "fsnp_debug_verify_sample_stats")
+        return {"samples": int(out[0]), "skipped": int(out[1]), "eligible_forwards": int(out[2])}
 
     def debug_corrupt_exchange(self, step):
         """Test hook (fsnp_debug_corrupt_exchange): the next forward's column-split launches publish one wrong h0 value at `step` - 1."""

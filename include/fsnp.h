@@ -19,7 +19,7 @@
  * All device work is enqueued on the caller's HIP stream; no device synchronisation
  * happens inside fsnp_forward.
  *
- * This header is the surface a maintainer of the reference binds (29 entry points).  Planner introspection, per-kernel timing,
+ * This header is the surface a maintainer of the reference binds (31 entry points).  Planner introspection, per-kernel timing,
  * stage read-back, calibration probes and every test / tuning hook live in fsnp_debug.h (same library, same ABI version).
  */
 #ifndef FSNP_H
@@ -265,6 +265,17 @@ int fsnp_flush(fsnp_handle* h, void* hip_stream);
  * fsnp_verify_count = verification passes run so far.  0 = off (default; FSNP_VERIFY_EVERY=N at fsnp_create time sets it). */
 int fsnp_watch_weights(fsnp_handle* h, const void* const* dev_ptrs, const int64_t* numels, int32_t n, int32_t every, void* hip_stream);
 int fsnp_set_verify(fsnp_handle* h, int32_t every);
+/* The same check cheap enough to leave on (round 6): with every = N > 0, every Nth forward whose plan consists of column-split launches
+ * ONLY (small batches - where those kernels do all the work; each launch must leave two CUs free) has ONE row tile of one of its launches
+ * - they come up in turn, so every tile of every launch is visited - recomputed on the exchange-free half-tile kernel from a snapshot of
+ * its input and compared with a snapshot of what the launch wrote.  Snapshot: two tiny kernels behind the launch; recomputation (as long
+ * as a whole round of that kernel: ~13 ms at 2 s clips) and comparison: a stream of their own, private buffers, beside the forwards that
+ * follow - nothing on the caller's critical path.  A sample is skipped while the previous one is still in flight.  A mismatch flags the
+ * handle with code 7 when it is FOUND, i.e. a few calls after the forward it belongs to.  Plans with a chip-filling launch (their
+ * column-split launches are remainders: < 1 % of the work; two more workgroups would cost the chip-filling launch a second round) are not
+ * sampled - fsnp_set_verify covers them.  0 = off (the C default; the Python module's default
+ * error policy "sync" sets 16). */
+int fsnp_set_verify_sample(fsnp_handle* h, int32_t every);
 int64_t fsnp_verify_count(const fsnp_handle* h);
 
 const char* fsnp_last_error(void);

@@ -166,6 +166,10 @@ int fsnp_debug_lstm_hpw_pack(int32_t hidden, int32_t input_size, int32_t kx, con
 int fsnp_debug_lstm_fbv_pack(int32_t hidden, int32_t input_size, const float* wih0, const float* whh0, const float* wih1, const float* whh1,
                              float* out, int64_t out_floats);
 
+/* fsnp_set_verify_sample's counters: out[0] = samples recomputed so far, out[1] = samples skipped because the previous one was still in
+ * flight, out[2] = eligible forwards seen (plans of column-split launches only) since the setting last changed. */
+int fsnp_debug_verify_sample_stats(const fsnp_handle* h, int64_t out[3]);
+
 /* Round 6 - calibration of the box a measurement ran on (bench.py's `box` object).
  *
  * fsnp_debug_box_probe: runs nothing but v_mfma_f32_32x32x2_f32 - the instruction the dominant kernel is bound by - on every SIMD of

@@ -1295,6 +1295,58 @@ def test_sync_error_policy_reruns_on_the_row_tile_kernel():
     m.poll_errors()
 
 
+@pytest.mark.parametrize("batch,tiles", [(1, 9), (2, 17)])
+def test_sampled_exchange_verification_catches_a_corruption_in_an_unsampled_tile_within_a_cycle(batch, tiles):
+    """fsnp_set_verify_sample (round 6; the default of error_check="sync" at every 16th forward): ONE row tile per sampled forward - the
+    tiles of a launch come up in turn - is recomputed on the exchange-free half-tile kernel from a snapshot, on a stream of its own.
+    (1) Without a fault nothing fires and outputs stay bit-identical; every eligible forward is sampled when the previous sample has
+    finished.  (2) The corruption hook damages row tile 0 of every forward; the sampler is first moved to tile 3, so tile 0 is NOT the
+    sampled one: the detector must fire within one cycle over the tiles, name utterance 0 / bin 0, and stay quiet afterwards."""
+    sd = make_state_dict(0, "default")
+    m = _model(DEFAULT_MODEL_ARGS, sd, "full")
+    ins = _cuda(make_inputs(batch, 0.6, 40 + batch))
+    m.error_check = "deferred"
+    m.verify_sample_every = 0
+    plain = m(*ins).cpu().numpy()
+    assert len(m.describe_plan(batch)) == 1 and m.describe_plan(batch)[0]["tiles"] == tiles
+    m.verify_sample_every = 1
+    for i in range(3):                                                   # samples 0, 1, 2 = tiles 0, 1, 2: clean
+        assert np.array_equal(m(*ins).cpu().numpy(), plain)
+        m.check_errors()                                                 # (device synchronisation: the sample has been compared)
+    st = m.verify_sample_stats()
+    assert st["samples"] == 3 and st["skipped"] == 0, st
+    fired_after = None
+    for i in range(tiles + 1):
+        m.debug_corrupt_exchange(5)
+        bad = m(*ins).cpu().numpy()
+        assert rel_err(bad, plain) > 1e-4
+        try:
+            m.check_errors()
+        except RuntimeError as e:
+            assert "exchange verification failed" in str(e) and "utterance 0, bin 0, frame" in str(e), str(e)
+            assert getattr(e, "code", None) == 7
+            fired_after = i + 1
+            break
+    assert fired_after == tiles - 3 + 1, fired_after                     # tiles 3 ... tiles - 1 are clean, tile 0 comes up next
+    assert np.array_equal(m(*ins).cpu().numpy(), plain)
+    m.check_errors()
+    # back to back without waiting: a sample is skipped while the previous one is still in flight - never queued up behind it
+    before = m.verify_sample_stats()
+    for _ in range(6):
+        m(*ins)
+    m.check_errors()
+    after = m.verify_sample_stats()
+    assert after["samples"] + after["skipped"] - before["samples"] - before["skipped"] == 6 and after["samples"] > before["samples"], (before, after)
+    # the module's default policy: 16 under "sync", off under "deferred"
+    m.verify_sample_every = None
+    m.error_check = "sync"
+    s0 = m.verify_sample_stats()["samples"]
+    for _ in range(17):
+        assert np.array_equal(m(*ins).cpu().numpy(), plain)
+    m.check_errors()
+    assert 1 <= m.verify_sample_stats()["samples"] - s0 <= 2
+
+
 @pytest.mark.parametrize("batch,kernel,round4", [(1, "lstm2_coop_hp_kernel", False), (2, "lstm2_coopw_kernel", False), (8, "lstm2_coopw_kernel", False),
                                                  (3, "lstm2_coop_kernel", True), (8, "lstm2_coopn_kernel", True)])
 def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel, round4):
@@ -1308,8 +1360,8 @@ def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel, round
     m = _model(DEFAULT_MODEL_ARGS, sd, "full")
     ins = _cuda(make_inputs(batch, 0.6, 40 + batch))
     if round4:                                                           # the K split / the three-way split lead the plan again
-        m(*ins)
-        m.debug_set_costs(m.planner_costs_raw()[:21], 1)
+        m(*ins)                                                          # (19 values: neither the wave-owned split nor the half-tile
+        m.debug_set_costs(m.planner_costs_raw()[:19], 1)                 #  ping-pong launches, which round 6 made cheap enough to lead B = 3)
     plain = m(*ins).cpu().numpy()
     assert m.describe_plan(batch)[0]["kernel"].startswith(kernel), m.describe_plan(batch)
     m.verify_every = 1

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"fsnp_handle", "fsnp_config"}
     # fsnp.h is the surface a maintainer binds: no test / tuning hook, no planner internals (those live in fsnp_debug.h)
     core_syms = set(re.findall(r"^[a-z][a-z0-9_ \*]*\b(fsnp_[a-z0-9_]+)\s*\(", core, flags=re.M))
-    assert not any(n.startswith("fsnp_debug_") for n in core_syms) and len(core_syms) <= 30, sorted(core_syms)
+    assert not any(n.startswith("fsnp_debug_") for n in core_syms) and len(core_syms) <= 32, sorted(core_syms)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
