@@ -53,11 +53,15 @@ __device__ __forceinline__ float4 wld_sc1(const WStream& s, int soff) {      // 
 template <int NT>
 __device__ __forceinline__ void w_mfma(f32x16 (&acc)[NT], const float4& a, const float4 (&b)[NT]) {
 #pragma unroll
+    // TRANSPOSED product (round 6): the weight fragment is the A operand (M = the tile's 32 gate-interleaved columns), h / x the B operand
+    // (N = 32 sequences).  Same lane -> (column, k) / (sequence, k) maps on both sides, so neither the weight pack nor the exchange images
+    // change, and every output element sums the same products in the same order - but accumulator register q of lane (sequence, hi) is now
+    // gate q & 3 of unit hi + 2 (q >> 2): the four gates of the lane's four cells, with no trip through LDS
     for (int n = 0; n < NT; ++n) {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[n].x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[n].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[n].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[n].w, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].x, a.x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].y, a.y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].z, a.z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].w, a.w, acc[n], 0, 0, 0);
     }
 }
 
@@ -220,13 +224,17 @@ __global__ __launch_bounds__(256) void lstm2_coopw_kernel(LstmWeights w, LstmArg
     }
 
     // ---- per-lane constants: the bias of the lane's column of every tile (accumulator initialisation), Linear weights of its cells
-    float bcol0[NT], bcol1[NT];
+    // (accumulator register q of lane (sequence, hi) = gate q & 3 of unit hi + 2 (q >> 2): 16 NT bias values per lane and layer, kept in the
+    //  wave's LDS slice - where the staging tile of the round-5 kernel used to be - as [layer][n][hi][16], read as four float4 per tile)
+    float4* biast = reinterpret_cast<float4*>(stg);                           // [2 layers][NT][2][4]
+    for (int i = lane; i < 2 * NT * 2 * 16; i += 64) {
+        const int q = i & 15, bh = (i >> 4) & 1, n = (i >> 5) % NT, layer = i / (32 * NT);
+        stg[i] = w.bias[layer * 4 * HID + (q & 3) * HID + part * UW + n * 8 + bh + 2 * (q >> 2)];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int c = lane & 31;
-        const int ucol = part * UW + n * 8 + (c >> 2), gate = c & 3;
-        bcol0[n] = w.bias[gate * HID + ucol];
-        bcol1[n] = w.bias[4 * HID + gate * HID + ucol];
         const int u = part * UW + n * 8 + hi;
         wfct[(2 * n) * 64] = make_float4(w.wfc[u], w.wfc[u + 2], w.wfc[u + 4], w.wfc[u + 6]);
         wfct[(2 * n + 1) * 64] = make_float4(w.wfc[HID + u], w.wfc[HID + u + 2], w.wfc[HID + u + 4], w.wfc[HID + u + 6]);
@@ -240,25 +248,24 @@ __global__ __launch_bounds__(256) void lstm2_coopw_kernel(LstmWeights w, LstmArg
     // accumulator tiles -> the wave's LDS slice -> the lane's 4 NT cells; emit(n, h) receives the float4 of the lane's slot of
     // k-group part * NT + n of the h image (components = units hi, hi + 2, hi + 4, hi + 6 of 8-unit block part * NT + n)
     auto cells = [&](f32x16 (&acc)[NT], float (&c)[NT][4], auto emit) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) stg[((q & 3) + 8 * (q >> 2) + 4 * hi) * STRIDE + n * 32 + (lane & 31)] = acc[n][q];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            float4 g4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g4[j] = *reinterpret_cast<const float4*>(stg + row * STRIDE + n * 32 + 4 * (hi + 2 * j));
             f32x2 ca{c[n][0], c[n][1]}, cb{c[n][2], c[n][3]};
-            const f32x2 ha = lstm_cell_pair(f32x2{g4[0].x, g4[1].x}, f32x2{g4[0].y, g4[1].y}, f32x2{g4[0].z, g4[1].z}, f32x2{g4[0].w, g4[1].w}, ca);
-            const f32x2 hb = lstm_cell_pair(f32x2{g4[2].x, g4[3].x}, f32x2{g4[2].y, g4[3].y}, f32x2{g4[2].z, g4[3].z}, f32x2{g4[2].w, g4[3].w}, cb);
+            const f32x2 ha = lstm_cell_pair(f32x2{acc[n][0], acc[n][4]}, f32x2{acc[n][1], acc[n][5]}, f32x2{acc[n][2], acc[n][6]}, f32x2{acc[n][3], acc[n][7]}, ca);
+            const f32x2 hb = lstm_cell_pair(f32x2{acc[n][8], acc[n][12]}, f32x2{acc[n][9], acc[n][13]}, f32x2{acc[n][10], acc[n][14]}, f32x2{acc[n][11], acc[n][15]}, cb);
             c[n][0] = ca.x; c[n][1] = ca.y; c[n][2] = cb.x; c[n][3] = cb.y;
             emit(n, make_float4(ha.x, ha.y, hb.x, hb.y));
         }
-        __builtin_amdgcn_wave_barrier();
+    };
+    // accumulator initialisation = the biases of the lane's 16 (gate, unit) rows of tile n
+    auto acc_init = [&](f32x16 (&acc)[NT], int layer) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b4 = biast[((layer * NT + n) * 2 + hi) * 4 + u];
+                acc[n][4 * u] = b4.x; acc[n][4 * u + 1] = b4.y; acc[n][4 * u + 2] = b4.z; acc[n][4 * u + 3] = b4.w;
+            }
     };
     auto hstore = [&](int img_f4, int n, const float4& v) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), hs.rsrc, hs.voff,
@@ -277,20 +284,25 @@ __global__ __launch_bounds__(256) void lstm2_coopw_kernel(LstmWeights w, LstmArg
         if (lane == 0) ok = xchg_wait(bar, target, a.coop_abort, a.coop_err) ? 1 : 0;
         return __builtin_amdgcn_readfirstlane(ok) != 0;
     };
-    // participant 0 sums the P partials of a finished step in a fixed order: the loads are issued where the step's partials are known
-    // to be complete (fc_issue) and summed a cell phase later (fc_finish), so that their round trip is not on participant 0's path
+    // ONE participant sums the P partials of a finished step in a fixed order: the loads are issued where the step's partials are known
+    // to be complete (fc_issue) and summed a cell phase later (fc_finish), so that their round trip is not on that wave's path.  Round 6:
+    // the owner ROTATES (step t_done belongs to participant t_done mod P).  With participant 0 as the fixed owner its P extra loads and adds
+    // per step made it the slowest wave of every step - and a launch runs at the pace of its slowest participant (the same finding as in
+    // lstm_hpw.hip: profiles/r06_b1_kernel.md); rotating, every wave pays once in P steps, inside the slack in front of its counters.
     float fcv[P];
+    const float bfc_lane = w.bfc[hi];                    // (lane (row, hi) finishes output hi of its row)
+    auto fc_owner = [&](int t_done) -> bool { return part == t_done % P; };
     auto fc_issue = [&](int t_done) {
-        if (part == 0) {
+        if (fc_owner(t_done)) {
             const float* src = fcp + (size_t)(t_done & 1) * P * 64 + lane;
 #pragma unroll
             for (int p = 0; p < P; ++p) fcv[p] = xchg_load(src + p * 64);
         }
     };
     auto fc_finish = [&](int t_done) {
-        if (part == 0) {
+        if (fc_owner(t_done)) {
             const int o = lane >> 5;
-            float sum = w.bfc[o];
+            float sum = bfc_lane;
 #pragma unroll
             for (int p = 0; p < P; ++p) sum += fcv[p];
             if (rd.valid && t_done >= a.LA)
@@ -316,10 +328,7 @@ __global__ __launch_bounds__(256) void lstm2_coopw_kernel(LstmWeights w, LstmArg
         FSNP_W_STAMP(t, 0);
         const bool have_next = t + 1 < Tp;
         f32x16 acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[n][q] = bcol0[n];
+        acc_init(acc, 0);
         const int hprev = h0off(pm3) * 16;
         // (the last D h0 groups refill the pipeline's WEIGHT slots with the first x k-groups; their A fragments are registers)
         w_segment<NT, HID, D, KGH, NXN>(acc, pa, pb, ws, part, KGX, [&](int g) -> float4 { return wld_sc1(hs, hprev + g * 1024); },
@@ -372,10 +381,7 @@ __global__ __launch_bounds__(256) void lstm2_coopw_kernel(LstmWeights w, LstmArg
         FSNP_W_STAMP(t + 1, 8);
         unsigned early0 = 0u;
         f32x16 acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[n][q] = bcol1[n];
+        acc_init(acc, 1);
         const int h1p = h1off(prv) * 16, h0c = h0off(m3) * 16;
         w_segment<NT, HID, D, KGH, D>(acc, pa, pb, ws, part, KG0, [&](int g) -> float4 { return wld_sc1(hs, h1p + g * 1024); },
                                       KG0 + KGH, [&](int g) -> float4 { return wld_sc1(hs, h0c + g * 1024); }, [] {});

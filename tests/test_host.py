@@ -917,8 +917,8 @@ def test_wave_owned_column_split_index_maps_and_asm():
     lane l is k = 8 g' + 2 p + (l >> 5) - emulating the kernel's indexing on the packer's output reproduces W x for both layers, for
     both split widths, K = 40 and 64.  (2) Lane / slot identities: lane (row, hi)'s features hi + 2 i are the components of ITS A
     fragment of x k-group i >> 2, and its cells (units hi + 2 j of block ub) are the components of ITS float4 of k-group ub of the h
-    image (a_frag_index).  (3) The staging tile [32][32 NT + 4]: the write pattern of a 32x32x2 accumulator and the read-back of
-    (i, f, g, o) cover every element once, ds_write_b32 / ds_read_b128 conflict-free per lane group (MI355X_MICROARCH.md, LDS).
+    image (a_frag_index).  (3) Round 6, transposed product: accumulator register q of lane (sequence, hi) is gate q & 3 of unit hi + 2 (q >> 2)
+    - the cells are lane-local straight out of the accumulators (the round-5 staging tile through LDS is gone); the bias table's index math.
     (4) The layer-skewed schedule with per-wave participants is the one test_exchange_schedules_are_race_free_under_any_interleaving
     model-checks (three h0 images, two h1 images).  (5) Static asm: clean k-group loops, no scratch, no workgroup barrier in the time
     loop, no cache maintenance, 16-byte sc1 stores."""
@@ -960,30 +960,26 @@ def test_wave_owned_column_split_index_maps_and_asm():
         for ub in (0, 7, 47):
             for j in range(4):                                                                # h: unit 8 ub + hi + 2 j <-> component j of float4 ub * 64 + l
                 assert a_frag(row, 8 * ub + hi + 2 * j) == (ub * 64 + l) * 4 + j
-    groups128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
-    groups128 += [[g + 32 for g in grp] for grp in groups128]                                 # ds_read_b128 lane groups
+    # (3) round 6: TRANSPOSED product.  D = W-fragment (A operand, M = the tile's 32 gate-interleaved columns) x h (B operand, N = 32 sequences):
+    # accumulator register q of lane l is D[m = (q & 3) + 8 (q >> 2) + 4 (l >> 5)][n = l & 31] (the 32x32 C/D layout); with column m = gate
+    # (m & 3) of unit (m >> 2) that is gate q & 3 of unit hi + 2 (q >> 2) for sequence l & 31: the four gates of each of the lane's four
+    # cells sit in consecutive registers, every (sequence, unit, gate) exactly once per wave - no staging tile.  The bias table
+    # [layer][n][hi][16] read as float4 u holds gates 0..3 of unit hi + 2 u.
     for NT in (1, 2):
-        stride = 32 * NT + 4
-        seen = np.zeros((32, 32 * NT), dtype=int)
-        for n in range(NT):
+        seen = set()
+        for l in range(64):
+            seq, hi = l & 31, l >> 5
             for q in range(16):
-                addr = [((q & 3) + 8 * (q >> 2) + 4 * (l >> 5)) * stride + n * 32 + (l & 31) for l in range(64)]
-                for half in (addr[:32], addr[32:]):
-                    assert len({a % 32 for a in half}) == 32                                 # ds_write_b32: 32 lanes, 32 banks
-                for l in range(64):
-                    seen[(q & 3) + 8 * (q >> 2) + 4 * (l >> 5), n * 32 + (l & 31)] += 1
-        assert (seen == 1).all()
-        read = np.zeros((32, 32 * NT), dtype=int)
-        for n in range(NT):
-            for j in range(4):
-                addr = [(l & 31) * stride + n * 32 + 4 * ((l >> 5) + 2 * j) for l in range(64)]
-                for grp in groups128:
-                    banks = [(addr[l] + e) % 64 for l in grp for e in range(4)]
-                    assert len(set(banks)) == 64                                              # ds_read_b128: 16 lanes x 4 banks, all distinct
-                for l in range(64):
-                    assert addr[l] % 4 == 0
-                    read[l & 31, n * 32 + 4 * ((l >> 5) + 2 * j): n * 32 + 4 * ((l >> 5) + 2 * j) + 4] += 1
-        assert (read == 1).all()
+                m = (q & 3) + 8 * (q >> 2) + 4 * hi
+                gate, unit = m & 3, m >> 2
+                assert gate == q & 3 and unit == hi + 2 * (q >> 2)
+                seen.add((seq, unit, gate))
+        assert len(seen) == 32 * 8 * 4
+        for i in range(2 * NT * 2 * 16):                                                      # the fill loop's decode of float index i
+            q, bh, n, layer = i & 15, (i >> 4) & 1, (i >> 5) % NT, i // (32 * NT)
+            assert i == ((layer * NT + n) * 2 + bh) * 16 + q
+            u, g = q >> 2, q & 3                                                              # float4 u of lane hi = bh, component g
+            assert (((layer * NT + n) * 2 + bh) * 4 + u) * 4 + g == i
     spec = importlib.util.spec_from_file_location("check_lstm_asm", os.path.join(ROOT, "tools", "check_lstm_asm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
