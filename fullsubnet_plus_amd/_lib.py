@@ -24,7 +24,7 @@ ACTIVATIONS = {None: 0, False: 0, "": 0, "ReLU": 1, "ReLU6": 2, "Tanh": 3}
 ATTENTION = {"TSSE": 0, "SE": 1, "ECA": 2, "CBAM": 3}
 SEQUENCE_MODELS = {"LSTM": 0, "GRU": 1, "TCN": 2}
 MODE_FULL, MODE_PARITY = 0, 1
-NUM_COSTS = 25           # FSNP_NUM_COSTS: values of the planner's flat cost table (fsnp_get_costs)
+NUM_COSTS = 27           # FSNP_NUM_COSTS: values of the planner's flat cost table (fsnp_get_costs)
 MODEL_FULLSUBNET_PLUS, MODEL_FULLSUBNET = 0, 1
 BOX_PROBE_VALUES = 9     # FSNP_BOX_PROBE_VALUES (include/fsnp_debug.h)
 

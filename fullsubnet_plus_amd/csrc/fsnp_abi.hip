@@ -598,7 +598,7 @@ static int calibrate_costs(fsnp_handle* h, bool adopt = true, CostTable* measure
         const double u1 = time_shape(SbChunk{8, 0, 0, 1, 0, 32, 16, 0, 0, 0, 0}), uf = time_shape(SbChunk{8, 0, 0, cap, 0, 32, 16, 0, 0, 0, 0});
         if (u1 < 0 || uf < 0) rc = 4; else { t.hp[0] = u1; t.hp[1] = uf; }
     }
-    for (int nt = 1; nt <= 2 && rc == 0 && h->coopw_ok; ++nt) {
+    for (int nt = 1; nt <= 3 && rc == 0 && h->coopw_ok; ++nt) {
         const int u = 32 * nt, cap = h->num_cus_real / (h->H / u);
         if (cap <= 0) continue;
         const double u1 = time_shape(SbChunk{9, 0, 0, 1, 0, 32, u, 0, 0, 0, 0}), uf = cap > 1 ? time_shape(SbChunk{9, 0, 0, cap, 0, 32, u, 0, 0, 0, 0}) : u1;
@@ -1475,7 +1475,7 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
     if (!h->committed || (!h->hp_ok && tiles_per_group == 0)) { set_error("fsnp_debug_pp_profile: no half-tile ping-pong kernel for this handle"); return 2; }
     // tiles_per_group: 0 = the half-tile ping-pong kernel (lstm_hp.hip: 2 halves x 16 stamps per step); 32 / 64 = the wave-owned column
     // split (lstm_coopw.hip) at that many units per workgroup (16 stamps per step: 8 per layer phase)
-    const bool hp = tiles_per_group == 0, cw = tiles_per_group == 32 || tiles_per_group == 64;
+    const bool hp = tiles_per_group == 0, cw = tiles_per_group == 32 || tiles_per_group == 64 || tiles_per_group == 96;
     if ((!hp && !cw) || num_stamps != (int64_t)steps * (hp ? 32 : 16)) { set_error("fsnp_debug_pp_profile: tiles_per_group must be 0 (half-tile ping-pong kernel, steps * 32 stamps) or 32 / 64 (wave-owned column split, steps * 16 stamps)"); return 2; }
     if (cw && !h->coopw_ok) { set_error("fsnp_debug_pp_profile: no wave-owned column split for this handle"); return 2; }
     const int tiles = cdiv(num_seq, 32), groups = tiles, S = hp ? h->H / 16 : h->H / tiles_per_group;
@@ -1633,10 +1633,10 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_GEMM_DMA=%s -> %d (0 = the general GEMM kernel everywhere)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma);
     add("  FSNP_VERIFY_EVERY=%s -> exchange verification every %d forwards (0 = off)\n", env("FSNP_VERIFY_EVERY"), h->verify_every);
     add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
-    add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, half-tile ping-pong %.1f / %.1f, wave-owned split full %.1f / %.1f, one tile %.1f / %.1f\n",
+    add("cost table (us per step): K split full %.1f / %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f / %.1f, three-way %.1f / %.1f, one tile per CU %.1f (+%.2f per VALU row), half tile %.1f, half-tile ping-pong %.1f / %.1f, wave-owned split full %.1f / %.1f / %.1f, one tile %.1f / %.1f / %.1f\n",
         h->cost.ksplit[0][0], h->cost.ksplit[1][0], h->cost.ksplit[2][0], h->cost.ksplit[3][0], h->cost.ksplit1[0], h->cost.ksplit1[1],
         h->cost.ksplit1[2], h->cost.ksplit1[3], h->cost.coopn[0][0], h->cost.coopn[1][0], h->cost.rowtile, h->cost.rowtile_ex, h->cost.rowtile16,
-        h->cost.hp[0], h->cost.hp[1], h->cost.coopw[0][1], h->cost.coopw[1][1], h->cost.coopw[0][0], h->cost.coopw[1][0]);
+        h->cost.hp[0], h->cost.hp[1], h->cost.coopw[0][1], h->cost.coopw[1][1], h->cost.coopw[2][1], h->cost.coopw[0][0], h->cost.coopw[1][0], h->cost.coopw[2][0]);
     if (buf && cap > 0) {
         const size_t n = o.size() < (size_t)cap - 1 ? o.size() : (size_t)cap - 1;
         memcpy(buf, o.data(), n);

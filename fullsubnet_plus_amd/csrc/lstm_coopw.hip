@@ -482,7 +482,7 @@ void lstm_coopw_pack_weights(int H, int NIN, int KX, const float* wih0, const fl
 }
 
 bool lstm_coopw_available(const LstmWeights& w, int units) {
-    return !w.gru && w.H == 384 && (w.KX == 40 || w.KX == 64) && (units == 32 || units == 64) && w.wpack_coopw != nullptr;
+    return !w.gru && w.H == 384 && (w.KX == 40 || w.KX == 64) && (units == 32 || units == 64 || units == 96) && w.wpack_coopw != nullptr;
 }
 
 template <int HID, int KX, int NT>
@@ -504,6 +504,7 @@ static void launch_coopw_inst(const LstmWeights& w, const LstmArgs& a, hipStream
 template <int KX>
 static void launch_coopw_kx(const LstmWeights& w, const LstmArgs& a, hipStream_t s, int* occ) {
     if (a.coop_units == 32) launch_coopw_inst<384, KX, 1>(w, a, s, occ);
+    else if (a.coop_units == 96) launch_coopw_inst<384, KX, 3>(w, a, s, occ);
     else launch_coopw_inst<384, KX, 2>(w, a, s, occ);
 }
 

@@ -30,20 +30,25 @@ CostTable default_costs() {
     // round 5: wave-owned column split (lstm_coopw.hip) at 32 / 64 units per workgroup: one row tile / a full launch of 21 / 42
     // (profiles/r05_column_split.md; a 96-unit instantiation - 64 tiles x 4 workgroups - measured 63.3 us: no better than a 42-tile
     // launch at 64 units + a 21-tile launch at 32, and it spilled registers: not built)
-    const double cw1[2] = {21.5, 37.5}, cwf[2] = {22.8, 39.0};
-    for (int i = 0; i < 2; ++i) { t.coopw[i][0] = cw1[i]; t.coopw[i][1] = cwf[i]; }
+    // round 6: 96 units per workgroup (NT = 3: 4 workgroups per row tile, 64 row tiles per launch - B = 8's 65 tiles as 64 + 1 instead of
+    // 42 + 21 + 2).  With the transposed product the cells come straight out of the accumulators, the staging tile is gone and the
+    // instantiation fits without spills (406 registers); 4 loads per 12 MFMAs in its k-loops (NT = 1: 2 per 4)
+    const double cw1[3] = {21.0, 37.0, 52.5}, cwf[3] = {22.3, 38.5, 56.5};      // (profiles/r06_coopw_times.txt)
+    for (int i = 0; i < 3; ++i) { t.coopw[i][0] = cw1[i]; t.coopw[i][1] = cwf[i]; }
     return t;
 }
 // flat layout (include/fsnp.h, fsnp_get_costs): [0..7] K split full launch x {one, two per CU} at 8 / 16 / 32 / 64 units, [8..11] three-way
 // split 1 / 2 row tiles per group x {one, two per CU}, [12] one tile per CU, [13] relative extra per VALU row, [14..17] K split with ONE row
 // tile, [18] half tile per CU, [19..20] half-tile ping-pong one tile / full launch, [21..22] wave-owned split at 32 / 64 units per
-// workgroup, a full launch, [23..24] the same with ONE row tile (kNumCosts = 25; the 96-unit instantiation was never built)
+// workgroup, a full launch, [23..24] the same with ONE row tile, [25..26] (round 6) the 96-unit instantiation: a full launch, one row tile
+// (kNumCosts = 27; appended, so that a 25-value table of the round-5 layout is still a valid prefix)
 void costs_to_array(const CostTable& t, double* out) {
     for (int i = 0; i < 4; ++i) { out[2 * i] = t.ksplit[i][0]; out[2 * i + 1] = t.ksplit[i][1]; out[14 + i] = t.ksplit1[i]; }
     for (int i = 0; i < 2; ++i) { out[8 + 2 * i] = t.coopn[i][0]; out[9 + 2 * i] = t.coopn[i][1]; }
     out[12] = t.rowtile; out[13] = t.rowtile_ex; out[18] = t.rowtile16;
     out[19] = t.hp[0]; out[20] = t.hp[1];
     for (int i = 0; i < 2; ++i) { out[21 + i] = t.coopw[i][1]; out[23 + i] = t.coopw[i][0]; }
+    out[25] = t.coopw[2][1]; out[26] = t.coopw[2][0];
 }
 void costs_from_array(CostTable& t, const double* in) {
     for (int i = 0; i < 4; ++i) { t.ksplit[i][0] = in[2 * i]; t.ksplit[i][1] = in[2 * i + 1]; t.ksplit1[i] = in[14 + i]; }
@@ -51,6 +56,7 @@ void costs_from_array(CostTable& t, const double* in) {
     t.rowtile = in[12]; t.rowtile_ex = in[13]; t.rowtile16 = in[18];
     t.hp[0] = in[19]; t.hp[1] = in[20];
     for (int i = 0; i < 2; ++i) { t.coopw[i][1] = in[21 + i]; t.coopw[i][0] = in[23 + i]; }
+    t.coopw[2][1] = in[25]; t.coopw[2][0] = in[26];
 }
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)
 CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
@@ -60,7 +66,7 @@ CostTable initial_costs(int sb_hidden, bool gru, bool sb_tcn) {
         const double f = sb_hidden / 384.0;
         for (int i = 0; i < 4; ++i) { t.ksplit[i][0] *= f; t.ksplit[i][1] *= f; t.ksplit1[i] *= f; }
         t.hp[0] *= f; t.hp[1] *= f;
-        for (int i = 0; i < 2; ++i) { t.coopw[i][0] *= f; t.coopw[i][1] *= f; }
+        for (int i = 0; i < 3; ++i) { t.coopw[i][0] *= f; t.coopw[i][1] *= f; }
         for (int i = 0; i < 2; ++i) { t.coopn[i][0] *= f; t.coopn[i][1] *= f; }
         t.rowtile *= f * f;
     }
@@ -132,7 +138,7 @@ static std::vector<SbChunk> plan_columns(const PlannerCtx& h, int row0, int nrow
         // half-tile ping-pong (lstm_hp.hip): H / 16 workgroups per row tile
         if (occ == 1 && h.hp_ok && h.coop_hp && slots / (h.H / 16) > 0) shapes.push_back({8, 16, 0, slots / (h.H / 16), 0});
         // wave-owned column split (lstm_coopw.hip): H / (32 NT) workgroups per row tile, one per CU
-        for (int nt = 1; nt <= 2 && occ == 1 && h.coopw_ok && h.coop_w; ++nt)
+        for (int nt = 1; nt <= 3 && occ == 1 && h.coopw_ok && h.coop_w; ++nt)
             if (h.H % (32 * nt) == 0 && slots / (h.H / (32 * nt)) > 0) shapes.push_back({9, 32 * nt, 0, slots / (h.H / (32 * nt)), 0});
     }
     auto shape_cost = [&](const Shape& sh, int n) {             // n tiles on this shape (n <= cap)
@@ -234,7 +240,10 @@ SbPlan plan_sb(const PlannerCtx& h, int num_rows) {
             if (!rc.empty()) {
                 comp.insert(comp.end(), rc.begin(), rc.end());
                 const double cc = cost_of(comp);
-                if (cc < best_cost) { best = comp; best_cost = cc; }
+                // (a composite of a half-tile round + column-split launches obeys composite_gain like the row-tile composite above:
+                //  with the 96-unit wave-owned launches of round 6 such a plan came within 2 % of ONE row-tile launch at B = 32)
+                const double whole_cost = rowtile_ok ? h.composite_gain * (est_step_us(h, whole) + 1.2) : 1e30;
+                if (cc < best_cost && cc < whole_cost) { best = comp; best_cost = cc; }
             }
         }
     }

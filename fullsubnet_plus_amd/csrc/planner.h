@@ -13,7 +13,7 @@ struct CostTable {
     double rowtile, rowtile_ex;   // one round of the one-tile-per-CU kernel; relative extra per VALU row
     double rowtile16;             // one round of the half-tile (16-row) kernel (lstm16.hip)
     double hp[2];                 // half-tile ping-pong (lstm_hp.hip, 16 units): ONE row tile, a FULL launch (num_cus / (H / 16) tiles)
-    double coopw[2][2];           // wave-owned column split (lstm_coopw.hip) at 32 / 64 units per workgroup: ONE row tile, a FULL launch
+    double coopw[3][2];           // wave-owned column split (lstm_coopw.hip) at 32 / 64 / 96 units per workgroup: ONE row tile, a FULL launch
     int calibrated;
 };
 
@@ -54,7 +54,7 @@ struct PlannerCtx {
 
 CostTable default_costs();
 // the flat table of fsnp_get_costs / fsnp_debug_set_costs (include/fsnp.h: FSNP_NUM_COSTS values)
-constexpr int kNumCosts = 25;
+constexpr int kNumCosts = 27;
 void costs_to_array(const CostTable& t, double* out);
 void costs_from_array(CostTable& t, const double* in);
 // the table a handle starts from: the built-in one scaled to the handle's cell and hidden size (measured at LSTM, H = 384)

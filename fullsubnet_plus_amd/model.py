@@ -728,7 +728,8 @@ class _HipModel(nn.Module):
                 "coopn_us": {r: {"one_per_cu": v[8 + 2 * i], "two_per_cu": v[9 + 2 * i]} for i, r in enumerate((1, 2))},
                 "rowtile_us": v[12], "valu_row_surcharge": v[13], "rowtile16_us": v[18],
                 "halftile_pingpong_us": {"one_tile": v[19], "full_launch": v[20]},
-                "coopw_us": {u: {"one_tile": v[23 + i], "full_launch": v[21 + i]} for i, u in enumerate((32, 64))}}
+                "coopw_us": {**{u: {"one_tile": v[23 + i], "full_launch": v[21 + i]} for i, u in enumerate((32, 64))},
+                             96: {"one_tile": v[26], "full_launch": v[25]}}}
 
     def measure_costs(self):
         """-> the same table MEASURED on the device (fsnp_measure_costs; ~0.3 s, synchronises; the plan is not touched)."""

@@ -51,7 +51,8 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
  * out[8..11] = three-way split with 1 / 2 row tiles per group x {one, two}, out[12] = one round of the one-tile-per-CU
  * kernel, out[13] = its relative surcharge per VALU row, out[18] = one round of the half-tile kernel, out[19..20] = half-tile ping-pong
  * kernel (csrc/lstm_hp.hip): one row tile, a full launch; out[21..22] = wave-owned column split (csrc/lstm_coopw.hip) at 32 / 64
- * units per workgroup, a full launch, out[23..24] = the same with ONE row tile.  The built-in table holds measurements
+ * units per workgroup, a full launch, out[23..24] = the same with ONE row tile, out[25..26] = (round 6) the 96-unit instantiation of that
+ * kernel: a full launch (64 row tiles), one row tile.  The built-in table holds measurements
  * (profiles/r03_planner_costs.json, profiles/r05_planner_costs.json), so plans - and performance - are reproducible from run to run
  * and box to box.  fsnp_measure_costs MEASURES the same numbers on the device (every launch shape on zeros at two step counts, slope;
  * ~0.3 s, synchronises; cached per process) without touching the plan: tests/test_gpu_parity.py asserts that the built-in
@@ -60,7 +61,7 @@ int fsnp_describe_plan_ex(const fsnp_handle* h, int32_t batch, int32_t mode, int
  * move near-ties between plans by up to 10 % either way, which is why adoption is opt-in.  *occ = workgroups per CU the
  * column-split kernels may be planned with (2 = allowed for the launch shapes whose kernel fits a CU twice; never chosen
  * with measured costs: two co-resident workgroups starve each other; FSNP_COOP_OCC=1 forces 1). */
-#define FSNP_NUM_COSTS 25
+#define FSNP_NUM_COSTS 27
 int fsnp_get_costs(const fsnp_handle* h, double out[FSNP_NUM_COSTS], int32_t* calibrated, int32_t* occ);
 int fsnp_measure_costs(fsnp_handle* h, double out[FSNP_NUM_COSTS]);
 /* The planner alone (host only, no device, no handle): how `num_rows` sub-band sequences would be cut on a chip with

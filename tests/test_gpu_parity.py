@@ -160,9 +160,10 @@ def _hp_only_costs():
 
 
 def _coopw_only_costs(units):
-    """A cost table under which every column-split launch is the wave-owned split at `units` (32 / 64) units per workgroup."""
+    """A cost table under which every column-split launch is the wave-owned split at `units` (32 / 64 / 96) units per workgroup."""
     w = [5.0 if 32 * (i + 1) == units else 900.0 for i in range(2)]
-    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + w + w
+    w96 = [5.0, 5.0] if units == 96 else [900.0, 900.0]
+    return [900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + w + w + w96
 
 
 @pytest.mark.parametrize("n,steps,hidden,fbn", [(1, 1, 384, 0), (16, 2, 384, 0), (17, 3, 384, 0), (32, 40, 384, 0), (33, 5, 384, 0), (257, 41, 384, 0),
@@ -195,7 +196,8 @@ def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden, fbn):
 
 @pytest.mark.parametrize("units,n,steps,fbn", [(32, 1, 1, 0), (32, 33, 2, 0), (32, 514, 41, 0), (32, 672, 3, 0), (32, 700, 9, 0),
                                                (64, 40, 1, 0), (64, 17, 2, 0), (64, 1285, 33, 0), (64, 1344, 7, 0), (64, 1400, 5, 0),
-                                               (64, 2056, 128, 0), (32, 514, 9, 2), (64, 300, 5, 3), (64, 96, 300, 0)])
+                                               (64, 2056, 128, 0), (32, 514, 9, 2), (64, 300, 5, 3), (64, 96, 300, 0),
+                                               (96, 1, 1, 0), (96, 2048, 41, 0), (96, 2056, 128, 0), (96, 2100, 7, 0), (96, 1799, 9, 2), (96, 70, 300, 0)])
 def test_wave_owned_column_split_kernel_vs_oracle(units, n, steps, fbn):
     """csrc/lstm_coopw.hip: a wave owns 8 / 16 hidden units (1 / 2 gate-interleaved accumulator tiles) over the whole K, 12 / 6
     workgroups share a row tile, layer-skewed schedule with the waves as participants, no workgroup barrier in the time loop, x in
@@ -388,8 +390,8 @@ def test_measured_cost_table_can_be_adopted(tmp_path):
 
 @pytest.mark.parametrize("plan", ["default", "round4"])
 def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle(plan):
-    """B = 8 (65 row tiles) through the whole forward, cumulative norm (per-row (m, d) tables) included: the default plan (round 5:
-    42 row tiles on the wave-owned split at 64 units + 21 at 32 + 2 on the K split) and the round-4 plan (lstm_coopn.hip, one row
+    """B = 8 (65 row tiles) through the whole forward, cumulative norm (per-row (m, d) tables) included: the default plan (round 6:
+    64 row tiles on the wave-owned split at 96 units per workgroup + 1 on the K split) and the round-4 plan (lstm_coopn.hip, one row
     tile per group - what GRU models and the other hidden sizes still run)."""
     for norm in ("offline_laplace_norm", "cumulative_layer_norm"):
         args = {**DEFAULT_MODEL_ARGS, "norm_type": norm}
@@ -402,7 +404,7 @@ def test_forward_b8_coopn_equals_row_tile_kernel_and_oracle(plan):
             m.debug_set_costs(m.planner_costs_raw()[:19], 1)       # (neither the wave-owned split nor - round 6: cheap enough to lead - the half-tile ping-pong launches)
             assert [c["kernel"][:18] for c in m.describe_plan(8)] == ["lstm2_coopn_kernel"]
         else:
-            assert [c["kernel"][:18] for c in m.describe_plan(8)][:2] == ["lstm2_coopw_kernel"] * 2
+            assert [c["kernel"][:18] for c in m.describe_plan(8)] == ["lstm2_coopw_kernel", "lstm2_coop_kernel "]     # 64 tiles at 96 units + 1 K split
         a = m(*ins).cpu().numpy()
         m.check_errors()
         m.debug_set_lstm_coop(0)

@@ -752,7 +752,7 @@ def test_half_tile_hot_loops_keep_their_accumulators_in_agprs():
     assert len(res) >= 1
     for key, loops in res.items():
         assert len(loops) >= 3, (key, loops)
-        bf = "ELb1EEEv" in key                       # the bf16 ih-GEMM instantiation (round 4): its last loop is 2 x 24 bf16 MFMAs per k-step of 32
+        bf = "ELi2ELb1ELb" in key                    # the bf16 ih-GEMM instantiation <384, 40, 2, BF = true, OWN> (round 4): its last loop is 2 x 24 bf16 MFMAs per k-step of 32
         for l in loops:                              # (round 6: every weight fragment multiplies the hi AND the lo bf16 image of h0)
             assert l["gload"] == 24 and (l["mfma"] == 96 or (bf and l["mfma"] == 48)), (key, l)
             assert l["scratch"] == 0 and l["drain"] == 0 and l["acc_moves"] == 0, (key, l)
@@ -984,7 +984,7 @@ def test_wave_owned_column_split_index_maps_and_asm():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.analyse_wave_owned()
-    assert len(res) == 4, sorted(res)                                                         # NT in {1, 2} x K in {40, 64}
+    assert len(res) == 6, sorted(res)                                                         # NT in {1, 2, 3} x K in {40, 64}
     for name, r in res.items():
         nt = int(re.search(r"ILi384ELi\d+ELi(\d)E", name).group(1))
         depth = 8 if nt == 1 else 4
@@ -1050,7 +1050,7 @@ def test_subband_plans_cover_every_sequence_and_fit_the_chip(rows, gru):
         elif c["kind"] == 2:
             assert c["rpg"] in (1, 2) and c["par"] * 3 <= 256 and c["par"] * c["rpg"] >= c["tiles"]
         elif c["kind"] == 9:
-            assert not gru and c["par"] in (32, 64) and c["tiles"] * (384 // c["par"]) <= 256       # wave-owned column split (lstm_coopw.hip)
+            assert not gru and c["par"] in (32, 64, 96) and c["tiles"] * (384 // c["par"]) <= 256   # wave-owned column split (lstm_coopw.hip)
         else:
             assert not gru, "there is no row-tile GRU kernel"
     assert nxt == rows
@@ -1068,22 +1068,22 @@ def test_subband_plan_choices_match_the_design():
     assert kinds(514) == [(9, 514)] and _plan(514)[0]["par"] == 32 and _plan(514)[0]["tiles"] == 17     # B = 2: wave-owned split, 12 workgroups per tile
     assert kinds(1285) == [(9, 1285)] and _plan(1285)[0]["par"] == 64               # B = 5: 41 tiles, 6 workgroups per tile
     assert kinds(1285, gru=1) == [(1, 1285)] and _plan(1285, gru=1)[0]["par"] == 64   # (GRU: the K split, as in round 4)
-    p = _plan(2056)                                                                 # B = 8: 42 tiles at 64 units + 21 at 32 + 2 on the K split
-    assert [(c["kind"], c["par"], c["tiles"]) for c in p] == [(9, 64, 42), (9, 32, 21), (1, 8, 2)] and sum(c["rows"] for c in p) == 2056
+    p = _plan(2056)                                                                 # B = 8 (round 6): 64 of the 65 tiles in ONE launch at 96 units per
+    assert [(c["kind"], c["par"], c["tiles"]) for c in p] == [(9, 96, 64), (1, 8, 1)] and sum(c["rows"] for c in p) == 2056   # workgroup + 1 on the K split (round 5: 42 + 21 + 2)
     assert kinds(2056, gru=1) == [(2, 2056)] and _plan(2056, gru=1)[0]["rpg"] == 1  # (GRU: three-way split)
     assert kinds(4096) == [(4, 4096)] and _plan(4096)[0]["tiles"] == 256            # parity-mode B = 32: one round of 256 half tiles
     assert kinds(4112) == [(4, 4096), (1, 16)]                                      # B = 16: a half-tile round + 16 sequences K split
     p = _plan(4096, gru=1)                                                          # GRU has no half-tile kernel: 128 tiles = one per
     assert [c["kind"] for c in p] == [2, 1, 1] and p[0]["rpg"] == 1 and p[1]["par"] == 64 and p[2]["par"] == 8   # group + 42 + 1
     assert sum(c["rows"] for c in p) == 4096 and p[0]["tiles"] <= 85 and p[1]["tiles"] == 42 and p[2]["tiles"] <= 5
-    assert kinds(3300) == [(4, 3300)] and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~103 row tiles up
+    assert seq(3300) == [9, 9] and kinds(3500) == [(4, 3500)] and kinds(3855) == [(4, 3855)]   # the half tiles pay from ~106 row tiles up (104 = 62 + 42 wave-owned: 95 us against 103)
     assert seq(2800) == [9, 9, 1] and kinds(2800, gru=1)[0][0] == 2
     assert seq(4256) == [4, 1]                                                      # 133 tiles: half-tile round + 5 tiles K split
     assert kinds(5397) == [(4, 4096), (9, 1301)] and _plan(5397)[1]["par"] == 64    # B = 21, 169 tiles: half-tile round + 41 tiles wave-owned split
     assert kinds(5397, gru=1) == [(2, 5397)] and _plan(5397, gru=1)[0]["rpg"] == 2  # (108 + 48.5 us against 157 for two per group); GRU: two per group
     assert kinds(8224) == [(0, 8192), (1, 32)] and _plan(8224)[1]["par"] == 8       # B = 32: full round + leftover tile
     assert _plan(8224)[1]["rpg"] == 0 and _plan(16448)[1]["rpg"] == 0 and _plan(16448)[1]["tiles"] == 2   # (the role-split schedule was removed in round 4)
-    assert seq(10280) == [0, 9, 9, 1] and kinds(10280)[0] == (0, 8192)              # B = 40: a full round + 42 + 21 + 3 tiles
+    assert seq(10280) == [0, 9, 1] and kinds(10280)[0] == (0, 8192) and _plan(10280)[1]["par"] == 96   # B = 40: a full round + 64 + 2 tiles
     assert kinds(16448) == [(0, 16384), (1, 64)]                                    # B = 64: two rounds + 2 tiles
     assert kinds(7967) == [(0, 7967)] and _plan(7967)[0]["ex"] == 0                 # B = 31: 249 tiles, one launch
     assert kinds(8224, coop=0) == [(0, 8224)] and _plan(8224, coop=0)[0]["ex"] == 1  # column-split kernels off: VALU rows
@@ -1094,9 +1094,9 @@ def test_subband_plan_choices_match_the_design():
     assert sum(c["rows"] for c in g) == 65792 and all(c["kind"] == 1 for c in g[12:])   # the short rest K split
     g = _plan(8224, gru=1)                                                          # GRU, B = 32: 257 tiles = 170 + 85 + 2
     assert [c["kind"] for c in g] == [2, 2, 1] and g[0]["rpg"] == 2 and g[1]["rpg"] == 1 and sum(c["rows"] for c in g) == 8224
-    # B = 12: 97 tiles = 42 + 42 on the wave-owned split + 10 on the half-tile ping-pong launch + 3 K split (round 6: with lstm_hpw.hip's
-    # 11 us per step that beats a third wave-owned launch of 13 tiles - measured 13.19 against 13.54 ms per forward); half tiles from ~103 tiles
-    assert seq(3084) == [9, 9, 8, 1] and kinds(3400) == [(4, 3400)]
+    # B = 12: 97 tiles = 55 at 96 units per workgroup + 42 at 64 on the wave-owned split (round 6: 12.4 ms per forward; round 5: three
+    # launches, 13.5); half tiles from ~103 tiles
+    assert seq(3084) == [9, 9] and [c["par"] for c in _plan(3084)] == [96, 64] and kinds(3400) == [(4, 3400)]
     p = _plan(3084, gru=1)                                                          # (GRU: 97 tiles = one per group + the rest K split)
     assert p[0]["kind"] == 2 and p[0]["rpg"] == 1 and p[0]["tiles"] == 85 and all(c["kind"] == 1 for c in p[1:]) and sum(c["rows"] for c in p) == 3084
     assert seq(4112, gru=1) == [2, 1, 1]                                            # GRU B = 16: 129 tiles = 85 + 42 + 2

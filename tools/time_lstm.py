@@ -26,7 +26,7 @@ if os.environ.get("PIN_R01"):
 if os.environ.get("COOPW"):                     # only the wave-owned column split (csrc/lstm_coopw.hip) at COOPW = 32 / 64 units per workgroup
     u = int(os.environ["COOPW"])
     wv = [5.0 if 32 * (i + 1) == u else 900.0 for i in range(2)]
-    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + wv + wv, 1)
+    m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [900.0, 900.0] + wv + wv + ([5.0, 5.0] if u == 96 else [900.0, 900.0]), 1)
     assert all(c["kernel"].startswith("lstm2_coopw_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
 if os.environ.get("NOCOOPW"):                   # the round-4 plans: no wave-owned column split
     m.debug_set_costs(list(m.planner_costs_raw())[:21], 1)
