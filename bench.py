@@ -427,12 +427,14 @@ def main():
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic,
                      "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of every round by "
-                                       "tools/gpu_r05_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
+                                       "tools/gpu_r06_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
                      # the same rate against what THIS box's matrix pipes held in a pure-MFMA probe right before / after the loops
                      # (box.mfma_peak_tflops: the lower of the two) - a slow box shows as frac < frac_of_box_peak, a slow kernel in both
                      "frac_of_box_peak": (achieved / box_peak) if box_peak else None,
                      "flops_per_launch": lstm_flops, "avg_launch_ms": lstm_ms, "avg_launch_ms_runs": launch_runs,
-                     # workgroup 0 of the last dominant launch: its wall time by the 100 MHz clock and the rate of s_memtime over it
+                     # the last dominant launch from the inside: workgroup 0's wall time (100 MHz clock) and the shader clock it held
+                     # (s_memtime = shader cycles), and the wall time of the launch's slowest / fastest workgroup - the launch lasts as
+                     # long as its slowest workgroup, and the XCDs of a chip do not all hold the same clock
                      "last_launch_clock": launch_clock,
                      # ... and the rate against the peak AT THAT CLOCK (65,536 FLOP per shader cycle on 256 CUs): the kernel needs a
                      # fixed number of cycles per launch, its milliseconds follow the clock the box holds
@@ -465,9 +467,8 @@ def main():
                           "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}, "roofline_of_rank": slow}
     if rank == 0 and not args.no_cpu_baseline:           # (rank 0 only; at N > 1 the other ranks wait in destroy_process_group)
         base, ref_outs = cpu_baseline(sd, cpu_in, args.cpu_budget_s, args.norm, fsn)
-        ref_path = os.path.join(ROOT, "profiles", "r05_cli_e2e.json")   # the REAL reference class timed on a GPU box's host cores
-        if not os.path.exists(ref_path):
-            ref_path = os.path.join(ROOT, "profiles", "r04_cli_e2e.json")
+        ref_path = next((p for p in (os.path.join(ROOT, "profiles", f"r0{n}_cli_e2e.json") for n in (6, 5, 4)) if os.path.exists(p)),
+                        os.path.join(ROOT, "profiles", "r04_cli_e2e.json"))    # the REAL reference class timed on a GPU box's host cores
         if os.path.exists(ref_path) and not fsn:                        # (tools/cli_e2e.py; the reference is not on this box)
             with open(ref_path) as f:
                 rm = json.load(f)["reference_cpu_forward"]

@@ -255,7 +255,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
         if (a.md_row) ca.md_row = a.md_row + (size_t)c.slot0 * a.Tp;
         if (c.kind == 0) {
             if (h->gru) launch_gru(h->lw, ca, s);
-            else { ca.clk = reinterpret_cast<unsigned long long*>(h->d_err) + 8; launch_lstm(h->lw, ca, s); }
+            else { ca.clk = h->d_clk; launch_lstm(h->lw, ca, s); }
             continue;
         }
         if (c.kind == 4) { launch_lstm16(h->lw, ca, s); continue; }
@@ -967,6 +967,12 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
         return 4;
     }
     memset(h->d_err, 0, 256);
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_clk), 64) != hipSuccess || hipMemset(h->d_clk, 0, 64) != hipSuccess) {
+        set_error("hipMalloc of the clock stamps failed");
+        (void)hipHostFree(h->d_err);
+        delete h;
+        return 4;
+    }
     const char* dbg = getenv("FSNP_DEBUG_STAGES");
     h->debug = dbg && dbg[0] == '1';
     *out = h;
@@ -986,6 +992,7 @@ void fsnp_destroy(fsnp_handle* h) {
     drop_weight_watch(h);
     if (h->verify_out) (void)hipFree(h->verify_out);
     if (h->verify_key) (void)hipFree(h->verify_key);
+    if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->vs_buf) (void)hipFree(h->vs_buf);
     if (h->vs_stream) (void)hipStreamDestroy(h->vs_stream);
     if (h->ev_vs_snap) (void)hipEventDestroy(h->ev_vs_snap);
@@ -1504,14 +1511,20 @@ int fsnp_debug_pp_profile(fsnp_handle* h, const float* x, float* out, int32_t nu
     return fsnp_check_errors(h);
 }
 
-int fsnp_debug_launch_clock(fsnp_handle* h, double out[4]) {
+int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]) {
     if (!h || !out) { set_error("fsnp_debug_launch_clock: null argument"); return 1; }
-    const volatile unsigned long long* c = reinterpret_cast<const volatile unsigned long long*>(h->d_err) + 8;
+    unsigned long long c[8] = {};
+    if (!h->d_clk) { set_error("fsnp_debug_launch_clock: no completed launch of the one-tile-per-CU LSTM kernel on this handle"); return 2; }
+    FSNP_ON_DEVICE(h);
+    FSNP_HIP_CHECK(hipMemcpy(c, h->d_clk, sizeof(c), hipMemcpyDeviceToHost));
     const unsigned long long t0 = c[0], r0 = c[1], t1 = c[2], r1 = c[3];
     if (r0 == 0 || r1 <= r0 || t1 <= t0) { set_error("fsnp_debug_launch_clock: no completed launch of the one-tile-per-CU LSTM kernel on this handle"); return 2; }
     out[0] = (double)(t1 - t0); out[1] = (double)(r1 - r0);
     out[2] = (double)(r1 - r0) * 1e-5;                          // 100 MHz ticks -> ms
     out[3] = (double)(t1 - t0) / (double)(r1 - r0) * 100.0;     // s_memtime ticks per microsecond
+    out[4] = (double)c[4] * 1e-5;                               // the slowest workgroup of the launch, ms
+    out[5] = c[6] == ~0ull ? 0.0 : (double)c[6] * 1e-5;         // the fastest
+    out[6] = (double)c[5];                                      // the largest s_memtime tick count of a workgroup
     return 0;
 }
 

@@ -250,8 +250,9 @@ struct LstmArgs {
                                // h0 of row 0 at step coop_corrupt - 1 with 1.0 added (its own state stays right): a corrupted exchange image
     int coop_chaos;            // test hook (fsnp_debug_set_chaos): != 0 = seed of pseudo-random, workgroup-uniform delays at the phase boundaries
                                // of the column-split kernels, so that the workgroups of a launch drift apart instead of running in lockstep
-    unsigned long long* clk;   // one-tile-per-CU LSTM kernel (lstm.hip) only, optional: workgroup 0 writes {s_memtime, s_memrealtime} when it starts
-                               // into clk[0..1] and when it ends into clk[2..3] (host-mapped: fsnp_debug_launch_clock - which clock did the launch hold?)
+    unsigned long long* clk;   // one-tile-per-CU LSTM kernel (lstm.hip) only, optional (device memory, 8 words): workgroup 0 writes {s_memtime,
+                               // s_memrealtime} when it starts into clk[0..1] and when it ends into clk[2..3]; every workgroup folds its duration into
+                               // clk[4] (max, 100 MHz ticks), clk[5] (max, s_memtime ticks), clk[6] (min, 100 MHz ticks): fsnp_debug_launch_clock
 };
 
 struct LstmPlan { int num_tiles, ex, rows_per_slot_tile; };

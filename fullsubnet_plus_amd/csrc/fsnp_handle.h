@@ -101,7 +101,7 @@ struct fsnp_handle {
     int coop_w = 1;              // ... and the planner may use it (FSNP_COOP_W=0: never)
     unsigned* d_err = nullptr;   // [0] = error bits of finished launches (kErr*): an inter-workgroup wait timed out in a column-split LSTM
                                  // kernel / the watched source tensors no longer match the packed weights / a verification pass
-                                 // disagreed; [16..23] = clock stamps of the last one-tile-per-CU LSTM launch (fsnp_debug_launch_clock).  Host-mapped, so the NEXT call on
+                                 // disagreed.  Host-mapped, so the NEXT call on
                                  // the handle can fail loudly without a device synchronisation
     // fsnp_watch_weights: the caller's SOURCE tensors of the packed weights, fingerprinted on the device in front of every forward
     void* watch_segs = nullptr;              // device: WatchSeg[watch_nseg]
@@ -112,6 +112,7 @@ struct fsnp_handle {
     int verify_every = 0;
     long long verify_calls = 0, verify_runs = 0;
     float* verify_out = nullptr;             // scratch mask of the verification pass (stream-ordered allocation)
+    unsigned long long* d_clk = nullptr;     // device: clock stamps of the last one-tile-per-CU LSTM launch (LstmArgs::clk, fsnp_debug_launch_clock)
     unsigned long long* verify_key_sampled = nullptr;   // the same key of the sampled check (inside vs_buf)
     unsigned long long* verify_key = nullptr; // device: smallest (utterance << 44 | bin << 24 | frame) at which a verification pass disagreed
     size_t verify_bytes = 0;

@@ -288,9 +288,13 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 
     // which clock does this launch hold?  workgroup 0 stamps the shader-side counter and the 100 MHz wall clock on entry and on exit
     // (straight to host-mapped memory: nothing stays live across the time loop); bench.py reports the ratio (fsnp_debug_launch_clock)
-    if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {
-        a.clk[1] = __builtin_amdgcn_s_memrealtime();
-        a.clk[0] = __builtin_amdgcn_s_memtime();
+    // ... and EVERY workgroup folds its own duration into a maximum / minimum (one 64-bit atomic each at the very end): the launch lasts as
+    // long as its slowest workgroup, and the chip's XCDs do not hold the same clock (profiles/r06_box_variance.md)
+    __shared__ unsigned long long clk_s[2];
+    if (a.clk != nullptr && tid == 0) {
+        clk_s[1] = __builtin_amdgcn_s_memrealtime();
+        clk_s[0] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 0) { a.clk[0] = clk_s[0]; a.clk[1] = clk_s[1]; a.clk[4] = 0ull; a.clk[5] = 0ull; a.clk[6] = ~0ull; }
     }
 
     for (int i = tid; i < (KGX + 2 * KGH) * (64 + 2 * EX); i += NTHR) Xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -517,9 +521,12 @@ void lstm2_fc_kernel(LstmWeights w, LstmArgs a) {
 #undef FSNP_STAMP
     __syncthreads();
     fc_store(Tp - 1);
-    if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {
-        a.clk[2] = __builtin_amdgcn_s_memtime();
-        a.clk[3] = __builtin_amdgcn_s_memrealtime();
+    if (a.clk != nullptr && tid == 0) {
+        const unsigned long long m1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) { a.clk[2] = m1; a.clk[3] = r1; }
+        atomicMax(a.clk + 4, r1 - clk_s[1]);
+        atomicMax(a.clk + 5, m1 - clk_s[0]);
+        atomicMin(a.clk + 6, r1 - clk_s[1]);
     }
 }
 

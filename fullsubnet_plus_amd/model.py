@@ -686,10 +686,12 @@ class _HipModel(nn.Module):
     def launch_clock(self):
         """-> {"wall_ms", "s_memtime_ticks", "s_memtime_mhz"} of the LAST launch of the one-tile-per-CU LSTM kernel on this handle, as its
         workgroup 0 stamped them (fsnp_debug_launch_clock; synchronise first), or None if there was no such launch."""
-        out = (ctypes.c_double * 4)()
-        if _lib.load().fsnp_debug_launch_clock(self._handle, ctypes.byref(out)) != 0:
-            return None
-        return {"wall_ms": out[2], "s_memtime_ticks": out[0], "s_memtime_mhz": out[3]}
+        out = (ctypes.c_double * 7)()
+        with torch.cuda.device(self._hip.device):
+            if _lib.load().fsnp_debug_launch_clock(self._handle, ctypes.byref(out)) != 0:
+                return None
+        return {"wall_ms": out[2], "s_memtime_ticks": out[0], "s_memtime_mhz": out[3], "slowest_workgroup_ms": out[4],
+                "fastest_workgroup_ms": out[5], "most_cycles_of_a_workgroup": out[6]}
 
     def describe_plan(self, batch, parity=False):
         """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups", "deferred_when_pipelined"}, ...]: how the

@@ -183,10 +183,14 @@ int fsnp_debug_verify_sample_stats(const fsnp_handle* h, int64_t out[3]);
 #define FSNP_BOX_PROBE_VALUES 9
 int fsnp_debug_box_probe(double target_ms, double out[FSNP_BOX_PROBE_VALUES], void* hip_stream);
 /* The clocks of the LAST launch of the one-tile-per-CU LSTM kernel (csrc/lstm.hip) on this handle: its workgroup 0 stamps s_memtime
- * and s_memrealtime when it starts and when it ends (four scalar instructions outside the time loop).  out[0] = s_memtime ticks,
- * out[1] = s_memrealtime ticks (10 ns each), out[2] = kernel wall time in ms as workgroup 0 saw it, out[3] = s_memtime rate in MHz
- * over the launch.  The caller synchronises first; returns 2 if no such launch has completed. */
-int fsnp_debug_launch_clock(fsnp_handle* h, double out[4]);
+ * (= shader cycles) and s_memrealtime (100 MHz) when it starts and when it ends, and every workgroup folds its own duration into a
+ * maximum / minimum (a handful of scalar instructions and three atomics per workgroup, outside the time loop).  out[0] = workgroup 0's
+ * s_memtime ticks, out[1] = its s_memrealtime ticks (10 ns each), out[2] = its wall time in ms, out[3] = the shader clock it held in MHz,
+ * out[4] / out[5] = wall time of the SLOWEST / fastest workgroup of the launch in ms (the launch lasts as long as its slowest workgroup;
+ * the XCDs of a chip do not all hold the same clock), out[6] = the largest shader-cycle count of a workgroup.  The caller synchronises
+ * first; returns 2 if no such launch has completed. */
+#define FSNP_LAUNCH_CLOCK_VALUES 7
+int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]);
 
 #ifdef __cplusplus
 }

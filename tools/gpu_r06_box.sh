@@ -34,7 +34,7 @@ try:
     print(f"{tag}: {r['value']:.0f} frames/s  ms/step {r['ms_per_step']:.3f} runs {['%.3f' % x for x in r['ms_per_step_runs']]}  "
           f"back-to-back {r['alt_ms_per_step']:.3f}  drop-in {r['dropin_ms_per_step']:.3f}")
     print(f"   dominant launch {r['roofline']['avg_launch_ms']:.3f} ms runs {['%.3f' % x for x in r['roofline']['avg_launch_ms_runs']]}  frac {r['roofline']['frac']:.4f}  "
-          f"frac_of_box_peak {r['roofline']['frac_of_box_peak']:.4f}  clock {r['roofline']['last_launch_clock']}")
+          f"frac_of_box_peak {r['roofline']['frac_of_box_peak']:.4f}  frac_at_held_clock {r['roofline']['frac_at_held_clock']:.4f}  clock {r['roofline']['last_launch_clock']}")
     print(f"   box peak {b['mfma_peak_tflops']:.2f} TFLOP/s (before {b['probe_before']['mfma_tflops']:.2f} @ {b['probe_before']['clock_mhz']:.0f} MHz, "
           f"after {b['probe_after']['mfma_tflops']:.2f} @ {b['probe_after']['clock_mhz']:.0f} MHz)  sampled {b['during_timed_loops']}")
 except Exception as e:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5 evidence run.  Usage (from the build container): gpurun -- "FSNP_HEAD=<commit> bash tools/gpu_r05_final.sh [ref]"
+# round 6 evidence run.  Usage (from the build container): gpurun -- "FSNP_HEAD=<commit> bash tools/gpu_r06_final.sh [ref]"
 #   1. the whole GPU suite (run A), smoke, the headline exactly as the driver runs it
 #   2. rocprofv3 kernel stats of that command (serving loop), of the back-to-back loop and of B = 1 / B = 2; PMC passes of the dominant kernel
 #      (each counter set in its own run) -> profiles/lstm_pmc.json
@@ -12,7 +12,7 @@ REF=${1:-}          # (saved: the column-split timing loop below re-uses the pos
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-digest() { cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h | sha256sum | cut -c1-16; }
+digest() { cat fullsubnet_plus_amd/csrc/*.hip fullsubnet_plus_amd/csrc/*.h fullsubnet_plus_amd/csrc/*.cpp include/fsnp.h include/fsnp_debug.h | sha256sum | cut -c1-16; }
 suite() {   # $1 = log name
   {
     echo "commit: ${FSNP_HEAD:-unknown}   csrc sha256[:16] at start: $(digest)   library stamp: $(cut -c1-16 fullsubnet_plus_amd/libfsnp_hip.so.stamp)   $(date -u +%FT%TZ)"
@@ -57,7 +57,7 @@ for i in (1, 2, 3, 4):
 if {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <= set(vals):
     out = {"kernel": "lstm2_fc_kernel<384,40,2,EX=0,NW=4> (the first chunk of the B=32 plan: 8192 of the 8224 sequences)",
            "workload": "B=32 x 2 s, full mode: 8192 sequences x 128 steps on the one-tile-per-CU kernel (+ 32 on a K-split kernel)",
-           "source": "rocprofv3 --pmc, separate passes (tools/gpu_r05_final.sh, final run of round 5 at HEAD); profiles/r05_pmc_summary.txt",
+           "source": "rocprofv3 --pmc, separate passes (tools/gpu_r06_final.sh, final run of round 6 at HEAD); profiles/r06_pmc_summary.txt",
            "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
            "TCC_HIT_per_launch": vals.get("TCC_HIT_sum"), "TCC_MISS_per_launch": vals.get("TCC_MISS_sum"),
            "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": vals["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE_per_launch": vals["GRBM_GUI_ACTIVE"],
@@ -69,20 +69,22 @@ if {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <
 PY
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
 : > gpurun_out/b_final.log
-for args in "--batch 1" "--batch 2" "--batch 3" "--batch 4" "--batch 5" "--batch 8" "--batch 12" "--batch 16" "--batch 21" "--batch 31" "--batch 40" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--mode parity --precision bf16_ih" "--precision bf16_ih" "--batch 16 --precision bf16_ih" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--model fullsubnet --batch 4" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
-  timeout 400 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 >> gpurun_out/b_final.log
+for args in "--batch 1" "--batch 2" "--batch 3" "--batch 4" "--batch 5" "--batch 6" "--batch 7" "--batch 8" "--batch 10" "--batch 12" "--batch 16" "--batch 21" "--batch 31" "--batch 40" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--mode parity --precision bf16_ih" "--precision bf16_ih" "--batch 16 --precision bf16_ih" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--model fullsubnet --batch 4" "--model fullsubnet --batch 8" "--model fullsubnet --batch 16" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
+  timeout 400 python bench.py $args --steps 10 --warmup 2 --no-cpu-baseline --probe-ms 0 2>&1 | tail -1 >> gpurun_out/b_final.log
 done
-python tools/make_config_table.py r05 > /dev/null
+python tools/make_config_table.py r06 > /dev/null
 python tools/dump_costs.py > gpurun_out/dump_costs.log 2>&1
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_rccl_n1.log
 timeout 120 python tools/pp_phase_profile.py 257 64 0 2>&1 | grep -v amdgpu > gpurun_out/hp_phase_profile.txt
 timeout 120 python tools/pp_phase_profile.py 514 64 32 2>&1 | grep -v amdgpu > gpurun_out/coopw_phase_profile.txt
 timeout 120 python tools/pp_phase_profile.py 1285 64 64 2>&1 | grep -v amdgpu >> gpurun_out/coopw_phase_profile.txt
+timeout 120 python tools/pp_phase_profile.py 2048 64 96 2>&1 | grep -v amdgpu >> gpurun_out/coopw_phase_profile.txt
 {
   echo "== per-step times of the column-split kernels (tools/time_lstm.py, 128 steps)"
-  for pair in "514 32" "672 32" "1285 64" "1344 64" "32 32" "32 64"; do set -- $pair; COOPW=$2 timeout 120 python tools/time_lstm.py $1 128 5 2>&1 | tail -1; done
+  for pair in "514 32" "672 32" "1285 64" "1344 64" "2048 96" "32 32" "32 64" "32 96"; do set -- $pair; COOPW=$2 timeout 120 python tools/time_lstm.py $1 128 5 2>&1 | tail -1; done
   for n in 514 1285 2056; do NOCOOPW=1 timeout 120 python tools/time_lstm.py $n 128 5 2>&1 | tail -1; timeout 120 python tools/time_lstm.py $n 128 5 2>&1 | tail -1; done
   HP=1 timeout 100 python tools/time_lstm.py 257 128 5 2>&1 | tail -1
+  FSNP_HP_WAVE=0 HP=1 timeout 100 python tools/time_lstm.py 257 128 5 2>&1 | tail -1 | sed "s/^/FSNP_HP_WAVE=0 (lstm_hp.hip) /"
 } > gpurun_out/column_split_times.txt 2>&1
 python - <<'PY' | tee gpurun_out/verify_overhead.txt
 # exchange verification (fsnp_set_verify): per-forward overhead at N = 64 and the cost of one verified forward, B = 1 and B = 32
