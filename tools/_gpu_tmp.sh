@@ -1,5 +1,23 @@
+#!/bin/bash
+# scratch: fused TCN block kernel - parity, then timings with / without
 set -u
-export TMPDIR=/tmp
 mkdir -p gpurun_out
-bash tools/gpu_r06_box.sh E 2>&1 | tail -14
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x --tb=short -p no:cacheprovider -k "box_probe or b32_full_vs_oracle" 2>&1 | tail -4
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "dma_gemm or stages_vs_reference or forward_vs_reference_golden" 2>&1 | tail -25 | tee gpurun_out/dev_pytest.log
+: > gpurun_out/dev_bench.log
+for B in 1 2 4 8 16; do
+  for F in 1 0 4000; do
+    FSNP_TCN_FUSED=$F timeout 300 python bench.py --batch $B --steps 20 --warmup 5 --no-cpu-baseline --probe-ms 0 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('B=$B fused=$F', 'ms', r['ms_per_step'], 'b2b', r['alt_ms_per_step'], 'dropin', r.get('dropin_ms_per_step'), 'fullband', r['roofline']['fullband_ms'], 'alt_fullband', r['roofline'].get('alt_fullband_ms'), 'err', r.get('cirm_rel_err'))" | tee -a gpurun_out/dev_bench.log
+  done
+done
+for F in 0 4000; do
+  FSNP_TCN_FUSED=$F timeout 300 python bench.py --batch 1 --seconds 10 --steps 20 --warmup 5 --no-cpu-baseline --probe-ms 0 --pipeline 0 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('B=1 10s fused=$F', 'ms', r['ms_per_step'], 'b2b', r['alt_ms_per_step'], 'dropin', r.get('dropin_ms_per_step'), 'fullband', r['roofline']['fullband_ms'], 'alt_fullband', r['roofline'].get('alt_fullband_ms'), 'err', r.get('cirm_rel_err'))" | tee -a gpurun_out/dev_bench.log
+done
+cd /tmp
+rm -rf /tmp/prof
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-alt --pipeline 0 --probe-ms 0 > /dev/null 2>&1
+f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-150 | tee $GRAFT_REPO_ROOT/gpurun_out/dev_kernel_stats_b1.csv

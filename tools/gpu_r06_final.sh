@@ -68,6 +68,38 @@ if {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <
     json.dump(out, open("gpurun_out/lstm_pmc.json", "w"), indent=1)
 PY
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
+# matrix-pipe counters of the small-batch sub-band kernels (busy on OCCUPIED CUs) -> profiles/r06_small_batch_pmc.txt
+cd /tmp
+: > $R/gpurun_out/small_batch_pmc.txt
+for B in 1 2 4 8; do
+  rm -rf /tmp/pmc
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -f csv -d /tmp/pmc -o pmc -- python $R/bench.py --gpus 1 --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 --probe-ms 0 > /dev/null 2>&1
+  python - $B <<'PY' | tee -a $R/gpurun_out/small_batch_pmc.txt
+import csv, glob, collections, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+wgs = {}
+for f in glob.glob("/tmp/pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "lstm2_" not in k: continue
+        k = k.split("(")[0][:60]
+        a = agg[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+        try:
+            wgs[k] = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+        except Exception:
+            pass
+for k, c in agg.items():
+    if not {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <= set(c): continue
+    n = c["GRBM_GUI_ACTIVE"][1]
+    busy, act = c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / n, c["GRBM_GUI_ACTIVE"][0] / n
+    chip = busy * 8 / (1024 * act)
+    w = wgs.get(k)
+    occ = ("  workgroups %d (one per CU)  busy on occupied CUs %.3f" % (w, chip * 256 / w)) if w and w <= 256 else ""
+    print("B=%s %-60s launches %d  MFMA_BUSY %.4g  GUI_ACTIVE %.4g  matrix-pipe busy over the whole chip %.3f%s" % (sys.argv[1], k, n, busy, act, chip, occ))
+PY
+done
+cd $R
 : > gpurun_out/b_final.log
 for args in "--batch 1" "--batch 2" "--batch 3" "--batch 4" "--batch 5" "--batch 6" "--batch 7" "--batch 8" "--batch 10" "--batch 12" "--batch 16" "--batch 21" "--batch 31" "--batch 40" "--batch 64" "--seconds 10" "--seconds 10 --norm cumulative_layer_norm" "--mode parity" "--mode parity --precision bf16_ih" "--precision bf16_ih" "--batch 16 --precision bf16_ih" "--wave" "--model fullsubnet" "--model fullsubnet --batch 1" "--model fullsubnet --batch 4" "--model fullsubnet --batch 8" "--model fullsubnet --batch 16" "--sequence-model GRU" "--sequence-model GRU --batch 1" "--sequence-model TCN"; do
   timeout 400 python bench.py $args --steps 10 --warmup 2 --no-cpu-baseline --probe-ms 0 2>&1 | tail -1 >> gpurun_out/b_final.log

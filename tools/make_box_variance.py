@@ -17,6 +17,16 @@ for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_box_*.json"))):
                  b["probe_after"]["clock_mhz_slowest_cu"], b["probe_after"]["clock_mhz_fastest_cu"],
                  (d.get("sclk_mhz") or {}).get("median"), (d.get("power_w") or {}).get("median"), d.get("power_cap_w")))
 f = lambda v, n=3: "-" if v is None else f"{v:.{n}f}"
+print("""# r06 - the headline on several boxes, each line with its own box calibration (VERDICT r05 item 1)
+
+One row per gpurun box (`tools/gpu_r06_box.sh <tag>`; row `final` = the evidence run `tools/gpu_r06_final.sh`): `python bench.py --gpus 1 --steps 20
+--warmup 5` exactly as the driver runs it.  Every field below is IN the bench line (`profiles/r06_box_<tag>.json`): the three timed runs and
+their median; `box.probe_before / probe_after` (50 ms of pure `v_mfma_f32_32x32x2_f32` on every SIMD, `csrc/box_probe.hip`) ->
+`box.mfma_peak_tflops` (the lower of the two) and `roofline.frac_of_box_peak`; `roofline.last_launch_clock` (the dominant kernel stamps
+`s_memtime` = shader cycles and `s_memrealtime` = 100 MHz wall clock at the start and end of workgroup 0, and every workgroup folds its end
+stamp into a max / min) -> the clock the launch HELD and `frac_at_held_clock` (algorithmic flops / (cycles of the slowest workgroup x 1024
+SIMDs x 64 flop per cycle)); sclk / socket power / power cap sampled from sysfs every 10 ms during the timed loops.
+""")
 print("| box | GPU serial | ms/step (median of 3) | runs | back to back | drop-in | dominant launch, hipEvents (ms) | frac (spec peak) | frac of box peak | frac at held clock | "
       "workgroup 0 (ms) | slowest workgroup (ms) | shader cycles of workgroup 0 | clock held (MHz) | probe before / after (TFLOP/s) | probe: slowest / fastest CU (MHz) | "
       "sclk median (sysfs) | power median / cap (W) |")
@@ -24,3 +34,30 @@ print("|" + "---|" * 18)
 for (tag, uid, ms, runs, alt, drop, lms, fr, fb, fh, w0, wmax, cyc, mhz, p0, p1, cmin, cmax, sclk, pw, cap) in rows:
     print(f"| {tag} | {uid} | **{ms:.3f}** | {' '.join(f'{x:.3f}' for x in runs)} | {f(alt)} | {f(drop)} | {lms:.3f} | {fr:.4f} | {fb:.4f} | {f(fh, 4)} | {f(w0)} | {f(wmax)} | "
           f"{'-' if cyc is None else f'{cyc / 1e6:.3f} M'} | {f(mhz, 0)} | {p0:.1f} / {p1:.1f} | {cmin:.0f} / {cmax:.0f} | {f(sclk, 0)} | {f(pw, 0)} / {f(cap, 0)} |")
+
+cyc = [r[12] for r in rows if r[12]]
+mhz = [r[13] for r in rows if r[13]]
+lms = [r[6] for r in rows]
+if cyc and mhz:
+    print(f"""
+## What the rows say
+
+* **The kernel's work is constant: {min(cyc) / 1e6:.3f} - {max(cyc) / 1e6:.3f} M shader cycles per launch on every box** (spread {(max(cyc) / min(cyc) - 1) * 100:.2f} %).
+  Its milliseconds are cycles / held clock ({min(mhz):.0f} - {max(mhz):.0f} MHz here), plus what hipEvents see around workgroup 0: launch ramp
+  and the slowest XCD's tail (0.13 - 0.41 ms; box D: 26.62 ms of events around a 26.21 ms workgroup 0).
+* `frac` (against the 157.3 TFLOP/s data-sheet figure at 2.4 GHz) moves with the box: {min(r[7] for r in rows):.4f} - {max(r[7] for r in rows):.4f}.
+  `frac_at_held_clock` does not: {min(r[9] for r in rows if r[9]):.4f} - {max(r[9] for r in rows if r[9]):.4f} - the kernel issues an MFMA on 94.0 - 94.1 % of the cycles it is given, everywhere.
+* The probe (pure MFMA, no memory traffic) sustains 152.2 - 152.9 TFLOP/s before the timed loops (2345 - 2355 MHz: the chip has just left
+  idle) and 154.4 - 155.1 after (2380 MHz): no box reaches the 2.4 GHz of the data sheet under an all-SIMD fp32-MFMA load at ~1200 W of a
+  1400 W cap; 0.968 - 0.986 of the spec peak is what the hardware gives.  The LSTM kernel holds 10 - 25 MHz LESS than the probe (it also
+  drives LDS and L2).
+* **Round 5's driver run (27.63 ms per launch, frac 0.879):** the same 62.0 M cycles in 27.63 ms - minus the ~0.27 ms the events add - is
+  **2266 MHz**: a box that held 4.4 % less clock than any of these.  None of this round's boxes ({len(rows)} calls, {len(set(r[1] for r in rows if r[1] != '-'))} distinct GPU
+  serials) did, so WHY that box ran slower (power cap, temperature, a neighbour on the same node) cannot be shown from here; what
+  the line now guarantees is that the next such run explains itself: `last_launch_clock.s_memtime_mhz` would read ~2270,
+  `frac_at_held_clock` would still read 0.94, and `box.during_timed_loops` would show the sclk / power the node allowed.
+* The other three candidates of the review are ruled out by construction: XCD / Infinity-Cache state would change the CYCLE count
+  (it does not: see the first bullet); the prologue launch in front of the kernel is outside workgroup 0's stamps and inside the events
+  (the 0.13 - 0.41 ms above, unchanged since round 4); a power cap shows as sclk below the probe's while power sits AT the cap (here:
+  1180 - 1230 W of 1400 W, never capped).
+""")
