@@ -345,16 +345,20 @@ static int plan_first_deferred(const fsnp_handle* h, const SbPlan& plan) {
     return (first < n && busiest <= h->num_cus_real - 32) ? first : n;
 }
 
-// One launch per TCNBlock (tcn_fused.hip) instead of three: planned while the launch is latency-bound - at most `tcn_fused_max_wgs`
-// workgroups (measured: profiles/r06_fullband.md) - and one plane's workgroups fit, two per CU, into the 32 CUs a deferred column-split
-// launch of the pipelined loop is guaranteed to leave (plan_first_deferred).  Off with the column-split kernels (FSNP_LSTM_COOP=0, the
-// retry after a time-out: no inter-workgroup waits at all then), with FSNP_TCN_FUSED=0 and with fsnp_debug_set_gemm_dma != 1.
-static bool tcn_fused_planned(const fsnp_handle* h, const Dims& d) {
+// The TCNBlock stack in one launch (tcn_fused.hip) instead of 24: planned while the launch is latency-bound - at most `tcn_fused_max_wgs`
+// workgroups (measured: profiles/r06_fullband.md) - and one plane's workgroups, ONE per CU, fit beside whatever this handle may have in
+// flight: a deferred column-split launch of the pipelined loop owns its CUs (plan_first_deferred: it leaves >= 32), the sampled
+// verification two.  Off with the column-split kernels (FSNP_LSTM_COOP=0, the retry after a time-out: no inter-workgroup waits at all
+// then), with FSNP_TCN_FUSED=0 and with fsnp_debug_set_gemm_dma != 1.
+static bool tcn_fused_planned(const fsnp_handle* h, const Dims& d, const SbPlan& plan) {
     if (!h->lstm_coop || !h->tcn_fused || h->tw.gemm_dma != 1 || !tcn_fused_available(d, h->tw)) return false;
-    // one plane's workgroups must be co-resident (four fit a CU: 10 KiB of LDS, <= 128 registers).  The only launches of this handle that
-    // can run beside them are deferred column-split launches of the pipelined loop, which leave >= 32 CUs (plan_first_deferred)
     const int per_plane = tcn_fused_workgroups_per_plane(d);
-    if (per_plane > (h->pipeline ? 4 * 32 : 4 * (h->num_cus_real - 16))) return false;
+    int free_cus = h->num_cus_real - 8;
+    if (h->pipeline) {
+        const int first = plan_first_deferred(h, plan);
+        for (int i = first; i < (int)plan.chunks.size(); ++i) free_cus = std::min(free_cus, h->num_cus_real - chunk_workgroups(h, plan.chunks[i]) - 2);
+    }
+    if (per_plane > free_cus) return false;
     return (long)per_plane * 3 * d.B <= h->tcn_fused_max_wgs;
 }
 
@@ -1026,6 +1030,7 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->verify_out) (void)hipFree(h->verify_out);
     if (h->verify_key) (void)hipFree(h->verify_key);
     if (h->d_clk) (void)hipFree(h->d_clk);
+    if (h->d_tcn_prof) (void)hipFree(h->d_tcn_prof);
     if (h->vs_buf) (void)hipFree(h->vs_buf);
     if (h->vs_stream) (void)hipStreamDestroy(h->vs_stream);
     if (h->ev_vs_snap) (void)hipEventDestroy(h->ev_vs_snap);
@@ -1150,9 +1155,10 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
         // the caller's tensors are read by the repack kernel only; everything up to the LSTM then stays in the workspace
         launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s);
-        tbuf.fused = tcn_fused_planned(h, d) ? 1 : 0;
+        tbuf.fused = tcn_fused_planned(h, d, plan) ? 1 : 0;
         tbuf.fused_abort = reinterpret_cast<unsigned*>(base + w.coop_abort) + 32;
         tbuf.fused_err = h->d_err;
+        tbuf.fused_prof = h->d_tcn_prof;
         if (tbuf.fused) launch_tcn_chained(h->device, s, h, [&] { launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s); });
         else launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
@@ -1562,6 +1568,23 @@ int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]
     out[4] = (double)c[4] * 1e-5;                               // the slowest workgroup of the launch, ms
     out[5] = c[6] == ~0ull ? 0.0 : (double)c[6] * 1e-5;         // the fastest
     out[6] = (double)c[5];                                      // the largest s_memtime tick count of a workgroup
+    return 0;
+}
+
+int fsnp_debug_tcn_profile(fsnp_handle* h, int32_t enable, double out[8]) {
+    if (!h) { set_error("fsnp_debug_tcn_profile: null handle"); return 1; }
+    FSNP_ON_DEVICE(h);
+    if (enable && !h->d_tcn_prof) {
+        FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_tcn_prof), 64));
+        FSNP_HIP_CHECK(hipMemset(h->d_tcn_prof, 0, 64));
+    }
+    if (out) {
+        unsigned long long c[8] = {};
+        if (!h->d_tcn_prof) { set_error("fsnp_debug_tcn_profile: not enabled on this handle"); return 2; }
+        FSNP_HIP_CHECK(hipMemcpy(c, h->d_tcn_prof, sizeof(c), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) out[i] = c[i] && c[0] ? (double)(long long)(c[i] - c[0]) : 0.0;
+    }
+    if (!enable && h->d_tcn_prof) { (void)hipFree(h->d_tcn_prof); h->d_tcn_prof = nullptr; }
     return 0;
 }
 

@@ -115,6 +115,7 @@ struct fsnp_handle {
     int verify_every = 0;
     long long verify_calls = 0, verify_runs = 0;
     float* verify_out = nullptr;             // scratch mask of the verification pass (stream-ordered allocation)
+    unsigned long long* d_tcn_prof = nullptr; // device: 8 s_memtime stamps of the fused TCN kernel's workgroup 0 (fsnp_debug_tcn_profile)
     unsigned long long* d_clk = nullptr;     // device: clock stamps of the last one-tile-per-CU LSTM launch (LstmArgs::clk, fsnp_debug_launch_clock)
     unsigned long long* verify_key_sampled = nullptr;   // the same key of the sampled check (inside vs_buf)
     unsigned long long* verify_key = nullptr; // device: smallest (utterance << 44 | bin << 24 | frame) at which a verification pass disagreed

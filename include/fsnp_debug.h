@@ -193,6 +193,11 @@ int fsnp_debug_box_probe(double target_ms, double out[FSNP_BOX_PROBE_VALUES], vo
  * first; returns 2 if no such launch has completed. */
 #define FSNP_LAUNCH_CLOCK_VALUES 7
 int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]);
+/* Profiling hook (round 6): phase stamps of the fused TCN kernel (csrc/tcn_fused.hip).  enable != 0: the following forwards run its
+ * stamping instantiation; out (may be NULL) receives, in shader cycles since the start of the stamped block (workgroup 0; the second block
+ * of the launch): [1] phase 1 done, [2] hand-off 1 passed, [3] phase 2 stored, [4] hand-off 2 passed, [5] phase 3 MFMAs done, [6] x stored,
+ * [7] hand-off 3 passed.  enable == 0 reads the last stamps and switches the profile off.  Synchronise first. */
+int fsnp_debug_tcn_profile(fsnp_handle* h, int32_t enable, double out[8]);
 
 #ifdef __cplusplus
 }
