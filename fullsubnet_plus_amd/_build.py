@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libfsnp_hip.so")
-SOURCES = ["fsnp_abi.hip", "fsnp_weights.hip", "fsnp_stft_abi.hip", "planner.cpp", "frontend.hip", "tcn.hip", "tcn_fused.hip", "subband.hip", "lstm.hip", "lstm16.hip", "lstm_gru.hip", "lstm_coop.hip",
+SOURCES = ["fsnp_abi.hip", "fsnp_weights.hip", "fsnp_stft_abi.hip", "planner.cpp", "frontend.hip", "tcn.hip", "subband.hip", "lstm.hip", "lstm16.hip", "lstm_gru.hip", "lstm_coop.hip",
            "lstm_hp.hip", "lstm_hpw.hip", "lstm_generic.hip", "lstm_coopn.hip", "lstm_coopw.hip", "lstm_fbv.hip", "stft.hip", "box_probe.hip", "stages.hip"]
 HEADERS = [os.path.join(CSRC, "fsnp_common.h"), os.path.join(CSRC, "lstm_common.h"), os.path.join(CSRC, "planner.h"), os.path.join(CSRC, "fsnp_handle.h"), os.path.join(CSRC, "weight_watch.h"),
            os.path.join(os.path.dirname(HERE), "include", "fsnp.h"), os.path.join(os.path.dirname(HERE), "include", "fsnp_debug.h")]

@@ -91,7 +91,6 @@ SYMBOLS = {
     "fsnp_debug_lstm_fbv_pack": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64]),
     "fsnp_debug_box_probe": (c_i32, [ctypes.c_double, ctypes.POINTER(ctypes.c_double * BOX_PROBE_VALUES), c_vp]),
     "fsnp_debug_launch_clock": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double * 7)]),
-    "fsnp_debug_tcn_profile": (c_i32, [c_vp, c_i32, ctypes.POINTER(ctypes.c_double * 8)]),
     "fsnp_last_error": (ctypes.c_char_p, []),
     "fsnp_version": (ctypes.c_char_p, []),
 }

@@ -212,32 +212,14 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueArgs a) {
 static std::mutex g_coop_mu;
 static hipEvent_t g_coop_ev[64] = {};
 static bool g_coop_used[64] = {};
-static const void* g_coop_owner[64] = {};
-// (round 6) the fused TCN-block launches (tcn_fused.hip) wait on plane-wide hand-offs too, but need only one plane's ~36 workgroups
-// co-resident.  Inside ONE handle they may overlap its own deferred column-split launch (the planner defers only launches that leave
-// 32 CUs free: plan_first_deferred); against column-split launches of OTHER handles / streams they are ordered both ways through a
-// second event, so that a launch that needs (almost) every CU never waits for CUs a spinning TCN plane holds, or the other way round.
-static hipEvent_t g_tcn_ev[64] = {};
-static bool g_tcn_used[64] = {};
 template <typename F>
-static void launch_coop_chained(int dev, hipStream_t s, F launch, const void* owner = nullptr) {
+static void launch_coop_chained(int dev, hipStream_t s, F launch) {
     if (dev < 0 || dev >= 64) { launch(); return; }
     std::lock_guard<std::mutex> lk(g_coop_mu);
     if (g_coop_used[dev]) (void)hipStreamWaitEvent(s, g_coop_ev[dev], 0);
-    if (g_tcn_used[dev]) (void)hipStreamWaitEvent(s, g_tcn_ev[dev], 0);
     launch();
-    g_coop_owner[dev] = owner;
     if (!g_coop_ev[dev] && hipEventCreateWithFlags(&g_coop_ev[dev], hipEventDisableTiming) != hipSuccess) { g_coop_ev[dev] = nullptr; return; }
     g_coop_used[dev] = hipEventRecord(g_coop_ev[dev], s) == hipSuccess;
-}
-template <typename F>
-static void launch_tcn_chained(int dev, hipStream_t s, const void* owner, F launch) {
-    if (dev < 0 || dev >= 64) { launch(); return; }
-    std::lock_guard<std::mutex> lk(g_coop_mu);
-    if (g_coop_used[dev] && g_coop_owner[dev] != owner) (void)hipStreamWaitEvent(s, g_coop_ev[dev], 0);
-    launch();
-    if (!g_tcn_ev[dev] && hipEventCreateWithFlags(&g_tcn_ev[dev], hipEventDisableTiming) != hipSuccess) { g_tcn_ev[dev] = nullptr; return; }
-    g_tcn_used[dev] = hipEventRecord(g_tcn_ev[dev], s) == hipSuccess;
 }
 
 // The planner itself (cost table, launch shapes, shortest path over tile counts) is host-only code: planner.h / planner.cpp.
@@ -304,7 +286,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             else if (c.kind == 9) launch_lstm_coopw(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
-        }, h);
+        });
     }
     if (after_first && last_chunk == nchunks) (void)hipEventRecord(after_first, s);
 }
@@ -343,23 +325,6 @@ static int plan_first_deferred(const fsnp_handle* h, const SbPlan& plan) {
     int busiest = 0;
     for (int i = first; i < n; ++i) busiest = std::max(busiest, chunk_workgroups(h, plan.chunks[i]));
     return (first < n && busiest <= h->num_cus_real - 32) ? first : n;
-}
-
-// The TCNBlock stack in one launch (tcn_fused.hip) instead of 24: planned while the launch is latency-bound - at most `tcn_fused_max_wgs`
-// workgroups (measured: profiles/r06_fullband.md) - and one plane's workgroups, ONE per CU, fit beside whatever this handle may have in
-// flight: a deferred column-split launch of the pipelined loop owns its CUs (plan_first_deferred: it leaves >= 32), the sampled
-// verification two.  Off with the column-split kernels (FSNP_LSTM_COOP=0, the retry after a time-out: no inter-workgroup waits at all
-// then), with FSNP_TCN_FUSED=0 and with fsnp_debug_set_gemm_dma != 1.
-static bool tcn_fused_planned(const fsnp_handle* h, const Dims& d, const SbPlan& plan) {
-    if (!h->lstm_coop || !h->tcn_fused || h->tw.gemm_dma != 1 || !tcn_fused_available(d, h->tw)) return false;
-    const int per_plane = tcn_fused_workgroups_per_plane(d);
-    int free_cus = h->num_cus_real - 8;
-    if (h->pipeline) {
-        const int first = plan_first_deferred(h, plan);
-        for (int i = first; i < (int)plan.chunks.size(); ++i) free_cus = std::min(free_cus, h->num_cus_real - chunk_workgroups(h, plan.chunks[i]) - 2);
-    }
-    if (per_plane > free_cus) return false;
-    return (long)per_plane * 3 * d.B <= h->tcn_fused_max_wgs;
 }
 
 static int rows_per_utt(const fsnp_handle* h, int mode) {
@@ -975,8 +940,6 @@ int fsnp_create(const fsnp_config* cfg, fsnp_handle** out) {
     build_specs(h);
     const char* cp = getenv("FSNP_LSTM_COOP");
     if (cp && cp[0] == '0') h->lstm_coop = 0;
-    if (const char* tf = getenv("FSNP_TCN_FUSED")) { if (tf[0] == '0') h->tcn_fused = 0; else if (atoi(tf) > 1) h->tcn_fused_max_wgs = atoi(tf); }
-    h->tcn_fused_cfg = h->tcn_fused;
     {
         // (The round-3 ping-pong K-split kernel lstm_pp.hip - opt-in, ahead of the other kernels at exactly 10 row tiles - was removed in
         // round 4; its measurements stay in profiles/r03_column_split.md and profiles/r03_pp_*.txt.)
@@ -1030,7 +993,6 @@ void fsnp_destroy(fsnp_handle* h) {
     if (h->verify_out) (void)hipFree(h->verify_out);
     if (h->verify_key) (void)hipFree(h->verify_key);
     if (h->d_clk) (void)hipFree(h->d_clk);
-    if (h->d_tcn_prof) (void)hipFree(h->d_tcn_prof);
     if (h->vs_buf) (void)hipFree(h->vs_buf);
     if (h->vs_stream) (void)hipStreamDestroy(h->vs_stream);
     if (h->ev_vs_snap) (void)hipEventDestroy(h->ev_vs_snap);
@@ -1155,12 +1117,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         tbuf.dbg_tcn0 = h->debug ? fptr(w.dbg_tcn0) : nullptr;
         // the caller's tensors are read by the repack kernel only; everything up to the LSTM then stays in the workspace
         launch_frontend(d, h->cfg.norm_type, in, strides, is_complex, h->fw, fbuf, s);
-        tbuf.fused = tcn_fused_planned(h, d, plan) ? 1 : 0;
-        tbuf.fused_abort = reinterpret_cast<unsigned*>(base + w.coop_abort) + 32;
-        tbuf.fused_err = h->d_err;
-        tbuf.fused_prof = h->d_tcn_prof;
-        if (tbuf.fused) launch_tcn_chained(h->device, s, h, [&] { launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s); });
-        else launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
+        launch_tcn(d, h->cfg.fb_act, h->tw, tbuf, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
     } else {
         // fullsubnet.py:82-90: pad, norm(noisy_mag), 2-layer LSTM(F -> CH), Linear(CH, F) + fb_act
@@ -1184,8 +1141,8 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         const int chp = (int)align_up(d.CH, 4);           // row stride of the h1 sequence (a float4 multiple; pad columns written as zeros)
         fa.seq_stride = chp;
         if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
-        else if (h->fb_valu && lstm_fbv_available(h->fbw, batch, h->num_cus_real)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); }, h);   // B <= 4: VALU
-        else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); }, h);
+        else if (h->fb_valu && lstm_fbv_available(h->fbw, batch, h->num_cus_real)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); });   // B <= 4: VALU
+        else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
         launch_linear_act(fptr(w.y1), chp, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
@@ -1571,23 +1528,6 @@ int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]
     return 0;
 }
 
-int fsnp_debug_tcn_profile(fsnp_handle* h, int32_t enable, double out[8]) {
-    if (!h) { set_error("fsnp_debug_tcn_profile: null handle"); return 1; }
-    FSNP_ON_DEVICE(h);
-    if (enable && !h->d_tcn_prof) {
-        FSNP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_tcn_prof), 64));
-        FSNP_HIP_CHECK(hipMemset(h->d_tcn_prof, 0, 64));
-    }
-    if (out) {
-        unsigned long long c[8] = {};
-        if (!h->d_tcn_prof) { set_error("fsnp_debug_tcn_profile: not enabled on this handle"); return 2; }
-        FSNP_HIP_CHECK(hipMemcpy(c, h->d_tcn_prof, sizeof(c), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 8; ++i) out[i] = c[i] && c[0] ? (double)(long long)(c[i] - c[0]) : 0.0;
-    }
-    if (!enable && h->d_tcn_prof) { (void)hipFree(h->d_tcn_prof); h->d_tcn_prof = nullptr; }
-    return 0;
-}
-
 int fsnp_set_precision(fsnp_handle* h, int32_t ih_bf16) {
     if (!h || ih_bf16 < 0 || ih_bf16 > 1) { set_error("fsnp_set_precision: 0 (fp32) or 1 (bf16 ih-GEMM, BASELINE.json configs[4])"); return 1; }
     if (ih_bf16 && (h->gru || h->sb_tcn)) { set_error("fsnp_set_precision: the bf16 ih-GEMM variant exists for the LSTM sub-band model only"); return 2; }
@@ -1703,7 +1643,6 @@ int64_t fsnp_dump_config(const fsnp_handle* h, char* buf, int64_t cap) {
     add("  FSNP_COOP_OCC=%s -> column-split workgroups per CU the planner may use: %d\n", env("FSNP_COOP_OCC"), h->coop_occ);
     add("  FSNP_LSTM16=%s -> half-tile kernel %s\n", env("FSNP_LSTM16"), h->lstm16_ok ? "planned" : "not used");
     add("  FSNP_CALIBRATE=%s -> cost table %s\n", env("FSNP_CALIBRATE"), h->cost.calibrated ? "measured / pinned" : h->calibrate ? "to be measured at the first plan" : "built-in");
-    add("  FSNP_TCN_FUSED=%s -> one launch per TCNBlock (tcn_fused.hip) %s, up to %d workgroups per launch\n", env("FSNP_TCN_FUSED"), h->tcn_fused && h->lstm_coop ? "planned" : "never", h->tcn_fused_max_wgs);
     add("  FSNP_GEMM_DMA=%s -> %d (0 = the general GEMM kernel everywhere)\n", env("FSNP_GEMM_DMA"), h->tw.gemm_dma);
     add("  FSNP_VERIFY_EVERY=%s -> exchange verification every %d forwards (0 = off)\n", env("FSNP_VERIFY_EVERY"), h->verify_every);
     add("  FSNP_DEBUG_STAGES=%s -> %d\n", env("FSNP_DEBUG_STAGES"), (int)h->debug);
@@ -1732,9 +1671,8 @@ int fsnp_debug_set_chaos(fsnp_handle* h, int32_t seed) {
 }
 
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode) {
-    if (!h || mode < 0 || mode > 4) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply; small batches: one fused launch per TCNBlock), 2 (as 1, neither the fused block kernel nor the small-batch split-K kernel), 3 (the 128-row DMA kernel only) or 4 (as 1 without the fused block kernel)"); return 1; }
-    h->tw.gemm_dma = mode == 4 ? 1 : mode;
-    h->tcn_fused = mode == 4 ? 0 : h->tcn_fused_cfg;
+    if (!h || mode < 0 || mode > 3) { set_error("fsnp_debug_set_gemm_dma: mode must be 0 (general GEMM kernel), 1 (DMA kernels where they apply), 2 (as 1, never the small-batch split-K kernel) or 3 (the 128-row DMA kernel only)"); return 1; }
+    h->tw.gemm_dma = mode;
     return 0;
 }
 

@@ -131,20 +131,9 @@ struct TcnBuffers {
     double* gn;        // [NB][2][3][B][kGnStride] GroupNorm (sum, sumsq) accumulators (one 128-byte line per pair), zeroed per forward
     float* fb;         // [3][B][Tp][FP]  output
     float* dbg_tcn0;   // optional [B][Tp][FP]: mag branch after block 0
-    // tcn_fused.hip (one launch per TCNBlock, small batches): 0 = the three-launch path; the launch-abort word (zeroed per forward) and
-    // the handle's host-mapped error word of the bounded waits (lstm_common.h)
-    int fused = 0;
-    unsigned* fused_abort = nullptr;
-    unsigned* fused_err = nullptr;
-    unsigned long long* fused_prof = nullptr;   // optional: 8 s_memtime stamps of workgroup 0 (fsnp_debug_tcn_profile)
 };
 
 void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers& buf, hipStream_t s, int branches = 3);
-// tcn_fused.hip: the TCNBlocks (causal_conv.py:96-108) of the three full-band stacks in one launch
-bool tcn_fused_available(const Dims& d, const TcnWeights& w);
-int tcn_fused_chunks(const Dims& d);
-int tcn_fused_workgroups_per_plane(const Dims& d);      // the workgroups that must be co-resident (hand-offs are per (branch, utterance) plane)
-void launch_tcn_fused(const Dims& d, const TcnWeights& w, const TcnBuffers& buf, int b0, int b1, bool relu_last, hipStream_t s);   // blocks [b0, b1)
 // C[utt][t][0..N) = act(A[utt][t][0..K) * W^T + bias), W [N pad 384][ldw] zero padded.  a_utt_stride / a_cols: optional
 // utterance stride of A and readable floats per row when rows overlap (lda < K: the STFT's hop-strided frames).
 void launch_linear_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int K,

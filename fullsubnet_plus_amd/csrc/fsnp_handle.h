@@ -95,9 +95,6 @@ struct fsnp_handle {
     bool hp_ok = false;          // the half-tile ping-pong kernel (lstm_hp.hip) exists for this handle's sub-band model
     int hp_wave = 1;             // kind-8 launches run on the wave-owned variant (lstm_hpw.hip); FSNP_HP_WAVE=0: lstm_hp.hip
     int coop_hp = 0, coop_hp_cfg = 0;   // ... and the planner may use it (FSNP_COOP_HP=0: never; fsnp_debug_set_lstm_coop(h, 4): even then)
-    int tcn_fused = 1;           // small batches: one launch per TCNBlock (tcn_fused.hip); FSNP_TCN_FUSED=0
-    int tcn_fused_cfg = 1;       // ... as configured at fsnp_create (fsnp_debug_set_gemm_dma(4) switches tcn_fused off, other modes restore this)
-    int tcn_fused_max_wgs = 512; // ... while the launch has at most this many workgroups (FSNP_TCN_FUSED=<n> overrides)
     int fb_valu = 1;             // FullSubNet: the full-band LSTM of <= 4 utterances runs on the VALU kernel (lstm_fbv.hip); fsnp_debug_set_gemm_dma-like
                                  // test switch: fsnp_debug_set_lstm_coop(h, 2) turns it off together with the other round-3+ schedules
     bool coopw_ok = false;       // the wave-owned column split (lstm_coopw.hip) exists for this handle's sub-band model (LSTM, H = 384) ...
@@ -115,7 +112,6 @@ struct fsnp_handle {
     int verify_every = 0;
     long long verify_calls = 0, verify_runs = 0;
     float* verify_out = nullptr;             // scratch mask of the verification pass (stream-ordered allocation)
-    unsigned long long* d_tcn_prof = nullptr; // device: 8 s_memtime stamps of the fused TCN kernel's workgroup 0 (fsnp_debug_tcn_profile)
     unsigned long long* d_clk = nullptr;     // device: clock stamps of the last one-tile-per-CU LSTM launch (LstmArgs::clk, fsnp_debug_launch_clock)
     unsigned long long* verify_key_sampled = nullptr;   // the same key of the sampled check (inside vs_buf)
     unsigned long long* verify_key = nullptr; // device: smallest (utterance << 44 | bin << 24 | frame) at which a verification pass disagreed

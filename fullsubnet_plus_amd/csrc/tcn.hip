@@ -997,19 +997,7 @@ void launch_tcn(const Dims& d, int fb_act, const TcnWeights& w, const TcnBuffers
     const bool dma = branches == 3 && w.gemm_dma;
     const bool relu_fused = dma && w.NB > 0 && !(w.NB == 1 && buf.dbg_tcn0);     // the last sconv stores max(x, 0) for the final Linear
 
-    // small batches: the whole stack in one launch (tcn_fused.hip); same folded GroupNorm-2 weights, so the same `relu_out` convention
-    const bool fused = dma && buf.fused && buf.fused_abort && buf.fused_err && tcn_fused_available(d, w);
-    if (fused) {
-        if (buf.dbg_tcn0) {         // (the debug stage read-back wants the mag branch after block 0)
-            launch_tcn_fused(d, w, buf, 0, 1, relu_fused, s);
-            (void)hipMemcpyAsync(buf.dbg_tcn0, buf.x, (size_t)x_bs * sizeof(float), hipMemcpyDeviceToDevice, s);
-            if (w.NB > 1) launch_tcn_fused(d, w, buf, 1, w.NB, relu_fused, s);
-        } else {
-            launch_tcn_fused(d, w, buf, 0, w.NB, relu_fused, s);
-        }
-    }
-
-    for (int blk = fused ? w.NB : 0; blk < w.NB; ++blk) {
+    for (int blk = 0; blk < w.NB; ++blk) {
         const float* xin = blk == 0 ? buf.att : buf.x;
         {   // conv1x1 + PReLU1 (+ GN1 stats): y1[M][CH] = x[M][F] * W1^T
             GemmArgs g{};

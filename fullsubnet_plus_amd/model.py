@@ -693,18 +693,6 @@ class _HipModel(nn.Module):
         return {"wall_ms": out[2], "s_memtime_ticks": out[0], "s_memtime_mhz": out[3], "slowest_workgroup_ms": out[4],
                 "fastest_workgroup_ms": out[5], "most_cycles_of_a_workgroup": out[6]}
 
-    def tcn_profile(self, enable=True, device="cuda"):
-        """Phase stamps of the fused TCN kernel's workgroup 0 (fsnp_debug_tcn_profile; shader cycles since the start of the stamped block).
-        tcn_profile(True) switches the stamping instantiation on; a later call returns the stamps of the last forward (synchronise first)."""
-        lib = self._ensure_handle(_resolve_device(device))
-        out = (ctypes.c_double * 8)()
-        with torch.cuda.device(self._hip.device):
-            rc = lib.fsnp_debug_tcn_profile(self._handle, 1 if enable else 0, ctypes.byref(out))
-        if rc != 0:
-            return None
-        names = ("start", "phase1", "handoff1", "phase2", "handoff2", "phase3_mfma", "x_stored", "handoff3")
-        return dict(zip(names, list(out)))
-
     def describe_plan(self, batch, parity=False):
         """-> [{"kernel", "sequences", "tiles", "valu_rows", "precision", "workgroups", "deferred_when_pipelined"}, ...]: how the
         sub-band sequences of a `batch`-utterance forward are cut into kernel launches, the arithmetic each launch runs in under the

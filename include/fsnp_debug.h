@@ -116,9 +116,7 @@ int fsnp_debug_set_lstm_coop(fsnp_handle* h, int32_t mode);   /* 2 = as 1, but t
  * they are not bit-identical (GroupNorm is applied after the k-sum instead of before it).  Small batches (at most 6 workgroups per CU
  * on 32-row tiles: B <= 16 at 2 s clips) run the same GEMMs on tcn_gemm_sk_kernel - 32 x 64 tiles whose four waves split K, no
  * workgroup barrier in the k-loop - and the sconv GEMMs of larger problems on the 64-row kernel; mode 2 = as 1 but never the
- * split-K kernel; mode 3 = the 128-row DMA kernel only (the environment switches that used to select these were removed in ABI 9).
- * Round 6: in mode 1 the small batches run ONE launch per TCNBlock (csrc/tcn_fused.hip: both GEMMs, the depthwise conv and the two
- * GroupNorm hand-offs); mode 4 = as 1 without that kernel (the three-launch path at every batch size, as rounds 3 - 5). */
+ * split-K kernel; mode 3 = the 128-row DMA kernel only (the environment switches that used to select these were removed in ABI 9). */
 int fsnp_debug_set_gemm_dma(fsnp_handle* h, int32_t mode);
 /* Test hook: sets the device error word as a timed-out inter-workgroup wait would (the next fsnp_forward /
  * fsnp_check_errors on the handle must then fail, once). */
@@ -193,11 +191,6 @@ int fsnp_debug_box_probe(double target_ms, double out[FSNP_BOX_PROBE_VALUES], vo
  * first; returns 2 if no such launch has completed. */
 #define FSNP_LAUNCH_CLOCK_VALUES 7
 int fsnp_debug_launch_clock(fsnp_handle* h, double out[FSNP_LAUNCH_CLOCK_VALUES]);
-/* Profiling hook (round 6): phase stamps of the fused TCN kernel (csrc/tcn_fused.hip).  enable != 0: the following forwards run its
- * stamping instantiation; out (may be NULL) receives, in shader cycles since the start of the stamped block (workgroup 0; the second block
- * of the launch): [1] phase 1 done, [2] hand-off 1 passed, [3] phase 2 stored, [4] hand-off 2 passed, [5] phase 3 MFMAs done, [6] x stored,
- * [7] hand-off 3 passed.  enable == 0 reads the last stamps and switches the profile off.  Synchronise first. */
-int fsnp_debug_tcn_profile(fsnp_handle* h, int32_t enable, double out[8]);
 
 #ifdef __cplusplus
 }
