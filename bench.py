@@ -121,6 +121,16 @@ def cpu_baseline(sd, inputs, budget_s, norm, fullsubnet=False):
                       f"torch {torch.__version__} CPU, {best_threads} of {ncpu} host threads), {dt:.1f} s"}, outs
 
 
+def dominant_kernel_source_digest():
+    """sha256 of the sources the one-tile-per-CU LSTM kernel is compiled from (profiles/lstm_pmc.json records the same digest)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("lstm.hip", "lstm_common.h", "fsnp_common.h"):
+        with open(os.path.join(ROOT, "fullsubnet_plus_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pci_address(dev):
     """"0000:05:00.0" of a torch device (None when this torch build does not expose it): selects the GPU's sysfs directory."""
     try:
@@ -392,11 +402,21 @@ def main():
     lstm_kernel_name = plan[0]["kernel"]
     probes = [p for p in (probe_before, probe_after) if p]
     box_peak = min(p["mfma_tflops"] for p in probes) if probes else None
-    traffic = None   # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes
+    # HBM-side bytes per launch of the dominant kernel, from committed rocprofv3 PMC passes - reported only while the kernel's sources are
+    # the ones those passes ran (the file carries their digest): a kernel edit without new counter passes turns the field to null
+    traffic, traffic_note = None, None
     pmc_path = os.path.join(ROOT, "profiles", "lstm_pmc.json")
     if os.path.exists(pmc_path) and B == 32 and abs(args.seconds - 2.0) < 1e-9 and args.mode == "full":
         with open(pmc_path) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
+            pmc = json.load(f)
+        want = pmc.get("kernel_source_sha256")
+        have = dominant_kernel_source_digest()
+        if want is None or want == have:
+            traffic = pmc.get("traffic_bytes_per_launch")
+            traffic_note = ("profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of every round by tools/gpu_r06_final.sh and "
+                            "committed; NOT re-measured by this run; kernel sources " + ("match the passes': " + have[:12] if want else "not recorded in the file") + ")")
+        else:
+            traffic_note = f"profiles/lstm_pmc.json was measured on other kernel sources ({want[:12]}, now {have[:12]}): not reported"
 
     result = {
         "metric": "STFT frames/sec (257-bin, 2 s clips), " + ("FullSubNet" if fsn else "FullSubNet+") +
@@ -426,8 +446,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": lstm_kernel_name, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": "profiles/lstm_pmc.json (rocprofv3 --pmc passes of this kernel, refreshed at the end of every round by "
-                                       "tools/gpu_r06_final.sh and committed; NOT re-measured by this run)" if traffic is not None else None,
+                     "traffic_source": traffic_note,
                      # the same rate against what THIS box's matrix pipes held in a pure-MFMA probe right before / after the loops
                      # (box.mfma_peak_tflops: the lower of the two) - a slow box shows as frac < frac_of_box_peak, a slow kernel in both
                      "frac_of_box_peak": (achieved / box_peak) if box_peak else None,
