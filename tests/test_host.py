@@ -1218,3 +1218,25 @@ def test_synthetic_generators_are_frozen():
     assert abs(f64(make_state_dict(4, "harsh", as_torch=False)["sb_model.sequence_model.weight_ih_l1"]) - 19.92727242918871) < 1e-5
     assert abs(f64(make_state_dict_fullsubnet(3, "harsh", as_torch=False)["fb_model.sequence_model.weight_hh_l1"]) + 15.92294563049542) < 1e-5
     assert abs(f64(make_wave(2, 0.5, 7)) + 3.7271236432115984) < 1e-6
+
+
+def test_every_environment_switch_is_documented_and_reported():
+    """The FSNP_* variables the library reads (getenv in csrc/) are exactly the rows of INTEGRATION.md's table, and fsnp_dump_config names each
+    one with the value in force - a switch cannot be added, or removed with what it selected, without its documentation."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fullsubnet_plus_amd", "csrc")
+    read = set()
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(csrc, name)) as f:
+                read |= set(re.findall(r'getenv\("(FSNP_[A-Z0-9_]+)"\)', f.read()))
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        text = f.read()
+    table = set(re.findall(r"^\| `(FSNP_[A-Z0-9_]+)=", text, flags=re.M))
+    assert read == table, (sorted(read - table), sorted(table - read))
+    assert {3: "Three", 10: "Ten", 11: "Eleven", 12: "Twelve"}.get(len(read), str(len(read))) + " switches" in text
+    with open(os.path.join(csrc, "fsnp_abi.hip")) as f:
+        abi = f.read()
+    dump = abi[abi.index("int64_t fsnp_dump_config("):]
+    for var in read:
+        assert f'{var}=%s' in dump, var
