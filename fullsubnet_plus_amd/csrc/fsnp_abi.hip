@@ -1419,8 +1419,10 @@ int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_
     int n = 0;
     for (const SbChunk& c : plan.chunks) {
         if (n >= max_chunks) break;
-        // kind 4 = half-tile kernel, 11 = runtime-sized kernel, 12 = half-tile ping-pong (lstm_hp.hip), 13 = wave-owned column split (lstm_coopw.hip)
-        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 7 ? 11 : c.kind == 8 ? 12 : c.kind == 9 ? 13 : c.kind);
+        // kind 4 = half-tile kernel, 11 = runtime-sized kernel, 12 = half-tile ping-pong (lstm_hp.hip), 13 = wave-owned column split (lstm_coopw.hip),
+        // 14 = half-tile ping-pong on its wave-owned kernel (lstm_hpw.hip: where launch_sb_lstm runs planner kind 8 by default)
+        const bool hpw = h->lw.hp_wave && lstm_hpw_available(h->lw);
+        out[4 * n + 0] = h->sb_tcn ? 3 : (c.kind == 7 ? 11 : c.kind == 8 ? (hpw ? 14 : 12) : c.kind == 9 ? 13 : c.kind);
         out[4 * n + 1] = c.nrows; out[4 * n + 2] = c.num_tiles; out[4 * n + 3] = c.ex;
         ++n;
     }

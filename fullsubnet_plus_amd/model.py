@@ -707,7 +707,8 @@ class _HipModel(nn.Module):
                  4: "lstm2_fc16_kernel (one 16-row tile per CU)",
                  11: "lstm2_generic_kernel (runtime-sized fp32 FMA kernel: no tuned instantiation for these sizes)",
                  12: "lstm2_coop_hp_kernel (16 units per workgroup, gate-split waves, two half tiles per row tile in turn)",
-                 13: "lstm2_coopw_kernel (a wave owns 8 / 16 units over the whole K, layer-skewed, no workgroup barrier)"}
+                 13: "lstm2_coopw_kernel (a wave owns 8 / 16 units over the whole K, layer-skewed, no workgroup barrier)",
+                 14: "lstm2_coop_hpw_kernel (16 units per workgroup, a wave owns 4 of them over the whole K, two half tiles per row tile in turn, no workgroup barrier)"}
         prec = {0: "f32", 1: "f32 + bf16 layer-1 ih-GEMM"}
         return [{"kernel": names[buf[7 * i]], "sequences": buf[7 * i + 1], "tiles": buf[7 * i + 2], "valu_rows": buf[7 * i + 3],
                  "precision": prec[buf[7 * i + 4]], "workgroups": buf[7 * i + 5], "deferred_when_pipelined": bool(buf[7 * i + 6])} for i in range(n)]

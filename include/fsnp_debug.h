@@ -34,7 +34,9 @@ int fsnp_get_timing(fsnp_handle* h, double ms[4], int64_t count[4], int32_t rese
  *  half-tile: 16-row tiles, csrc/lstm16.hip, 11 = lstm2_generic runtime-sized kernel, csrc/lstm_generic.hip; 12 = lstm2_coop_hp: 16 units per
  *  workgroup, gate-split waves, resident weights, every row tile as two half tiles in turn, csrc/lstm_hp.hip - planned for 6-10 row
  *  tiles, FSNP_COOP_HP=0 = never; 13 = lstm2_coopw: a wave owns 8 / 16 hidden units over the whole K, 12 / 6 workgroups per row
- *  tile, no workgroup barrier in the time loop, csrc/lstm_coopw.hip - planned from 11 row tiles up, FSNP_COOP_W=0 = never),
+ *  tile, no workgroup barrier in the time loop, csrc/lstm_coopw.hip - planned from 11 row tiles up, FSNP_COOP_W=0 = never; 14 = the launch
+ *  shape of 12 on its wave-owned kernel, csrc/lstm_hpw.hip: a wave owns 4 of the workgroup's 16 units over the whole K, no workgroup
+ *  barrier - what runs where that kernel is instantiated, FSNP_HP_WAVE=0 = kind 12 instead),
  *  sequences, 32-row tiles, VALU rows per tile}, in launch order.  Returns the number of chunks (< 0 on error). */
 int fsnp_describe_plan(const fsnp_handle* h, int32_t batch, int32_t mode, int32_t* out, int32_t max_chunks);
 /* The same with 7 ints per record: {kernel, sequences, tiles, VALU rows, precision, workgroups, deferred}; deferred = 1: in the

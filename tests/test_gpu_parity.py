@@ -184,7 +184,7 @@ def test_half_tile_ping_pong_kernel_vs_oracle(n, steps, hidden, fbn):
     m.lstm2_fc(x[:1])
     m.debug_set_lstm_coop(4)
     m.debug_set_costs(_hp_only_costs(), 1)
-    assert all(c["kernel"].startswith("lstm2_coop_hp_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
+    assert all(c["kernel"].startswith(("lstm2_coop_hp_kernel", "lstm2_coop_hpw_kernel")) for c in m.describe_plan(1)), m.describe_plan(1)
     got = m.lstm2_fc(x).cpu().numpy()
     m.check_errors()
     want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()
@@ -1349,7 +1349,7 @@ def test_sampled_exchange_verification_catches_a_corruption_in_an_unsampled_tile
     assert 1 <= m.verify_sample_stats()["samples"] - s0 <= 2
 
 
-@pytest.mark.parametrize("batch,kernel,round4", [(1, "lstm2_coop_hp_kernel", False), (2, "lstm2_coopw_kernel", False), (8, "lstm2_coopw_kernel", False),
+@pytest.mark.parametrize("batch,kernel,round4", [(1, "lstm2_coop_hpw_kernel", False), (2, "lstm2_coopw_kernel", False), (8, "lstm2_coopw_kernel", False),
                                                  (3, "lstm2_coop_kernel", True), (8, "lstm2_coopn_kernel", True)])
 def test_exchange_verification_detects_a_corrupted_exchange(batch, kernel, round4):
     """the column-split kernels' hand-off can only detect a TIME-OUT; a stale or corrupted exchange image would give a

@@ -33,7 +33,7 @@ if os.environ.get("NOCOOPW"):                   # the round-4 plans: no wave-own
 if os.environ.get("HP"):                        # only the half-tile ping-pong kernel (csrc/lstm_hp.hip)
     m.debug_set_lstm_coop(4)
     m.debug_set_costs([900.0] * 12 + [900.0, 0.11] + [900.0] * 4 + [900.0] + [5.0, 5.0], 1)
-    assert all(c["kernel"].startswith("lstm2_coop_hp_kernel") for c in m.describe_plan(1)), m.describe_plan(1)
+    assert all(c["kernel"].startswith(("lstm2_coop_hp_kernel", "lstm2_coop_hpw_kernel")) for c in m.describe_plan(1)), m.describe_plan(1)
 torch.cuda.synchronize()
 best = 1e9
 for _ in range(reps):
