@@ -39,6 +39,7 @@ cyc = [r[12] for r in rows if r[12]]
 mhz = [r[13] for r in rows if r[13]]
 lms = [r[6] for r in rows]
 if cyc and mhz:
+    slow = max((r for r in rows if r[13]), key=lambda r: r[6])
     print(f"""
 ## What the rows say
 
@@ -47,17 +48,22 @@ if cyc and mhz:
   and the slowest XCD's tail (0.13 - 0.41 ms; box D: 26.62 ms of events around a 26.21 ms workgroup 0).
 * `frac` (against the 157.3 TFLOP/s data-sheet figure at 2.4 GHz) moves with the box: {min(r[7] for r in rows):.4f} - {max(r[7] for r in rows):.4f}.
   `frac_at_held_clock` does not: {min(r[9] for r in rows if r[9]):.4f} - {max(r[9] for r in rows if r[9]):.4f} - the kernel issues an MFMA on 94.0 - 94.1 % of the cycles it is given, everywhere.
-* The probe (pure MFMA, no memory traffic) sustains 152.2 - 152.9 TFLOP/s before the timed loops (2345 - 2355 MHz: the chip has just left
-  idle) and 154.4 - 155.1 after (2380 MHz): no box reaches the 2.4 GHz of the data sheet under an all-SIMD fp32-MFMA load at ~1200 W of a
-  1400 W cap; 0.968 - 0.986 of the spec peak is what the hardware gives.  The LSTM kernel holds 10 - 25 MHz LESS than the probe (it also
+* The slowest box of the set explains itself: row `{slow[0]}` holds {slow[13]:.0f} MHz under the kernel (sysfs sclk median {slow[18]:.0f}) while
+  drawing {slow[19]:.0f} W median of the {slow[20]:.0f} W cap - the most of any row (the others: 1180 - 1235 W at 2357 - 2370 MHz) - and needs
+  {slow[6]:.2f} ms per launch, `frac` {slow[7]:.4f}: the same {slow[12] / 1e6:.2f} M cycles, `frac_at_held_clock` {slow[9]:.4f}.  A chip that needs more power for
+  the same work is given less clock by the same power management; nothing about the kernel differs.
+* The probe (pure MFMA, no memory traffic) sustains 152.2 - 152.9 TFLOP/s before the timed loops (2338 - 2355 MHz: the chip has just left
+  idle) and 154.4 - 155.4 after (2380 - 2387 MHz): no box reaches the 2.4 GHz of the data sheet under an all-SIMD fp32-MFMA load at ~1200 W of a
+  1400 W cap; 0.968 - 0.986 of the spec peak is what the hardware gives.  The LSTM kernel holds 10 - 50 MHz LESS than the probe after it (it also
   drives LDS and L2).
 * **Round 5's driver run (27.63 ms per launch, frac 0.879):** the same 62.0 M cycles in 27.63 ms - minus the ~0.27 ms the events add - is
-  **2266 MHz**: a box that held 4.4 % less clock than any of these.  None of this round's boxes ({len(rows)} calls, {len(set(r[1] for r in rows if r[1] != '-'))} distinct GPU
-  serials) did, so WHY that box ran slower (power cap, temperature, a neighbour on the same node) cannot be shown from here; what
+  **2266 MHz**: a box that held 3 - 4.4 % less clock than these.  None of this round's boxes ({len(rows)} calls, {len(set(r[1] for r in rows if r[1] != '-'))} distinct GPU
+  serials) did - row `final` shows the mechanism at a third of the size (-1.1 % clock at +6 % power) -, so WHY that box ran slower still (a chip
+  further down the same curve, temperature, a neighbour on the same node) cannot be shown from here; what
   the line now guarantees is that the next such run explains itself: `last_launch_clock.s_memtime_mhz` would read ~2270,
   `frac_at_held_clock` would still read 0.94, and `box.during_timed_loops` would show the sclk / power the node allowed.
 * The other three candidates of the review are ruled out by construction: XCD / Infinity-Cache state would change the CYCLE count
   (it does not: see the first bullet); the prologue launch in front of the kernel is outside workgroup 0's stamps and inside the events
   (the 0.13 - 0.41 ms above, unchanged since round 4); a power cap shows as sclk below the probe's while power sits AT the cap (here:
-  1180 - 1230 W of 1400 W, never capped).
+  1180 - 1300 W median of 1400 W, never AT the cap; the highest sample of any row is 1362 W).
 """)
