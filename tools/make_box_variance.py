@@ -49,7 +49,7 @@ if cyc and mhz:
 * `frac` (against the 157.3 TFLOP/s data-sheet figure at 2.4 GHz) moves with the box: {min(r[7] for r in rows):.4f} - {max(r[7] for r in rows):.4f}.
   `frac_at_held_clock` does not: {min(r[9] for r in rows if r[9]):.4f} - {max(r[9] for r in rows if r[9]):.4f} - the kernel issues an MFMA on 94.0 - 94.1 % of the cycles it is given, everywhere.
 * The slowest box of the set explains itself: row `{slow[0]}` holds {slow[13]:.0f} MHz under the kernel (sysfs sclk median {slow[18]:.0f}) while
-  drawing {slow[19]:.0f} W median of the {slow[20]:.0f} W cap - the most of any row (the others: 1180 - 1235 W at 2357 - 2370 MHz) - and needs
+  drawing {slow[19]:.0f} W median of the {slow[20]:.0f} W cap - the most of any row (the others: {min(r[19] for r in rows if r is not slow and r[19]):.0f} - {max(r[19] for r in rows if r is not slow and r[19]):.0f} W at {min(r[13] for r in rows if r is not slow and r[13]):.0f} - {max(r[13] for r in rows if r is not slow and r[13]):.0f} MHz) - and needs
   {slow[6]:.2f} ms per launch, `frac` {slow[7]:.4f}: the same {slow[12] / 1e6:.2f} M cycles, `frac_at_held_clock` {slow[9]:.4f}.  A chip that needs more power for
   the same work is given less clock by the same power management; nothing about the kernel differs.
 * The probe (pure MFMA, no memory traffic) sustains 152.2 - 152.9 TFLOP/s before the timed loops (2338 - 2355 MHz: the chip has just left
@@ -58,7 +58,7 @@ if cyc and mhz:
   drives LDS and L2).
 * **Round 5's driver run (27.63 ms per launch, frac 0.879):** the same 62.0 M cycles in 27.63 ms - minus the ~0.27 ms the events add - is
   **2266 MHz**: a box that held 3 - 4.4 % less clock than these.  None of this round's boxes ({len(rows)} calls, {len(set(r[1] for r in rows if r[1] != '-'))} distinct GPU
-  serials) did - row `final` shows the mechanism at a third of the size (-1.1 % clock at +6 % power) -, so WHY that box ran slower still (a chip
+  serials) did - row `final` shows the mechanism at a third of the size (-1.1 % clock at +4 ... +10 % power) -, so WHY that box ran slower still (a chip
   further down the same curve, temperature, a neighbour on the same node) cannot be shown from here; what
   the line now guarantees is that the next such run explains itself: `last_launch_clock.s_memtime_mhz` would read ~2270,
   `frac_at_held_clock` would still read 0.94, and `box.during_timed_loops` would show the sclk / power the node allowed.
