@@ -1,24 +1,29 @@
-// lstm_coopw.hip - "wave-owned" column-split two-layer LSTM + Linear for 11 ... 42 row tiles per launch on gfx950 (round 5).
+// lstm_coopw.hip - "wave-owned" column-split two-layer LSTM + Linear for 11 ... 64 row tiles per launch on gfx950 (round 5; round 6: the
+// transposed product, the 96-unit instantiation, a rotating Linear owner).
 //
 // Same arithmetic as lstm.hip / lstm_coop.hip / lstm_coopn.hip (SequenceModel.forward's LSTM branch,
 // speech_enhance/audio_zen/model/module/sequence_model.py:113-123: nn.LSTM(input, hidden, 2) + Linear(hidden, 2)).
-// What it is for: B = 2 ... 8 utterances (17 ... 65 row tiles of 32 sequences).  Round 4 ran them on
+// What it is for: B = 2 ... 12 utterances (17 ... 97 row tiles of 32 sequences).  Round 4 ran them on
 //   * the K-split kernel (lstm_coop.hip) at 32 / 64 units per workgroup: the four waves of a workgroup split K, so every layer
 //     pass ends in an LDS reduction of four partial tiles, a cell phase spread over 256 threads and two workgroup barriers, and
 //   * the three-way split (lstm_coopn.hip: 128 units per workgroup): 65 row tiles x 3 = 195 of 256 CUs, serial schedule.
-// Here a WAVE owns 8 NT hidden units (NT = 1, 2 gate-interleaved 32-column accumulator tiles) over the FULL K, a workgroup 32 NT
-// units, and S = H / (32 NT) = 12 / 6 workgroups share a row tile: 17 row tiles x 12 = 204 CUs (B = 2), 41 x 6 = 246 (B = 5).
-// Nothing is shared between the waves of a workgroup, so the time loop has NO workgroup barrier:
-//   * column c of a tile = gate (c & 3) of unit (c >> 2): the accumulator tile goes through a wave-private LDS slice once
-//     ([32 rows][32 NT + 4] floats: ds_write_b32 conflict-free, the read-back ds_read_b128 = (i, f, g, o) of one cell,
-//     conflict-free); lane (row = lane & 31, hi = lane >> 5) owns the cells of units hi, hi + 2, hi + 4, hi + 6 of every tile -
-//     exactly the four floats of ITS slot of the exchange image, so h leaves as ONE 16-byte write-through store per tile;
+// Here a WAVE owns 8 NT hidden units (NT = 1, 2, 3 gate-interleaved 32-column accumulator tiles) over the FULL K, a workgroup 32 NT
+// units, and S = H / (32 NT) = 12 / 6 / 4 workgroups share a row tile: 17 row tiles x 12 = 204 CUs (B = 2), 41 x 6 = 246 (B = 5),
+// 64 x 4 = 256 (B = 8).  Nothing is shared between the waves of a workgroup, so the time loop has NO workgroup barrier:
+//   * the product is TRANSPOSED (round 6, w_mfma below): the weight fragment is the A operand, h / x the B operand.  Column c of a
+//     tile = gate (c & 3) of unit (c >> 2), so accumulator register q of lane (sequence = lane & 31, hi = lane >> 5) is gate q & 3 of
+//     unit hi + 2 (q >> 2): the lane holds (i, f, g, o) of ITS four cells of every tile in registers - the cell update reads the
+//     accumulators directly (round 5 took the tile through a wave-private LDS slice and back: that staging and its 2 x 32 NT LDS
+//     instructions per phase are gone, and with them the registers that made NT = 3 spill).  The four results are exactly the four
+//     floats of the lane's slot of the exchange image, so h leaves as ONE 16-byte write-through store per tile.  Same products in the
+//     same order as the round-5 kernel: bit-identical results;
 //   * the same lane / slot identity holds for the input: lane (row, hi) gathers features hi + 2 i of its row, which are the
 //     components of its own A fragments of the x k-groups - x never touches LDS.  The x k-groups are multiplied LAST in layer 0, the
 //     raw x_{t+1} is gathered into the same registers right behind them and normalised a whole phase pair later;
 //   * biases ride in the accumulator initialisation; the Linear(H, 2) partial of a wave is 4 NT lane-local FMAs + one
-//     cross-half add, two coalesced 128-byte stores per step; participant 0 sums the P partials of a step two phases later (loads
-//     issued in front of a cell phase, summed behind it);
+//     cross-half add, two coalesced 128-byte stores per step; ONE participant sums the P partials of a step two phases later (loads
+//     issued in front of a cell phase, summed behind it) - participant t mod P for step t (round 6: a fixed owner was the slowest wave
+//     of every phase);
 //   * layer-skewed schedule of lstm2_coop_skew_kernel with the WAVES as participants (P = 4 S per row tile): A_t = layer 0 of
 //     step t, C_t = layer 1; every wave runs A_0, [A_1, C_0], [A_2, C_1], ...; counter b0 counts finished A phases, b1 finished C
 //     phases; every wait is for an arrival that happened a whole phase earlier; h0 cycles through three images, h1 and the Linear
@@ -113,8 +118,9 @@ __device__ __forceinline__ void w_segment(f32x16 (&acc)[NT], float4 (&a)[D], flo
     }
 }
 
-constexpr int coopw_stride(int NT) { return 32 * NT + 4; }       // floats per row of a wave's staging tile (conflict-free both ways)
-// a wave's LDS slice: the staging tile [32][stride], the lane-private gather offsets [KX / 2][64] and Linear weights [2 NT][64][4]
+constexpr int coopw_stride(int NT) { return 32 * NT + 4; }       // floats per row of the round-5 staging tile
+// a wave's LDS slice: [32][stride] floats that were the staging tile of round 5 and now hold the lanes' bias quadruples ([2 layers][NT][2][4]
+// float4: the accumulator initialisation of the transposed product), the lane-private gather offsets [KX / 2][64] and Linear weights [2 NT][64][4]
 constexpr int coopw_slice_words(int NT, int KX) { return 32 * coopw_stride(NT) + (KX / 2) * 64 + 2 * NT * 256; }
 constexpr size_t coopw_smem_bytes(int NT, int KX) { return (size_t)4 * coopw_slice_words(NT, KX) * 4 + 32 * sizeof(RowDesc); }
 

@@ -26,8 +26,9 @@
 //     s_waitcnt vmcnt(0) behind that pass's x k-groups -> one relaxed arrival per wave; every wave polls for itself (the load is issued
 //     in front of a pass's last 8 k-groups and looked at behind them), then prefills its pipeline for the other half before its cells.
 // The time loop has no workgroup barrier, no LDS traffic except the lane-private gather offsets, and no staging.
-// Linear(H, 2): a wave's partial over its 4 units (two cross-lane adds), 128 bytes per participant and half-phase; wave 0 of workgroup
-// q < 16 sums the P partials of output row q in a fixed order a half-phase later (bitwise repeatable).
+// Linear(H, 2): a wave's partial over its 4 units (two cross-lane adds), 128 bytes per participant and half-phase; the 32 sums of a
+// half-phase (16 sequences x 2 outputs, each over the P partials in a fixed order: bitwise repeatable) are 32 jobs that ROTATE over the
+// participants a half-phase later - a fixed set of summing waves was the slowest of every pass and paced the launch (+0.39 us per half-phase).
 // 16x16x4 MFMAs in this operand order sum K like lstm_hp.hip does per accumulator (two chains per layer, added at the end): same oracle
 // tolerance, bit-identical to no sibling.
 #include <type_traits>
