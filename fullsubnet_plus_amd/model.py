@@ -15,6 +15,7 @@ The modules below only *hold parameters* with the reference's names; no torch op
 anything in ``forward``.  CPU tensors are rejected: there is deliberately no CPU fallback.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -100,6 +101,25 @@ class _SubBandParams(nn.Module):
         self.sequence_model = rnn(input_size, hidden, num_layers=2, batch_first=True)
         self.fc_output_layer = nn.Linear(hidden, output_size)
 
+    def __getstate__(self):              # (the back-reference is re-made by the owner: _HipModel._attach_holders; a weakref does not pickle)
+        state = self.__dict__.copy()
+        state.pop("_fsnp_owner", None)
+        return state
+
+    def forward(self, x):
+        """SequenceModel.forward (sequence_model.py:97-123) of the sub-band model as a call on the submodule, like the reference's
+        `self.sb_model(sb_input)` (fullsubnet_plus.py:203): x [N, input, T] -> [N, output, T] on the fused HIP kernels of the model that
+        owns this holder (fsnp_lstm2_fc).  No torch fallback: CPU tensors are refused like forward() refuses them."""
+        assert x.dim() == 3, f"The shape of input is {x.shape}."          # sequence_model.py:103
+        owner = self.__dict__.get("_fsnp_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError("this sub-band model holder is not attached to a fullsubnet_plus_amd model")
+        if not x.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; move the model and inputs to 'cuda'. "
+                               "There is deliberately no CPU fallback.")
+        return owner.lstm2_fc(x)
+
 
 class _HipState:
     """Owns the fsnp_handle (plain object: its finaliser must not go through nn.Module.__setattr__)."""
@@ -160,6 +180,16 @@ class _HipModel(nn.Module):
     """Everything the two reference models share on the HIP side: the fsnp_handle, lazy strict weight packing,
     the fsnp_forward call and the test / bench hooks.  Subclasses hold the reference's parameter tree and
     provide ``_config()``."""
+
+    def _attach_holders(self):
+        """The sub-band holder is callable like the reference's submodule (`model.sb_model(x)`): it needs to know whose kernels to run."""
+        sb = self._modules.get("sb_model")
+        if isinstance(sb, _SubBandParams):
+            sb.__dict__["_fsnp_owner"] = weakref.ref(self)
+
+    def __setstate__(self, state):          # copy.deepcopy / pickle: the copy's holder points at the copy
+        super().__setstate__(state)
+        self._attach_holders()
 
     def _init_hip(self):
         # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196,
@@ -825,6 +855,7 @@ class FullSubNet_Plus(_HipModel):
             self.sb_model = _FullBandParams(sb_in, 512, output_size)
         else:
             self.sb_model = _SubBandParams(sb_in, sb_model_hidden_size, output_size, sequence_model)
+            self._attach_holders()
         self.sequence_model = sequence_model
 
         self.subband_num = subband_num
@@ -919,6 +950,7 @@ class FullSubNet(_HipModel):
         self.fb_model = _FullBandLSTMParams(num_freqs, fb_model_hidden_size, sequence_model)
         self.sb_model = _SubBandParams((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), sb_model_hidden_size, 2,
                                        sequence_model)
+        self._attach_holders()
         self.sequence_model = sequence_model
 
         self.sb_num_neighbors = sb_num_neighbors

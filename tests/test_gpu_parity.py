@@ -1043,6 +1043,29 @@ def test_norm_and_unfold_stage_entry_points_vs_oracle(norm_type):
         assert np.array_equal(FullSubNet_Plus.unfold(xs.cuda(), nb).cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("kind", ["LSTM", "GRU"])
+def test_sub_band_model_is_callable_as_a_submodule(kind):
+    """`model.sb_model(x)` - the reference's `self.sb_model(sb_input)` (fullsubnet_plus.py:203; SequenceModel.forward, sequence_model.py:97-123)
+    as a call on the parameter holder: runs the owning model's fused kernels (fsnp_lstm2_fc), equals `model.lstm2_fc` bit for bit and the
+    oracle within the recurrent kernels' tolerance; a deep copy with other weights answers with ITS weights."""
+    import copy as _copy
+    args = {**DEFAULT_MODEL_ARGS, "sequence_model": kind}
+    sd = make_state_dict(5, "harsh", sequence_model=kind)
+    m = _model(args, sd)
+    rng = np.random.Generator(np.random.PCG64(77))
+    x = torch.from_numpy(rng.standard_normal((300, 34, 19)).astype(np.float32)).cuda()
+    got = m.sb_model(x)
+    assert got.shape == (300, 2, 19) and torch.equal(got, m.lstm2_fc(x))
+    want = fsnp_torch.lstm2_fc(x.cpu(), sd).numpy()                               # (the oracle tells LSTM from GRU by the weight shapes)
+    assert rel_err(got.cpu().numpy(), want) < 2e-5
+    twin = _copy.deepcopy(m)
+    with torch.no_grad():
+        twin.sb_model.fc_output_layer.weight.mul_(2.0)
+        twin.sb_model.fc_output_layer.bias.mul_(2.0)
+    assert rel_err(twin.sb_model(x).cpu().numpy(), 2.0 * want) < 2e-5          # the copy's kernels, the copy's weights (no output activation)
+    assert torch.equal(m.sb_model(x), got)                                       # ... and the original is untouched
+
+
 def test_weight_watch_registered_on_one_stream_forward_on_another():
     """fsnp_watch_weights queued its baseline fingerprint on the caller's stream without recording the handle's
     cross-stream event, so a forward on ANOTHER non-blocking stream could start its watch blocks (same ticket word, same baseline

@@ -713,6 +713,20 @@ def test_models_carry_the_reference_base_model_helpers():
             m.unfold(x, 2)
         with pytest.raises(AssertionError, match="four dim"):
             m.unfold(x[0], 2)
+        # the sub-band model is callable as a submodule, like the reference's `self.sb_model(sb_input)` (fullsubnet_plus.py:203,
+        # fullsubnet.py:114): it runs its OWNER's kernels, also after a deepcopy / a whole-module pickle round trip
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.sb_model(torch.zeros(3, m.sb_model.sequence_model.input_size, 4))
+        with pytest.raises(AssertionError, match="shape of input"):
+            m.sb_model(torch.zeros(3, 4))
+        twin = copy.deepcopy(m)
+        assert twin.sb_model.__dict__["_fsnp_owner"]() is twin and m.sb_model.__dict__["_fsnp_owner"]() is m
+        import io
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=False)
+        assert back.sb_model.__dict__["_fsnp_owner"]() is back and list(back.state_dict()) == list(m.state_dict())
     lib = _lib.load()
     st = (ctypes.c_int64 * 4)(1, 1, 1, 1)
     assert lib.fsnp_norm(9, 1, ctypes.byref(st), 1, 1, 1, 1, 1, None) == 2 and b"norm_type" in lib.fsnp_last_error()
