@@ -47,6 +47,8 @@ SYMBOLS = {
                                 c_i32, c_vp]),
     "fsnp_norm": (c_i32, [c_i32, c_vp, ctypes.POINTER(c_i64 * 4), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fsnp_unfold": (c_i32, [c_vp, ctypes.POINTER(c_i64 * 4), c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "fsnp_channel_attention": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, c_i32, c_i32, c_vp]),
+    "fsnp_fullband_model": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(c_i64 * 3), c_vp, c_i32, c_i32, c_vp]),
     "fsnp_lstm2_fc": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "fsnp_read_stage": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i64]),
     "fsnp_set_timing": (c_i32, [c_vp, c_i32]),

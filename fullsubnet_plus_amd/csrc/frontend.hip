@@ -495,4 +495,46 @@ void launch_frontend_mag(const Dims& d, int norm_type, const float* mag, const i
     hipLaunchKernelGGL(fe_scan_kernel, dim3(d.B, 1), dim3(256), 0, s, buf.frame, buf.md, d.B, d.Tp, d.F, norm_type);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-level entry (fsnp_channel_attention): ONE branch's channel attention on a caller's [B, F, T] tensor, as the reference calls the
+// submodule - `self.channel_attention(fb_input)` (fullsubnet_plus.py:160-165; ChannelTimeSenseSELayer.forward attention_model.py:78-101,
+// or the SE / ECA / CBAM layer the handle was configured with).  The input is whatever the caller normalised (or not): the kernels run on
+// their per-frame (m, d) path with the identity table.  `w` holds the branch's weights in slot 0.  (With subband_num > 1 the FORWARD
+// regroups the magnitude branch's channels around this call, fullsubnet_plus.py:146-153; the module itself never does: subband_num = 1 here.)
+__global__ void fe_identity_md_kernel(NormMD* __restrict__ md, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) md[i] = NormMD{0.0f, 1.0f};
+}
+void launch_attention_stage(const Dims& d, const FrontendWeights& w, const float* in, const int64_t strides[3],
+                            const FrontendBuffers& buf, hipStream_t s) {
+    StridedIn si;
+    for (int i = 0; i < 3; ++i) { si.p[i] = in; si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2]; }
+    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, buf.raw, nullptr, nullptr,
+                       d.B, d.T, d.Tp, d.F, d.FP);
+    const long nmd = (long)d.B * d.Tp;
+    hipLaunchKernelGGL(fe_identity_md_kernel, dim3((unsigned)((nmd + 255) / 256)), dim3(256), 0, s, buf.md, nmd);
+    const int frows = fsum_rows_per_wg(d.B);
+    const int fthreads = d.F <= 256 ? 256 : d.F >= 512 ? 512 : (d.F + 63) / 64 * 64;
+    hipLaunchKernelGGL(fe_fsum_kernel, dim3(cdiv(d.Tp, frows), d.B, 1), dim3(fthreads), 0, s, buf.raw, buf.md, buf.fsum, d.B, d.Tp, d.F, d.FP, frows);
+    GateArgs g;
+    g.w = w;
+    g.w.subband_num = 1;
+    g.raw = buf.raw; g.md = buf.md; g.fsum = buf.fsum; g.tot = buf.tot; g.gate = buf.gate;
+    g.B = d.B; g.Tp = d.Tp; g.F = d.F; g.FP = d.FP;
+    g.offline_norm = -1;
+    static PerDeviceOnce gate_once;
+    gate_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fe_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
+    hipLaunchKernelGGL(fe_gate_kernel, dim3(d.B, 1), dim3(kGateThreads), (size_t)(2 + 2 * 16 + 3) * d.FP * sizeof(float), s, g);
+    const long rows = (long)d.B * d.Tp, total = rows * d.FP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(fe_apply_kernel, dim3(blocks), dim3(256), 0, s, buf.raw, buf.md, buf.gate, buf.att, rows, d.Tp, d.F, d.FP);
+}
+// the time-major repack alone ([B, F, T] strided -> [B][T'][FP], pad columns and look-ahead rows zero): fsnp_fullband_model's input
+void launch_repack_plane(const Dims& d, const float* in, const int64_t strides[3], float* raw, hipStream_t s) {
+    StridedIn si;
+    for (int i = 0; i < 3; ++i) { si.p[i] = in; si.sb[i] = strides[0]; si.sf[i] = strides[1]; si.st[i] = strides[2]; }
+    hipLaunchKernelGGL(fe_repack_kernel, dim3(cdiv(d.FP, 32), cdiv(d.Tp, 32), d.B), dim3(256), 0, s, si, raw, nullptr, nullptr,
+                       d.B, d.T, d.Tp, d.F, d.FP);
+}
+
 }  // namespace fsnp

@@ -1306,6 +1306,90 @@ int fsnp_lstm2_fc(fsnp_handle* h, const float* x, float* out, int32_t num_seq, i
     return run_dense_plan(h, plan, x, out, num_seq, steps, s);
 }
 
+// ---- the forward's submodules as stages (include/fsnp.h: "third kind")
+static int stage_args_ok(const char* fn, const fsnp_handle* h, int32_t branch, const float* in, const int64_t* strides, const float* out, int32_t B, int32_t T) {
+    if (!h || !in || !strides || !out) { set_error("%s: null argument", fn); return 1; }
+    if (!h->committed) { set_error("%s: weights not committed", fn); return 4; }
+    if (h->model != FSNP_MODEL_FULLSUBNET_PLUS) { set_error("%s: FullSubNet+ handles only (the original FullSubNet has no attention layer and a recurrent full-band model)", fn); return 2; }
+    if (branch < 0 || branch > 2) { set_error("%s: branch must be 0 (magnitude), 1 (real) or 2 (imaginary)", fn); return 2; }
+    if (B <= 0 || T <= 0) { set_error("%s: empty input", fn); return 2; }
+    if ((double)B * T * std::max(h->FP, h->CH) * 4.0 > 2.0e9) { set_error("%s: input too large for 32-bit offsets", fn); return 2; }
+    return 0;
+}
+static Dims stage_dims(const fsnp_handle* h, int B, int T) {
+    Dims d{};
+    d.B = B; d.T = T; d.Tp = T; d.F = h->F; d.FP = h->FP; d.CH = h->CH; d.H = h->H; d.NIN = h->NIN; d.LA = 0;
+    return d;
+}
+
+int fsnp_channel_attention(fsnp_handle* h, int32_t branch, const float* in, const int64_t strides[3], float* out, int32_t batch,
+                           int32_t frames, void* hip_stream) {
+    if (const int rc = stage_args_ok("fsnp_channel_attention", h, branch, in, strides, out, batch, frames)) return rc;
+    if (branch == 0 && h->fw.subband_num > 1) {
+        set_error("fsnp_channel_attention: with subband_num > 1 the magnitude branch's layer runs on the tensor the forward regroups around it (fullsubnet_plus.py:146-153): not a stage");
+        return 2;
+    }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    FSNP_ON_DEVICE(h);
+    const Dims d = stage_dims(h, batch, frames);
+    const size_t plane = align_up((size_t)d.B * d.Tp * d.FP * 4, 256), md_b = align_up((size_t)d.B * d.Tp * sizeof(NormMD), 256);
+    const size_t fsum_b = align_up((size_t)d.B * d.FP * 8, 256), tot_b = align_up((size_t)d.B * 2 * 8, 256), gate_b = align_up((size_t)d.B * d.FP * 4, 256);
+    unsigned char* work = nullptr;
+    FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&work), 2 * plane + md_b + fsum_b + tot_b + gate_b, s));
+    FrontendBuffers buf{};
+    buf.raw = reinterpret_cast<float*>(work); buf.att = reinterpret_cast<float*>(work + plane);
+    buf.md = reinterpret_cast<NormMD*>(work + 2 * plane);
+    buf.fsum = reinterpret_cast<double*>(work + 2 * plane + md_b);
+    buf.tot = reinterpret_cast<double*>(work + 2 * plane + md_b + fsum_b);
+    buf.gate = reinterpret_cast<float*>(work + 2 * plane + md_b + fsum_b + tot_b);
+    FSNP_HIP_CHECK(hipMemsetAsync(buf.fsum, 0, fsum_b + tot_b, s));
+    FrontendWeights w = h->fw;                      // the branch's weights in slot 0 (the kernels index by grid.y)
+    for (int k = 0; k < 3; ++k) { w.conv_w[0][k] = h->fw.conv_w[branch][k]; w.conv_b[0][k] = h->fw.conv_b[branch][k]; }
+    w.cat_w[0] = h->fw.cat_w[branch]; w.cat_b[0] = h->fw.cat_b[branch];
+    w.fc1_wT[0] = h->fw.fc1_wT[branch]; w.fc1_b[0] = h->fw.fc1_b[branch];
+    w.fc2_wT[0] = h->fw.fc2_wT[branch]; w.fc2_b[0] = h->fw.fc2_b[branch];
+    launch_attention_stage(d, w, in, strides, buf, s);
+    launch_tm_to_bft(buf.att, out, d.B, d.T, d.Tp, d.F, d.FP, s);
+    FSNP_HIP_CHECK(hipGetLastError());
+    FSNP_HIP_CHECK(hipFreeAsync(work, s));
+    return 0;
+}
+
+int fsnp_fullband_model(fsnp_handle* h, int32_t branch, const float* in, const int64_t strides[3], float* out, int32_t batch,
+                        int32_t frames, void* hip_stream) {
+    if (const int rc = stage_args_ok("fsnp_fullband_model", h, branch, in, strides, out, batch, frames)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    FSNP_ON_DEVICE(h);
+    const Dims d = stage_dims(h, batch, frames);
+    const TcnWeights& t = h->tw;
+    const size_t plane = align_up((size_t)d.B * d.Tp * d.FP * 4, 256), yplane = align_up((size_t)d.B * d.Tp * d.CH * 4, 256);
+    const size_t gn_b = align_up((size_t)std::max(t.NB, 1) * 2 * d.B * kGnStride * 8, 256);
+    unsigned char* work = nullptr;
+    FSNP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&work), 3 * plane + 2 * yplane + gn_b, s));
+    TcnBuffers tb{};
+    float* att = reinterpret_cast<float*>(work);
+    tb.att = att; tb.x = reinterpret_cast<float*>(work + plane); tb.fb = reinterpret_cast<float*>(work + 2 * plane);
+    tb.y1 = reinterpret_cast<float*>(work + 3 * plane); tb.y2 = reinterpret_cast<float*>(work + 3 * plane + yplane);
+    tb.gn = reinterpret_cast<double*>(work + 3 * plane + 2 * yplane);
+    FSNP_HIP_CHECK(hipMemsetAsync(tb.gn, 0, gn_b, s));
+    // (the running activation's pad columns [F, FP) meet zero weights in every GEMM but must be finite: fresh pool memory is not)
+    FSNP_HIP_CHECK(hipMemsetAsync(tb.x, 0, 2 * plane, s));
+    TcnWeights wb = t;                              // this branch's slice of every [3][...] array (strides: launch_tcn)
+    const long nb = t.NB, br = branch;
+    wb.w1 += br * nb * t.N1P * t.K1P; wb.b1 += br * nb * t.N1P; wb.a1 += br * nb;
+    wb.g1w += br * nb * d.CH; wb.g1b += br * nb * d.CH; wb.dw += br * nb * 3 * d.CH; wb.db += br * nb * d.CH; wb.a2 += br * nb;
+    wb.g2w += br * nb * d.CH; wb.g2b += br * nb * d.CH;
+    wb.w2 += br * nb * t.N2P * t.K2P; wb.b2 += br * nb * t.N2P;
+    if (wb.w2g) { wb.w2g += br * nb * t.N2P * t.K2P; wb.c1 += br * nb * t.N2P; wb.c2 += br * nb * t.N2P; }
+    wb.wf += br * (long)t.N2P * t.K1P; wb.bf += br * t.N2P;
+    launch_repack_plane(d, in, strides, att, s);
+    launch_tcn(d, h->cfg.fb_act, wb, tb, s, 1);
+    launch_tm_to_bft(tb.fb, out, d.B, d.T, d.Tp, d.F, d.FP, s);
+    FSNP_HIP_CHECK(hipGetLastError());
+    FSNP_HIP_CHECK(hipFreeAsync(work, s));
+    return 0;
+}
+
 int fsnp_read_stage(fsnp_handle* h, const char* name, float* host_out, int64_t numel) {
     if (!h || !name || !host_out) { set_error("fsnp_read_stage: null argument"); return 1; }
     if (!h->have_last) { set_error("fsnp_read_stage: no forward has run"); return 2; }

@@ -83,6 +83,11 @@ struct FrontendBuffers {
     float* att;       // [3][B][Tp][FP]
 };
 
+// stage-level entry points (fsnp_channel_attention, fsnp_fullband_model): one branch on a caller's [B, F, T] tensor
+void launch_attention_stage(const Dims& d, const FrontendWeights& w_slot0, const float* in, const int64_t strides[3],
+                            const FrontendBuffers& buf, hipStream_t s);
+void launch_repack_plane(const Dims& d, const float* in, const int64_t strides[3], float* raw, hipStream_t s);
+void launch_tm_to_bft(const float* tm, float* out, int B, int T, int Tp, int F, int FP, hipStream_t s);       // stages.hip
 void launch_apply_cirm(const float* mask, const float* noisy, const int64_t strides[3], float* out,
                        const int64_t out_strides[3], int B, int F, int T, hipStream_t s);
 // is_complex: in[0] is the interleaved complex64 STFT buffer (strides[0] in complex elements); mag / real / imag are

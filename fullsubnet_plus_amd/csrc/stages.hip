@@ -88,6 +88,23 @@ __global__ __launch_bounds__(256) void stage_unfold_kernel(const float* __restri
     }
 }
 
+// [B][T'][FP] time-major plane (the layout of every full-band stage buffer) -> the caller's contiguous [B, F, T] (frames t < T)
+__global__ __launch_bounds__(256) void stage_tm_to_bft_kernel(const float* __restrict__ tm, float* __restrict__ out, int T, int Tp, int F, int FP) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, f0 = blockIdx.x * 32, t0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, f = f0 + tx;
+        tile[ty + 8 * i][tx] = (t < T && f < F) ? tm[((long)b * Tp + t) * FP + f] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = f0 + ty + 8 * i, t = t0 + tx;
+        if (f < F && t < T) out[((long)b * F + f) * T + t] = tile[tx][ty + 8 * i];
+    }
+}
+
 }  // namespace
 
 int launch_norm_stage(int norm_type, const float* in, const int64_t strides[4], float* out, int B, int C, int F, int T, hipStream_t s) {
@@ -113,6 +130,10 @@ void launch_unfold_stage(const float* in, const int64_t strides[4], float* out, 
     const long total = (long)B * F * C * (2 * N + 1) * T;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(stage_unfold_kernel, dim3(blocks), dim3(256), 0, s, in, st, out, C, F, T, N, total);
+}
+
+void launch_tm_to_bft(const float* tm, float* out, int B, int T, int Tp, int F, int FP, hipStream_t s) {
+    hipLaunchKernelGGL(stage_tm_to_bft_kernel, dim3(cdiv(F, 32), cdiv(T, 32), B), dim3(256), 0, s, tm, out, T, Tp, F, FP);
 }
 
 }  // namespace fsnp

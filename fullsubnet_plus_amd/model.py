@@ -39,7 +39,26 @@ nn.modules.module.register_module_parameter_registration_hook(_bump_tree_generat
 nn.modules.module.register_module_module_registration_hook(_bump_tree_generation)
 
 
-class _TSSEParams(nn.Module):
+class _StageHolder(nn.Module):
+    """A parameter holder that is CALLABLE like the reference's submodule: the call runs the owning model's HIP stage kernels on the branch
+    this holder belongs to (_HipModel._attach_holders sets owner, branch and the C entry point).  No torch fallback."""
+
+    def __getstate__(self):              # (the back-reference is re-made by the owner; a weakref does not pickle)
+        state = self.__dict__.copy()
+        for k in ("_fsnp_owner", "_fsnp_branch", "_fsnp_entry"):
+            state.pop(k, None)
+        return state
+
+    def forward(self, x):
+        owner = self.__dict__.get("_fsnp_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError(f"{self.__class__.__name__}: this parameter holder is not a callable stage of a fullsubnet_plus_amd model "
+                               "(only the full-band attention layers and TCN stacks of FullSubNet_Plus, and the sub-band recurrent model, are)")
+        return owner._stage_call(self.__dict__["_fsnp_entry"], self.__dict__["_fsnp_branch"], x)
+
+
+class _TSSEParams(_StageHolder):
     """Parameter holder named like ChannelTimeSenseSELayer (attention_model.py:49-76)."""
 
     def __init__(self, num_channels, kersize, reduction_ratio=2):
@@ -52,7 +71,7 @@ class _TSSEParams(nn.Module):
         self.fc2 = nn.Linear(reduced, num_channels)
 
 
-class _SEParams(nn.Module):
+class _SEParams(_StageHolder):
     """Parameter holder named like ChannelSELayer / ChannelCBAMLayer (attention_model.py:12-23, 302-313)."""
 
     def __init__(self, num_channels, reduction_ratio=2):
@@ -61,7 +80,7 @@ class _SEParams(nn.Module):
         self.fc2 = nn.Linear(num_channels // reduction_ratio, num_channels)
 
 
-class _ECAParams(nn.Module):
+class _ECAParams(_StageHolder):
     """Parameter holder named like ChannelECAlayer (attention_model.py:343-347)."""
 
     def __init__(self, k_size=3):
@@ -83,7 +102,7 @@ class _TCNBlockParams(nn.Module):
         self.sconv = nn.Conv1d(hidden, channels, 1)
 
 
-class _FullBandParams(nn.Module):
+class _FullBandParams(_StageHolder):
     """Parameter holder named like SequenceModel(sequence_model="TCN") (sequence_model.py:47-58,80-81)."""
 
     def __init__(self, num_freqs, hidden, output_size=None):
@@ -186,10 +205,33 @@ class _HipModel(nn.Module):
         sb = self._modules.get("sb_model")
         if isinstance(sb, _SubBandParams):
             sb.__dict__["_fsnp_owner"] = weakref.ref(self)
+        # FullSubNet+: the three attention layers and the three full-band TCN stacks (fullsubnet_plus.py:160-165, 171-173)
+        for branch, tag in enumerate(("", "_real", "_imag")):
+            for name, entry in (("channel_attention" + tag, "fsnp_channel_attention"), ("fb_model" + tag, "fsnp_fullband_model")):
+                mod = self._modules.get(name)
+                if isinstance(mod, _StageHolder) and not isinstance(mod, (_SubBandParams, _FullBandLSTMParams)):
+                    mod.__dict__.update(_fsnp_owner=weakref.ref(self), _fsnp_branch=branch, _fsnp_entry=entry)
 
     def __setstate__(self, state):          # copy.deepcopy / pickle: the copy's holder points at the copy
         super().__setstate__(state)
         self._attach_holders()
+
+    def _stage_call(self, entry, branch, x):
+        """One of the forward's submodules on a caller's [B, F, T] tensor (fsnp_channel_attention / fsnp_fullband_model)."""
+        assert x.dim() == 3, f"The shape of input is {x.shape}."
+        if not x.is_cuda:
+            raise RuntimeError("fullsubnet_plus_amd runs on MI355X (HIP) only; move the model and inputs to 'cuda'. "
+                               "There is deliberately no CPU fallback.")
+        assert x.shape[1] == self.num_freqs, f"expected {self.num_freqs} channels, got {x.shape[1]}"
+        lib = self._ensure_handle(x.device)
+        x = x if x.dtype == torch.float32 else x.float()
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        st = (ctypes.c_int64 * 3)(*x.stride())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(getattr(lib, entry)(self._handle, int(branch), x.data_ptr(), ctypes.byref(st), out.data_ptr(), x.shape[0], x.shape[2],
+                                           ctypes.c_void_p(stream)), entry)
+        return out
 
     def _init_hip(self):
         # "parity": B > 1 reproduces the reference's drop_band output [B,2,F//2,T] (fullsubnet_plus.py:192-196,
@@ -855,7 +897,7 @@ class FullSubNet_Plus(_HipModel):
             self.sb_model = _FullBandParams(sb_in, 512, output_size)
         else:
             self.sb_model = _SubBandParams(sb_in, sb_model_hidden_size, output_size, sequence_model)
-            self._attach_holders()
+        self._attach_holders()               # the submodules the forward calls are callable stages, like the reference's
         self.sequence_model = sequence_model
 
         self.subband_num = subband_num
@@ -909,7 +951,7 @@ class FullSubNet_Plus(_HipModel):
                              noisy_mag.device)
 
 
-class _FullBandLSTMParams(nn.Module):
+class _FullBandLSTMParams(_StageHolder):
     """Parameter holder named like SequenceModel(sequence_model="LSTM") of the original FullSubNet's full-band model
     (fullsubnet/model/fullsubnet.py:39-47; sequence_model.py:31-38,78-79)."""
 

@@ -19,7 +19,7 @@
  * All device work is enqueued on the caller's HIP stream; no device synchronisation
  * happens inside fsnp_forward.
  *
- * This header is the surface a maintainer of the reference binds (31 entry points).  Planner introspection, per-kernel timing,
+ * This header is the surface a maintainer of the reference binds (33 entry points).  Planner introspection, per-kernel timing,
  * stage read-back, calibration probes and every test / tuning hook live in fsnp_debug.h (same library, same ABI version).
  */
 #ifndef FSNP_H
@@ -206,6 +206,23 @@ int fsnp_norm(int32_t norm_type, const float* in, const int64_t strides[4], floa
               int32_t frames, void* hip_stream);
 int fsnp_unfold(const float* in, const int64_t strides[4], float* out, int32_t batch, int32_t channels, int32_t freqs, int32_t frames,
                 int32_t num_neighbor, void* hip_stream);
+
+/* Stage-level entry points, third kind: the SUBMODULES the reference's forward calls, one branch at a time, on a caller's tensor -
+ * what `model.channel_attention(x)` / `model.fb_model(x)` (and their `_real` / `_imag` siblings) are on the reference model object
+ * (fullsubnet_plus.py:160-165, 171-173).  FullSubNet+ handles only; branch 0 = magnitude, 1 = real, 2 = imaginary.
+ *   in  : DEVICE fp32 [B, F, T] with ELEMENT strides[3] (batch, freq, time);  out : DEVICE fp32 contiguous [B, F, T].
+ *   fsnp_channel_attention : the configured attention layer (ChannelTimeSenseSELayer.forward attention_model.py:78-101; ChannelSELayer
+ *                            :25-41, ChannelECAlayer :349-360, ChannelCBAMLayer :315-341) of that branch: in * gate.  With subband_num > 1
+ *                            the magnitude branch's layer is built for the regrouped tensor the FORWARD makes around it
+ *                            (fullsubnet_plus.py:146-153): not available as a stage (code 2).
+ *   fsnp_fullband_model    : SequenceModel.forward of the branch's full-band TCN stack (sequence_model.py:106-112: 8 TCNBlocks,
+ *                            ReLU, Linear, fb_output_activate_function).
+ * Same kernels as the forward's stages (the TCN GEMMs on the general kernel: one branch is not the three-branch DMA launch); scratch is
+ * stream-ordered (hipMallocAsync on hip_stream), nothing of the handle's forward workspace is touched, no synchronisation. */
+int fsnp_channel_attention(fsnp_handle* h, int32_t branch, const float* in, const int64_t strides[3], float* out, int32_t batch,
+                           int32_t frames, void* hip_stream);
+int fsnp_fullband_model(fsnp_handle* h, int32_t branch, const float* in, const int64_t strides[3], float* out, int32_t batch,
+                        int32_t frames, void* hip_stream);
 
 /* For bug reports: a text dump of the handle's configuration and of EVERY effective FSNP_* setting (the environment variables
  * are read at fsnp_create; the value in force is printed next to each).  Writes at most cap bytes (NUL-terminated) into buf

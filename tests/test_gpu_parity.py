@@ -1066,6 +1066,37 @@ def test_sub_band_model_is_callable_as_a_submodule(kind):
     assert torch.equal(m.sb_model(x), got)                                       # ... and the original is untouched
 
 
+@pytest.mark.parametrize("att", ["TSSE", "SE", "ECA", "CBAM"])
+def test_attention_layers_and_fullband_stacks_are_callable_as_submodules(att):
+    """`model.channel_attention(x)` / `model.fb_model(x)` and their `_real` / `_imag` siblings - what the reference's forward calls
+    (fullsubnet_plus.py:160-165, 171-173) - as calls on the parameter holders: fsnp_channel_attention / fsnp_fullband_model run ONE
+    branch's stage kernels on the caller's [B, F, T] tensor (contiguous, or strided like a view of the STFT), against the oracle's
+    restatement of the layers.  The full-band stacks are checked once (they do not depend on the attention kind)."""
+    args = {**DEFAULT_MODEL_ARGS, "channel_attention_model": att}
+    sd = make_state_dict(9, "harsh", attention=att)
+    m = _model(args, sd, "full")
+    rng = np.random.Generator(np.random.PCG64(123))
+    for branch, tag in enumerate(("", "_real", "_imag")):
+        for B, T in ((3, 37), (1, 130)):
+            x = torch.from_numpy(rng.standard_normal((B, 257, T)).astype(np.float32))
+            want = fsnp_torch.attention(x, sd, "channel_attention" + tag, att).numpy()
+            got = getattr(m, "channel_attention" + tag)(x.cuda())
+            assert got.shape == x.shape and rel_err(got.cpu().numpy(), want) < 2e-5, (att, tag, B, T, rel_err(got.cpu().numpy(), want))
+            xs = x.permute(0, 2, 1).contiguous().permute(0, 2, 1)            # same values, memory order [B][T][F]
+            assert not xs.is_contiguous() and torch.equal(getattr(m, "channel_attention" + tag)(xs.cuda()), got)
+            if att == "TSSE":
+                want_fb = fsnp_torch.fb_sequence_model(x, sd, "fb_model" + tag, "ReLU").numpy()
+                got_fb = getattr(m, "fb_model" + tag)(x.cuda())
+                e = rel_err(got_fb.cpu().numpy(), want_fb)
+                assert got_fb.shape == x.shape and e < 2e-4, (tag, B, T, e)
+                assert torch.equal(getattr(m, "fb_model" + tag)(xs.cuda()), got_fb)
+    # a forward before and after: the stage calls leave the handle's own workspace alone
+    ins = _cuda(make_inputs(2, 0.6, 5))
+    a = m(*ins).cpu().numpy()
+    m.fb_model(torch.zeros(1, 257, 9, device="cuda"))
+    assert np.array_equal(m(*ins).cpu().numpy(), a)
+
+
 def test_weight_watch_registered_on_one_stream_forward_on_another():
     """fsnp_watch_weights queued its baseline fingerprint on the caller's stream without recording the handle's
     cross-stream event, so a forward on ANOTHER non-blocking stream could start its watch blocks (same ticket word, same baseline

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"fsnp_handle", "fsnp_config"}
     # fsnp.h is the surface a maintainer binds: no test / tuning hook, no planner internals (those live in fsnp_debug.h)
     core_syms = set(re.findall(r"^[a-z][a-z0-9_ \*]*\b(fsnp_[a-z0-9_]+)\s*\(", core, flags=re.M))
-    assert not any(n.startswith("fsnp_debug_") for n in core_syms) and len(core_syms) <= 32, sorted(core_syms)
+    assert not any(n.startswith("fsnp_debug_") for n in core_syms) and len(core_syms) <= 34, sorted(core_syms)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -721,6 +721,16 @@ def test_models_carry_the_reference_base_model_helpers():
             m.sb_model(torch.zeros(3, 4))
         twin = copy.deepcopy(m)
         assert twin.sb_model.__dict__["_fsnp_owner"]() is twin and m.sb_model.__dict__["_fsnp_owner"]() is m
+        if isinstance(m, FullSubNet_Plus):      # ... and so are the attention layers and full-band stacks (fullsubnet_plus.py:160-165, 171-173)
+            for branch, tag in enumerate(("", "_real", "_imag")):
+                for name in ("channel_attention" + tag, "fb_model" + tag):
+                    holder = getattr(m, name)
+                    assert holder.__dict__["_fsnp_branch"] == branch and getattr(twin, name).__dict__["_fsnp_owner"]() is twin
+                    with pytest.raises(RuntimeError, match="no CPU fallback"):
+                        holder(torch.zeros(2, 257, 6))
+        else:                                   # (the original FullSubNet's full-band model is recurrent: no stage entry point, said so)
+            with pytest.raises(RuntimeError, match="not a callable stage"):
+                m.fb_model(torch.zeros(2, 257, 6))
         import io
         buf = io.BytesIO()
         torch.save(m, buf)
