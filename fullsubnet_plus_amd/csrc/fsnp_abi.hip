@@ -209,17 +209,44 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueArgs a) {
 // of one process) could each hold part of the chip and wait for peers that cannot be scheduled, so within a process
 // they are chained per device: each one waits for the previous one's completion event.  Other kernels always finish,
 // so they cannot close a cycle; a foreign PROCESS still can - that case ends in the kernels' wall-clock timeout.
+// Round 6: two such launches of ONE handle may run side by side when their workgroups - one per CU each - fit on the chip together
+// (`wgs` of both known, sum <= num_cus - 8): the pipelined loop's deferred remainder chunk of forward i (48 workgroups that own their CUs)
+// and the original FullSubNet's full-band LSTM of forward i + 1 (64 workgroups) used to wait for each other through this chain, which is
+// what kept FullSubNet at B = 32 above its 29 ms bar.  Both are resident at once whatever the dispatch order, so neither can wait for a CU
+// the other holds; everything else (other handles, unknown sizes, sums beyond the chip) is chained as before.
 static std::mutex g_coop_mu;
-static hipEvent_t g_coop_ev[64] = {};
-static bool g_coop_used[64] = {};
+struct CoopSlot { hipEvent_t ev = nullptr; bool used = false; const void* owner = nullptr; int wgs = 0; unsigned long long seq = 0; };
+static CoopSlot g_coop[64][2];
+static unsigned long long g_coop_seq = 0;
 template <typename F>
-static void launch_coop_chained(int dev, hipStream_t s, F launch) {
+static void launch_coop_chained(int dev, hipStream_t s, F launch, const void* owner = nullptr, int wgs = 0, int num_cus = 0) {
     if (dev < 0 || dev >= 64) { launch(); return; }
     std::lock_guard<std::mutex> lk(g_coop_mu);
-    if (g_coop_used[dev]) (void)hipStreamWaitEvent(s, g_coop_ev[dev], 0);
+    CoopSlot* sl = g_coop[dev];
+    const int order[2] = {sl[0].seq <= sl[1].seq ? 0 : 1, sl[0].seq <= sl[1].seq ? 1 : 0};      // older first
+    bool waited[2] = {false, false};
+    int beside = wgs;
+    for (int o = 0; o < 2; ++o) {
+        CoopSlot& c = sl[order[o]];
+        if (!c.used) continue;
+        const bool fits = owner && c.owner == owner && wgs > 0 && c.wgs > 0 && num_cus > 0 && beside + c.wgs <= num_cus - 8;
+        if (fits) beside += c.wgs;
+        else { (void)hipStreamWaitEvent(s, c.ev, 0); waited[order[o]] = true; }
+    }
     launch();
-    if (!g_coop_ev[dev] && hipEventCreateWithFlags(&g_coop_ev[dev], hipEventDisableTiming) != hipSuccess) { g_coop_ev[dev] = nullptr; return; }
-    g_coop_used[dev] = hipEventRecord(g_coop_ev[dev], s) == hipSuccess;
+    // the slot this launch takes: a free one, else one it waited for (that launch is behind it now), else one that has finished, else
+    // the older one - after waiting for it
+    int k = -1;
+    for (int i = 0; i < 2 && k < 0; ++i) if (!sl[i].used) k = i;
+    for (int o = 0; o < 2 && k < 0; ++o) if (waited[order[o]]) k = order[o];
+    for (int o = 0; o < 2 && k < 0; ++o) {
+        if (hipEventQuery(sl[order[o]].ev) == hipSuccess) k = order[o];
+        else (void)hipGetLastError();
+    }
+    if (k < 0) { k = order[0]; (void)hipStreamWaitEvent(s, sl[k].ev, 0); }
+    if (!sl[k].ev && hipEventCreateWithFlags(&sl[k].ev, hipEventDisableTiming) != hipSuccess) { sl[k].ev = nullptr; sl[k].used = false; return; }
+    sl[k].used = hipEventRecord(sl[k].ev, s) == hipSuccess;
+    sl[k].owner = owner; sl[k].wgs = wgs; sl[k].seq = ++g_coop_seq;
 }
 
 // The planner itself (cost table, launch shapes, shortest path over tile counts) is host-only code: planner.h / planner.cpp.
@@ -286,7 +313,7 @@ static void launch_sb_lstm(const fsnp_handle* h, const SbPlan& plan, const LstmA
             else if (c.kind == 9) launch_lstm_coopw(h->lw, ca, s);
             else if (c.kind == 1) launch_lstm_coop(h->lw, ca, s);
             else launch_lstm_coopn(h->lw, ca, s);
-        });
+        }, h, chunk_workgroups(h, c), h->num_cus_real);
     }
     if (after_first && last_chunk == nchunks) (void)hipEventRecord(after_first, s);
 }
@@ -1142,7 +1169,7 @@ static int forward_impl(fsnp_handle* h, const float* mag, const float* real, con
         fa.seq_stride = chp;
         if (h->generic_fb) { fa.coop_rows_per_group = fb_rg; launch_lstm_generic(h->fbw, fa, true, s); }
         else if (h->fb_valu && lstm_fbv_available(h->fbw, batch, h->num_cus_real)) launch_coop_chained(h->device, s, [&] { launch_lstm_fbv(h->fbw, fa, s); });   // B <= 4: VALU
-        else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); });
+        else launch_coop_chained(h->device, s, [&] { launch_lstm_coop_seq(h->fbw, fa, s); }, h, fa.coop_units > 0 ? fb_tiles * (h->CH / fa.coop_units) : 0, h->num_cus_real);
         launch_linear_act(fptr(w.y1), chp, h->fsn_wf, h->fsn_kp, h->fsn_bf, fptr(w.fb), d.FP, d.CH, d.F, d.B, d.Tp,
                           h->cfg.fb_act, h->num_cus, s);
         launch_subband_stats(d, h->cfg.norm_type, sbuf, rows, num_slots, s);
