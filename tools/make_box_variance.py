@@ -19,7 +19,8 @@ for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_box_*.json"))):
 f = lambda v, n=3: "-" if v is None else f"{v:.{n}f}"
 print("""# r06 - the headline on several boxes, each line with its own box calibration (VERDICT r05 item 1)
 
-One row per gpurun box (`tools/gpu_r06_box.sh <tag>`; row `final` = the evidence run `tools/gpu_r06_final.sh`): `python bench.py --gpus 1 --steps 20
+One row per gpurun box (`tools/gpu_r06_box.sh <tag>`, `tools/gpu_r06_head.sh <tag>`; row `final` = the first evidence run `tools/gpu_r06_final.sh`
+at 0e43fe7, row `I` = the same script at the round's HEAD): `python bench.py --gpus 1 --steps 20
 --warmup 5` exactly as the driver runs it.  Every field below is IN the bench line (`profiles/r06_box_<tag>.json`): the three timed runs and
 their median; `box.probe_before / probe_after` (50 ms of pure `v_mfma_f32_32x32x2_f32` on every SIMD, `csrc/box_probe.hip`) ->
 `box.mfma_peak_tflops` (the lower of the two) and `roofline.frac_of_box_peak`; `roofline.last_launch_clock` (the dominant kernel stamps
