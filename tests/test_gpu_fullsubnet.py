@@ -137,6 +137,31 @@ def test_fullsubnet_small_batches_run_the_full_band_lstm_on_the_valu(batch, seco
         assert err < TOL, err
 
 
+@pytest.mark.parametrize("batch", [32, 16])
+def test_fullsubnet_pipelined_loop_is_bit_identical(batch):
+    """fsnp_set_pipeline on the original FullSubNet: the deferred remainder chunk of forward i (side stream) and the full-band LSTM of
+    forward i + 1 (caller's stream) are both column-split launches.  Round 6 lets them run side by side (csrc/fsnp_abi.hip
+    launch_coop_chained: launches of ONE handle whose workgroups fit the chip together are not chained - B = 32: 29.7 -> 28.5 ms per
+    forward); the masks of a back-to-back loop over different inputs must be the plain call's, bit for bit, and no hand-off may time out."""
+    sd = make_state_dict_fullsubnet(0, "default")
+    m = _model(FULLSUBNET_MODEL_ARGS, sd, "full")
+    m.error_check = "deferred"
+    batches = [make_inputs(batch, 0.5, 700 + i)[0].cuda() for i in range(3)]
+    plain = [m(b).clone() for b in batches]
+    torch.cuda.synchronize()
+    assert any(c["deferred_when_pipelined"] for c in m.describe_plan(batch)), m.describe_plan(batch)
+    m.set_pipeline(True)
+    piped = [m(b) for b in batches * 4]
+    m.flush()
+    torch.cuda.synchronize()
+    m.poll_errors()
+    for a, b in zip(piped, plain * 4):
+        assert torch.equal(a, b)
+    m.set_pipeline(False)
+    assert torch.equal(m(batches[1]), plain[1])
+    m.check_errors()
+
+
 def test_fullsubnet_enhance_epilogue():
     sd = make_state_dict_fullsubnet(12, "default")
     mag, real, imag = make_inputs(2, 1.0, 32)
